@@ -1,0 +1,58 @@
+// Flattened, position-independent "match program" shared by the host compiler (compile.cpp), the HIP
+// kernels (kernels.hip) and the test-only host walker.  One blob = header + tables; all offsets are in
+// bytes from the start of the blob; the blob is uploaded to HBM as-is and staged into LDS by the kernels.
+//
+// What the tables encode (see DESIGN.md §3 for the derivation):
+//   * symbol classes: code points 0..0x1FFFFF partitioned by every segment boundary of the range-NFA
+//     (reference src/nfa/nfa_node_m.F90:410-501 `disjoin_nfa`), then columns merged when identical.
+//   * A  = forward ANCHORED DFA of the NFA (what `automaton%construct` would lazily build from the
+//          initial closure; reference src/automaton_m.F90:333-381).  State 0 = dead (DFA_INVALID_INDEX).
+//   * R  = reverse UNANCHORED DFA: scanning a row right-to-left, R is in a "hit" state at position p iff
+//          a NON-EMPTY match starts at p -- the set the reference enumerates with its restart loop
+//          (reference src/api_internal_m.F90:108-164), in one linear pass.
+#pragma once
+#include <stdint.h>
+
+#define FXP_MAGIC 0x31505846u /* "FXP1" */
+#define FXP_VERSION 3u
+
+enum FxpMode {
+   FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
+   FXP_MODE_SEARCH_ENGINE = 1,   // .in. / regex through the automaton
+   FXP_MODE_SEARCH_LITERAL = 2,  // .in. / regex: whole pattern is a literal -> raw byte INDEX (forgex.F90:111-130)
+   FXP_MODE_MATCH_ENGINE = 3,    // .match. (forgex.F90:163-231)
+};
+
+enum FxpFlags {
+   FXP_F_INIT_ACCEPTING = 1u << 0,  // initial DFA state accepts (empty-text rule, api_internal_m.F90:68-74,247-250)
+   FXP_F_PREFILTER = 1u << 1,       // prefix literal is not blank -> candidate-list driver (api_internal_m.F90:76-104)
+   FXP_F_HAS_SUFFIX = 1u << 2,      // suffix literal is not blank
+   FXP_F_FAST_OK = 1u << 3,         // <=8-state byte tables present and brute-force semantics proven equivalent
+   FXP_F_HAS_R = 1u << 4,           // reverse DFA present (else: bounded restart loop)
+   FXP_F_MATCH_LITERAL = 1u << 5,   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
+};
+
+struct FxpHeader {
+   uint32_t magic, version, mode, status, flags;
+   uint32_t n_classes, n_bounds, nA, nR;
+   uint32_t A_init, R_start, M_start;
+   uint32_t cls_nul, cls_ffff;
+   uint32_t len_prefix, len_suffix, len_all;
+   uint32_t fast_accA_min, fast_hitR_min, fast_R_start, fast_A_init;   // fast tables: state >= *_min <=> accepting / hit
+   uint32_t off_bounds;      // int32  [n_bounds]   ascending first code point of each interval (bounds[0] == 0)
+   uint32_t off_bound_cls;   // uint16 [n_bounds]   class of each interval
+   uint32_t off_ascii_cls;   // uint16 [128]
+   uint32_t off_TA;          // uint16 [nA * n_classes]   bit15 = destination accepts
+   uint32_t off_TR;          // uint16 [nR * n_classes]   bit15 = destination is a hit state
+   uint32_t off_accA;        // uint8  [nA]
+   uint32_t off_hitR;        // uint8  [nR]
+   uint32_t off_finalM;      // uint8  [nA]   .match. verdict of a state reached after the last text byte
+   uint32_t off_prefix, off_suffix, off_all;   // raw bytes
+   uint32_t off_fastA;       // uint8 [128][8]   next state of each of 8 states on an ASCII byte (fast path)
+   uint32_t off_fastR;       // uint8 [128][8]
+   uint32_t total_bytes;
+   uint32_t reserved[4];
+};
+
+#define FXP_STATE_MASK 0x7FFFu
+#define FXP_FLAG_BIT 0x8000u

@@ -1,0 +1,370 @@
+// Per-row match procedure over a compiled program (program.h).  This is the body of the GENERAL HIP
+// kernel (one wavefront lane = one row): it is written once, as templates over a row accessor, and is
+// compiled for the device by kernels.hip.  tests/support/host_walk.cpp compiles the same text for the
+// host as a TEST-ONLY harness (so table/driver logic can be checked without a GPU); the product library
+// never contains a host instantiation -- there is no CPU fallback.
+//
+// Reference behaviour reproduced here (file:line of the reference):
+//   search driver        src/api_internal_m.F90:31-167   (NUL wrapping, restart order, span arithmetic)
+//   full-match driver    src/api_internal_m.F90:171-303  (prefix/suffix gate, leading-NUL retry, verdict)
+//   candidate list       src/essential/utility_m.f90:58-117
+//   literal fast paths   src/forgex.F90:111-130, :207-213
+//   UTF-8 stepping       src/essential/utf8_m.f90:44-140, :168-246, :338-430 (structural validity only;
+//                        every byte of an invalid sequence is one U+FFFF symbol: api_internal_m.F90:129-133)
+#pragma once
+#include <stdint.h>
+
+#include "program.h"
+
+#if defined(__HIPCC__)
+#define FX_HD __device__ __forceinline__
+#else
+#define FX_HD inline
+#endif
+
+namespace fxrow {
+
+struct ProgView {
+   const uint8_t* base;
+   FX_HD const FxpHeader& h() const { return *reinterpret_cast<const FxpHeader*>(base); }
+   FX_HD int32_t bound(uint32_t i) const { return reinterpret_cast<const int32_t*>(base + h().off_bounds)[i]; }
+   FX_HD uint32_t bound_cls(uint32_t i) const { return reinterpret_cast<const uint16_t*>(base + h().off_bound_cls)[i]; }
+   FX_HD uint32_t ascii_cls(uint32_t b) const { return reinterpret_cast<const uint16_t*>(base + h().off_ascii_cls)[b]; }
+   FX_HD uint32_t TA(uint32_t s, uint32_t c) const { return reinterpret_cast<const uint16_t*>(base + h().off_TA)[s * h().n_classes + c]; }
+   FX_HD uint32_t TR(uint32_t s, uint32_t c) const { return reinterpret_cast<const uint16_t*>(base + h().off_TR)[s * h().n_classes + c]; }
+   FX_HD uint32_t finalM(uint32_t s) const { return (base + h().off_finalM)[s]; }
+   FX_HD uint32_t prefix(uint32_t i) const { return (base + h().off_prefix)[i]; }
+   FX_HD uint32_t suffix(uint32_t i) const { return (base + h().off_suffix)[i]; }
+   FX_HD uint32_t all(uint32_t i) const { return (base + h().off_all)[i]; }
+   FX_HD uint32_t class_of_code(int32_t code) const {
+      uint32_t lo = 0, hi = h().n_bounds;   // last interval whose first code point is <= code
+      while (hi - lo > 1) {
+         uint32_t mid = (lo + hi) >> 1;
+         if (bound(mid) <= code) lo = mid;
+         else hi = mid;
+      }
+      return bound_cls(lo);
+   }
+};
+
+FX_HD bool is_cont(uint32_t b) { return (b >> 6) == 2u; }
+FX_HD int lead_len(uint32_t b) {
+   if ((b >> 5) == 6u) return 2;
+   if ((b >> 4) == 14u) return 3;
+   if ((b >> 3) == 30u) return 4;
+   return 0;
+}
+template <class Row>
+FX_HD int32_t decode(const Row& r, int i, int n) {   // utf8_m.f90:338-430 (arithmetic, no range checks)
+   uint32_t b0 = r[i];
+   uint32_t code = n == 2 ? (b0 & 0x1Fu) : (n == 3 ? (b0 & 0x0Fu) : (b0 & 0x07u));
+   for (int k = 1; k < n; ++k) code = (code << 6) | (r[i + k] & 0x3Fu);
+   return static_cast<int32_t>(code);
+}
+
+// symbol that STARTS at 0-based text index j (a character start); L = text length
+template <class Row>
+FX_HD uint32_t fwd_symbol(const ProgView& pv, const Row& r, int L, int j, int& next) {
+   uint32_t b = r[j];
+   if (b < 0x80u) {
+      next = j + 1;
+      return pv.ascii_cls(b);
+   }
+   int n = lead_len(b);
+   if (n != 0 && j + n <= L) {
+      bool ok = true;
+      for (int k = 1; k < n; ++k) ok = ok && is_cont(r[j + k]);
+      if (ok) {
+         next = j + n;
+         return pv.class_of_code(decode(r, j, n));
+      }
+   }
+   next = j + 1;
+   return pv.h().cls_ffff;
+}
+
+// symbol that ENDS at 0-based text index j, given that j+1 is a character start (or the end of the text)
+template <class Row>
+FX_HD uint32_t back_symbol(const ProgView& pv, const Row& r, int j, int& start) {
+   uint32_t b = r[j];
+   start = j;
+   if (b < 0x80u) return pv.ascii_cls(b);
+   if (is_cont(b)) {
+      int n = 0;
+      if (j >= 1 && lead_len(r[j - 1]) == 2) n = 2;
+      else if (j >= 2 && is_cont(r[j - 1]) && lead_len(r[j - 2]) == 3) n = 3;
+      else if (j >= 3 && is_cont(r[j - 1]) && is_cont(r[j - 2]) && lead_len(r[j - 3]) == 4) n = 4;
+      if (n != 0) {
+         start = j - n + 1;
+         return pv.class_of_code(decode(r, start, n));
+      }
+   }
+   return pv.h().cls_ffff;
+}
+
+// byte i (1-based) of NUL // text // NUL
+template <class Row>
+FX_HD uint32_t wrapped(const Row& r, int L, int i) {
+   return (i == 1 || i == L + 2) ? 0u : r[i - 2];
+}
+
+// Longest non-empty match of the anchored automaton started at wrapped index `st` (1 <= st <= L+1).
+// Returns max_match exactly as api_internal_m.F90:119-137 computes it (0 = none).
+template <class Row>
+FX_HD int anchored_max_match(const ProgView& pv, const Row& r, int L, int st) {
+   const FxpHeader& h = pv.h();
+   uint32_t cur = h.A_init;
+   int mm = 0;
+   int j;   // 0-based text index of the next symbol
+   if (st == 1) {
+      uint32_t e = pv.TA(cur, h.cls_nul);
+      cur = e & FXP_STATE_MASK;
+      if (e & FXP_FLAG_BIT) mm = 2;
+      j = 0;
+   } else {
+      j = st - 2;
+   }
+   while (cur != 0 && j < L) {
+      int next;
+      uint32_t cls = fwd_symbol(pv, r, L, j, next);
+      uint32_t e = pv.TA(cur, cls);
+      cur = e & FXP_STATE_MASK;
+      j = next;
+      if (e & FXP_FLAG_BIT) mm = j + 2;
+   }
+   if (cur != 0) {   // trailing NUL
+      uint32_t e = pv.TA(cur, h.cls_nul);
+      if (e & FXP_FLAG_BIT) mm = L + 3;
+   }
+   return mm;
+}
+
+FX_HD void span_from(int start, int max_match, int L, int& from, int& to) {   // api_internal_m.F90:140-148
+   from = start - 1;
+   if (from == 0) from = 1;
+   to = (max_match >= L + 2) ? L : max_match - 2;
+}
+
+// first occurrence (1-based, 0 = none) of pat[0..m) in the wrapped string, searching wrapped indices >= lo
+template <class Row, class PatFn>
+FX_HD int find_wrapped(const Row& r, int L, PatFn pat, int m, int lo) {
+   for (int i = lo; i + m - 1 <= L + 2; ++i) {
+      bool ok = true;
+      for (int k = 0; ok && k < m; ++k) ok = wrapped(r, L, i + k) == pat(k);
+      if (ok) return i;
+   }
+   return 0;
+}
+
+struct Result {
+   uint32_t flag;   // verdict of `.in.` / `.match.`
+   int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none
+};
+
+template <class Row>
+FX_HD void search_engine(const ProgView& pv, const Row& r, int L, Result& out) {
+   const FxpHeader& h = pv.h();
+   out.flag = 0;
+   out.from = 0;
+   out.to = 0;
+   // api_internal_m.F90:68-74 -- `len(string) <= 1 .and. string == ''` : empty text, or ONE blank
+   if (L == 0 || (L == 1 && r[0] == 0x20u)) {
+      if (h.flags & FXP_F_INIT_ACCEPTING) out.flag = 1;   // ACCEPTED_EMPTY: .in. is true, regex() returns '' / 0 / 0
+      return;
+   }
+   bool brute = !(h.flags & FXP_F_PREFILTER);
+   int first = 0, suf_idx = -1;
+   const int lp = static_cast<int>(h.len_prefix), ls = static_cast<int>(h.len_suffix);
+   auto pre = [&](int k) { return pv.prefix(static_cast<uint32_t>(k)); };
+   auto suf = [&](int k) { return pv.suffix(static_cast<uint32_t>(k)); };
+   if (!brute) {
+      // get_index_list_forward, utility_m.f90:58-117 (first element only; the rest is generated on the fly below)
+      int idx = find_wrapped(r, L, pre, lp, 1);
+      if (ls == 0) {
+         suf_idx = L + 3;   // INDEX(text, '', back=.true.) == len(text)+1
+      } else {
+         suf_idx = -1;
+         for (int i = L + 2 - ls + 1; i >= 1; --i) {
+            bool ok = true;
+            for (int k = 0; ok && k < ls; ++k) ok = wrapped(r, L, i + k) == suf(k);
+            if (ok) {
+               suf_idx = i;
+               break;
+            }
+         }
+      }
+      if (idx > 0 && (suf_idx < 0 || idx <= suf_idx)) first = idx;
+      if (first == 0) brute = true;   // api_internal_m.F90:79-81
+   }
+   if (brute) {
+      int s = 0;
+      if (h.flags & FXP_F_HAS_R) {
+         uint32_t state = h.R_start;
+         int j = L - 1;
+         while (j >= 0) {
+            int start;
+            uint32_t cls = back_symbol(pv, r, j, start);
+            uint32_t e = pv.TR(state, cls);
+            state = e & FXP_STATE_MASK;
+            if (e & FXP_FLAG_BIT) s = start + 2;
+            j = start - 1;
+         }
+         uint32_t e = pv.TR(state, h.cls_nul);
+         if (e & FXP_FLAG_BIT) s = 1;
+         if (s == 0) return;
+         int mm = anchored_max_match(pv, r, L, s);
+         span_from(s, mm, L, out.from, out.to);
+      } else {
+         // bounded restart loop, api_internal_m.F90:108-155
+         int start = 1;
+         while (start < L + 2) {
+            int mm = anchored_max_match(pv, r, L, start);
+            if (mm > 0) {
+               span_from(start, mm, L, out.from, out.to);
+               s = start;
+               break;
+            }
+            if (start == 1) start = 2;
+            else {
+               int next;
+               (void)fwd_symbol(pv, r, L, start - 2, next);
+               start = next + 2;
+            }
+         }
+         if (s == 0) return;
+      }
+   } else {
+      // candidate-list driver, api_internal_m.F90:84-164
+      int suf2 = -1;
+      if (h.flags & FXP_F_HAS_SUFFIX) {
+         suf2 = 0;
+         for (int i = L - ls + 1; i >= 1; --i) {   // INDEX(string, suffix, back=.true.) on the UNWRAPPED text
+            bool ok = true;
+            for (int k = 0; ok && k < ls; ++k) ok = r[i - 1 + k] == suf(k);
+            if (ok) {
+               suf2 = i;
+               break;
+            }
+         }
+         if (suf2 == 0) return;
+      }
+      int cand = first;                 // index_list(i)
+      int offset = first + lp - 1;      // end of the last collected occurrence
+      bool more = true;                 // list construction still running
+      int start = (first == 2) ? 1 : first;
+      bool at_nul = (first == 2);
+      int found = 0, mm = 0;
+      while (start < L + 2) {
+         if (suf2 >= 0 && suf2 < start) break;
+         mm = anchored_max_match(pv, r, L, start);
+         if (mm > 0) {
+            found = start;
+            break;
+         }
+         if (at_nul) {
+            at_nul = false;
+            start = cand;
+            continue;
+         }
+         // next element of the index list
+         if (!more || !(offset < L + 2)) break;
+         int nxt = find_wrapped(r, L, pre, lp, offset + 1);
+         if (nxt == 0) break;
+         cand = nxt;
+         offset = nxt + lp - 1;
+         if (suf_idx >= 0 && offset > suf_idx) more = false;
+         start = cand;
+      }
+      if (found == 0) return;
+      span_from(found, mm, L, out.from, out.to);
+   }
+   if (out.from > 0 && out.to > 0) {
+      out.flag = 1;
+   } else {   // forgex.F90:152-156, :337-343
+      out.from = 0;
+      out.to = 0;
+   }
+}
+
+template <class Row>
+FX_HD void search_literal(const ProgView& pv, const Row& r, int L, Result& out) {   // forgex.F90:111-130, :281-307
+   const int m = static_cast<int>(pv.h().len_all);
+   out.flag = 0;
+   out.from = 0;
+   out.to = 0;
+   for (int i = 0; i + m <= L; ++i) {
+      bool ok = true;
+      for (int k = 0; ok && k < m; ++k) ok = r[i + k] == pv.all(static_cast<uint32_t>(k));
+      if (ok) {
+         out.flag = 1;
+         out.from = i + 1;
+         out.to = i + m;
+         return;
+      }
+   }
+}
+
+template <class Row>
+FX_HD void match_engine(const ProgView& pv, const Row& r, int L, Result& out) {   // forgex.F90:207-226 + api_internal_m.F90:171-303
+   const FxpHeader& h = pv.h();
+   out.flag = 0;
+   out.from = 0;
+   out.to = 0;
+   const int n = L, lp = static_cast<int>(h.len_prefix), ls = static_cast<int>(h.len_suffix);
+   if ((h.flags & FXP_F_MATCH_LITERAL) && n == static_cast<int>(h.len_all)) {
+      bool eq = true;
+      for (int k = 0; eq && k < n; ++k) eq = r[k] == pv.all(static_cast<uint32_t>(k));
+      out.flag = eq ? 1u : 0u;
+      return;
+   }
+   if (n > 0 && lp > 0 && lp == n) {   // :200-205 "prefix == whole string => true"
+      bool eq = true;
+      for (int k = 0; eq && k < n; ++k) eq = r[k] == pv.prefix(static_cast<uint32_t>(k));
+      if (eq) {
+         out.flag = 1;
+         return;
+      }
+   }
+   if (lp > n || ls > n) return;
+   const bool empty_pre = !(h.flags & FXP_F_PREFILTER), empty_post = !(h.flags & FXP_F_HAS_SUFFIX);
+   bool matches_pre = true, matches_post = true;
+   if (n > 0) {
+      if (!empty_pre)
+         for (int k = 0; matches_pre && k < lp; ++k) matches_pre = r[k] == pv.prefix(static_cast<uint32_t>(k));
+      if (!empty_post)
+         for (int k = 0; matches_post && k < ls; ++k) matches_post = r[n - ls + k] == pv.suffix(static_cast<uint32_t>(k));
+   } else {
+      matches_pre = lp == 0;
+      matches_post = ls == 0;
+   }
+   if (!((empty_pre || matches_pre) && (empty_post || matches_post))) return;
+   if (n == 0) {
+      out.flag = (h.flags & FXP_F_INIT_ACCEPTING) ? 1u : 0u;
+      return;
+   }
+   uint32_t cur = h.M_start;
+   int j = 0;
+   while (cur != 0 && j < L) {
+      int next;
+      uint32_t cls = fwd_symbol(pv, r, L, j, next);
+      cur = pv.TA(cur, cls) & FXP_STATE_MASK;
+      j = next;
+   }
+   out.flag = (cur != 0 && pv.finalM(cur)) ? 1u : 0u;
+}
+
+template <class Row>
+FX_HD void run_row(const ProgView& pv, const Row& r, int L, Result& out) {
+   switch (pv.h().mode) {
+      case FXP_MODE_SEARCH_ENGINE: search_engine(pv, r, L, out); break;
+      case FXP_MODE_SEARCH_LITERAL: search_literal(pv, r, L, out); break;
+      case FXP_MODE_MATCH_ENGINE: match_engine(pv, r, L, out); break;
+      default:
+         out.flag = 0;
+         out.from = 0;
+         out.to = 0;
+         break;
+   }
+}
+
+}   // namespace fxrow

@@ -1,0 +1,133 @@
+// TEST-ONLY harness: compiles the product's table compiler and its per-row match procedure
+// (forgex_amd/csrc/row_engine.hpp, the body of the general HIP kernel) for the HOST, so that table and
+// driver logic can be checked against the oracle in the CPU-only container.  It is not part of the
+// product library and is never used as a fallback: libforgex_amd.so has no host matching path.
+// Speaks the I/M/R/V protocol of oracle/ref_driver.f90 (answers "U <status>" for patterns the GPU build
+// does not support, e.g. DFA state explosion).
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../forgex_amd/csrc/compile.hpp"
+#include "../../forgex_amd/csrc/row_engine.hpp"
+
+namespace {
+struct HostRow {
+   const uint8_t* p;
+   uint32_t operator[](int j) const { return p[j]; }
+};
+std::string unhex(const std::string& h) {
+   if (h == "-") return std::string();
+   std::string s;
+   for (size_t i = 0; i + 1 < h.size(); i += 2) s.push_back(static_cast<char>(std::stoi(h.substr(i, 2), nullptr, 16)));
+   return s;
+}
+std::string tohex(const std::string& s) {
+   if (s.empty()) return "-";
+   static const char* d = "0123456789ABCDEF";
+   std::string h;
+   for (unsigned char ch : s) {
+      h.push_back(d[ch >> 4]);
+      h.push_back(d[ch & 15]);
+   }
+   return h;
+}
+}   // namespace
+
+extern "C" {
+// returns status; writes flag/from/to for ONE row
+int hw_run(const char* pat, int64_t plen, int op, const uint8_t* row, int64_t L, int32_t* flag, int32_t* from, int32_t* to) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
+   if (p.status != 0) return p.status;
+   fxrow::ProgView pv{p.blob.data()};
+   HostRow r{row};
+   fxrow::Result res;
+   fxrow::run_row(pv, r, static_cast<int>(L), res);
+   *flag = static_cast<int32_t>(res.flag);
+   *from = res.from;
+   *to = res.to;
+   return 0;
+}
+// batch with one compile (what the GPU path does)
+int hw_batch(const char* pat, int64_t plen, int op, const uint8_t* rows, int64_t n, int64_t L, uint8_t* flags, int32_t* from,
+             int32_t* to) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
+   if (p.status != 0) return p.status;
+   fxrow::ProgView pv{p.blob.data()};
+   for (int64_t i = 0; i < n; ++i) {
+      HostRow r{rows + i * L};
+      fxrow::Result res;
+      fxrow::run_row(pv, r, static_cast<int>(L), res);
+      flags[i] = static_cast<uint8_t>(res.flag);
+      if (from) from[i] = res.from;
+      if (to) to[i] = res.to;
+   }
+   return 0;
+}
+// program facts for tests: fills info[0..7] = mode, flags, nA, nR, n_classes, status, total_bytes, n_bounds
+void hw_info(const char* pat, int64_t plen, int op, int32_t* info) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
+   const FxpHeader& h = p.hdr();
+   info[0] = static_cast<int32_t>(h.mode);
+   info[1] = static_cast<int32_t>(h.flags);
+   info[2] = static_cast<int32_t>(h.nA);
+   info[3] = static_cast<int32_t>(h.nR);
+   info[4] = static_cast<int32_t>(h.n_classes);
+   info[5] = p.status;
+   info[6] = static_cast<int32_t>(h.total_bytes);
+   info[7] = static_cast<int32_t>(h.n_bounds);
+}
+}
+
+#ifdef HW_MAIN
+int main() {
+   std::string line;
+   while (std::getline(std::cin, line)) {
+      if (line.empty()) continue;
+      std::vector<std::string> f;
+      size_t p = 0;
+      while (p < line.size()) {
+         while (p < line.size() && line[p] == ' ') ++p;
+         if (p >= line.size()) break;
+         size_t q = line.find(' ', p);
+         if (q == std::string::npos) q = line.size();
+         f.push_back(line.substr(p, q - p));
+         p = q;
+      }
+      if (f.size() < 3) {
+         std::puts("E bad-line");
+         continue;
+      }
+      std::string pat = unhex(f[1]), txt = unhex(f[2]);
+      int op = f[0] == "M" ? fxc::OP_MATCH : fxc::OP_SEARCH;
+      int32_t flag = 0, from = 0, to = 0;
+      int st = 0;
+      if (f[0] == "V") {
+         fxc::Program pr = fxc::compile(pat, fxc::OP_SEARCH);
+         std::printf("V %c\n", (pr.status == 0 || pr.status >= 100) ? 'T' : 'F');
+         std::fflush(stdout);
+         continue;
+      }
+      st = hw_run(pat.data(), static_cast<int64_t>(pat.size()), op, reinterpret_cast<const uint8_t*>(txt.data()),
+                  static_cast<int64_t>(txt.size()), &flag, &from, &to);
+      if (st >= 100) {
+         std::printf("U %d\n", st);
+      } else if (f[0] == "I" || f[0] == "M") {
+         std::printf("%s %c\n", f[0].c_str(), (st == 0 && flag) ? 'T' : 'F');
+      } else if (f[0] == "R") {
+         if (st != 0) {
+            std::printf("R -9999 -9999 0 %d -\n", st);
+         } else {
+            bool m = from > 0 && to > 0;
+            std::string sub = m ? txt.substr(static_cast<size_t>(from - 1), static_cast<size_t>(to - from + 1)) : std::string();
+            std::printf("R %d %d %d 0 %s\n", m ? from : 0, m ? to : 0, m ? to - from + 1 : 0, tohex(sub).c_str());
+         }
+      } else {
+         std::puts("E bad-op");
+      }
+      std::fflush(stdout);
+   }
+   return 0;
+}
+#endif
