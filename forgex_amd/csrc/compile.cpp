@@ -463,6 +463,17 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    return finish(h, bl);
 }
 
+Program make_search_literal(const std::string& all) {
+   Blob bl;
+   bl.b.assign(sizeof(FxpHeader), 0);
+   FxpHeader h;
+   std::memset(&h, 0, sizeof(h));
+   h.mode = FXP_MODE_SEARCH_LITERAL;
+   h.len_all = static_cast<uint32_t>(all.size());
+   h.off_all = bl.put(all.data(), all.size());
+   return finish(h, bl);
+}
+
 Program compile(const std::string& pattern, int op, const Limits& lim) {
    std::string buff;
    if (op == OP_SEARCH) {
@@ -484,16 +495,7 @@ Program compile(const std::string& pattern, int op, const Limits& lim) {
    tree.build(buff);
    if (!tree.is_valid) return invalid_program(tree.code);
    Literals lit = extract_literal(tree);
-   if (op == OP_SEARCH && !f_eq(lit.all, "")) {   // forgex.F90:111-130, :281-307
-      Blob bl;
-      bl.b.assign(sizeof(FxpHeader), 0);
-      FxpHeader h;
-      std::memset(&h, 0, sizeof(h));
-      h.mode = FXP_MODE_SEARCH_LITERAL;
-      h.len_all = static_cast<uint32_t>(lit.all.size());
-      h.off_all = bl.put(lit.all.data(), lit.all.size());
-      return finish(h, bl);
-   }
+   if (op == OP_SEARCH && !f_eq(lit.all, "")) return make_search_literal(lit.all);   // forgex.F90:111-130, :281-307
    Nfa nfa = build_nfa(tree, lim.max_nfa_states);
    return compile_from_nfa(nfa, lit, op, lim);
 }

@@ -34,4 +34,7 @@ Program compile(const std::string& pattern, int op, const Limits& lim = Limits()
 // the NFA of reference `nfa_graph_t` after `build_nfa_graph`, plus the three literals of `extract_literal`.
 Program compile_from_nfa(const fxfe::Nfa& nfa, const fxfe::Literals& lit, int op, const Limits& lim = Limits());
 
+// whole-pattern literal for `.in.` / regex: raw-byte INDEX (forgex.F90:111-130, :281-307)
+Program make_search_literal(const std::string& all);
+
 }   // namespace fxc

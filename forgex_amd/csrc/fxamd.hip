@@ -1,0 +1,539 @@
+// libforgex_amd.so: HIP kernels (gfx950 / CDNA4) + the C ABI of include/forgex_amd.h.
+//
+// Two kernel families:
+//   fx_search_fast<CH>   the hot kernel.  One wavefront owns a tile of 64 consecutive rows (64 x 16*CH bytes,
+//                        contiguous in HBM): 16-byte/lane coalesced global loads -> XOR-swizzled ds_write_b128
+//                        -> transposed ds_read_b128 so that lane r holds row r.  The per-byte state advance is
+//                        ONE ds_read_b64 of the fused byte table F[byte] (8 next-state bytes, independent of the
+//                        state, so lookups pipeline) + ONE v_perm_b32 (state selects its byte).  Right-to-left
+//                        pass with the reverse DFA finds the leftmost match start, a short left-to-right pass with
+//                        the anchored DFA finds the longest end.  No MFMA: table lookup, not a contraction.
+//   fx_general           one lane = one row through fxrow::run_row (row_engine.hpp): every mode, UTF-8 decode
+//                        on device, candidate-list driver, literal search, `.match.`; also the fix-up pass for
+//                        rows the fast kernel flags as non-ASCII.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/forgex_amd.h"
+#include "compile.hpp"
+#include "program.h"
+#include "row_engine.hpp"
+
+#define FX_NEEDS_GENERAL 0xFFu   // marker the fast kernel leaves in flags[] for rows with a byte >= 0x80
+
+// =========================================================================================================
+// tile staging: 64 rows x (16*CH) bytes, HBM -> LDS, transposed so each lane reads its own row conflict-free
+// cell(R, k) = k*64 + (R ^ (k & 63))   [16-byte cells]; chunk k of row R.
+// =========================================================================================================
+__device__ __forceinline__ uint32_t tile_cell(uint32_t R, uint32_t k) { return (k << 6) + (R ^ (k & 63u)); }
+
+template <int CH>
+__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint4* tile, uint32_t lane) {
+   // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH
+   const uint4* src = reinterpret_cast<const uint4*>(rows + row0 * (int64_t)(16 * CH));
+   const int64_t rows_left = n - row0;
+   const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (uint32_t)rows_left * CH;
+   uint4 v[CH];
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      uint32_t p = q * 64 + lane;
+      v[q] = p < valid_pieces ? src[p] : make_uint4(0, 0, 0, 0);
+   }
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      uint32_t p = q * 64 + lane;
+      uint32_t R = p / CH, k = p % CH;
+      tile[tile_cell(R, k)] = v[q];
+   }
+}
+
+// =========================================================================================================
+// fast search kernel
+// =========================================================================================================
+struct FastParams {
+   uint32_t R_start, A_init, hit_min, acc_min;
+};
+
+// 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
+__device__ __forceinline__ void lookup8(uint2 (&f)[8], uint32_t lo, uint32_t hi, const uint2* __restrict__ tab) {
+#pragma unroll
+   for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
+}
+
+// right-to-left state chain over 8 bytes; records the lowest byte index whose state is a hit
+__device__ __forceinline__ void chain8_back(const uint2 (&f)[8], uint32_t& state, uint32_t& s, uint32_t hit_min, int base) {
+   uint32_t loc = 8;
+#pragma unroll
+   for (int i = 7; i >= 0; --i) {
+      state = __builtin_amdgcn_perm(f[i].y, f[i].x, state) & 0xFFu;
+      loc = state >= hit_min ? (uint32_t)i : loc;
+   }
+   s = loc != 8u ? (uint32_t)(base + 2) + loc : s;
+}
+
+template <int CH, bool SPANS>
+__global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+                                                        FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
+                                                        int32_t* __restrict__ to) {
+   constexpr int L = 16 * CH;
+   __shared__ uint2 tabR[256];
+   __shared__ uint2 tabA[256];
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   {
+      const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
+      const uint2* gA = reinterpret_cast<const uint2*>(prog + h->off_fastA);
+      uint32_t t = threadIdx.x;   // 256 threads: entries 0..127 real, 128..255 dead (rows with such bytes are redone)
+      tabR[t] = t < 128 ? gR[t] : make_uint2(0, 0);
+      tabA[t] = t < 128 ? gA[t] : make_uint2(0, 0);
+   }
+   __syncthreads();
+   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   uint4* tile = tiles + wave * (64 * CH);
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+
+   for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
+      const int64_t row0 = t << 6;
+      stage_tile<CH>(rows, row0, n, tile, lane);
+      // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
+
+      // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
+      // software pipeline: table lookups of chunk k-1 are in flight while the state chain of chunk k runs
+      uint32_t state = fp.R_start;
+      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
+      uint32_t na = 0;
+      // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
+      // expressible) while the state chain of the current group runs
+      uint2 fa[8], fb[8];
+      uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
+      if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+      lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll
+      for (int k = CH - 1; k >= 0; --k) {
+         na |= wk.x | wk.y | wk.z | wk.w;
+         lookup8(fb, wk.x, wk.y, tabR);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_back(fa, state, s, fp.hit_min, k * 16 + 8);
+         __builtin_amdgcn_sched_barrier(0);
+         if (k >= 1) {
+            wk = wn;
+            lookup8(fa, wk.z, wk.w, tabR);
+            if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+         }
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_back(fb, state, s, fp.hit_min, k * 16);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+         uint2 f = tabR[0];   // leading NUL
+         state = __builtin_amdgcn_perm(f.y, f.x, state) & 0xFFu;
+         s = state >= fp.hit_min ? 1u : s;
+      }
+      const bool nonascii = (na & 0x80808080u) != 0;
+      const int64_t row = row0 + lane;
+
+      // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
+      // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk
+      uint32_t cur = (s != 0 && !nonascii && (SPANS || s == 1)) ? fp.A_init : 0u;
+      uint32_t mm = 0;                      // max_match (wrapped index of the byte after the longest match)
+      uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
+      if (s == 1) {
+         uint2 f = tabA[0];
+         cur = __builtin_amdgcn_perm(f.y, f.x, cur) & 0xFFu;
+         mm = cur >= fp.acc_min ? 2u : 0u;
+      }
+      while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         if (cur != 0) {
+            const uint32_t jal = j & ~7u;                  // 8 bytes per round trip: one row read + 8 table lookups
+            const uint32_t k = jal >> 4;
+            const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, k) << 4) + (jal & 15u));
+            uint2 f[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] = tabA[((q < 4 ? rw.x : rw.y) >> ((q & 3) * 8)) & 0xFFu];
+            uint32_t loc = 0;                               // 1 + index of the last accepting byte in this group
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               const uint32_t nx = __builtin_amdgcn_perm(f[q].y, f[q].x, cur) & 0xFFu;
+               cur = jal + q >= j ? nx : cur;
+               loc = (jal + q >= j && cur >= fp.acc_min) ? (uint32_t)(q + 1) : loc;
+            }
+            mm = loc != 0 ? jal + loc + 2 : mm;
+            j = jal + 8;
+            if (j >= (uint32_t)L && cur != 0) {             // trailing NUL, then stop
+               uint2 fz = tabA[0];
+               cur = __builtin_amdgcn_perm(fz.y, fz.x, cur) & 0xFFu;
+               mm = cur >= fp.acc_min ? (uint32_t)L + 3 : mm;
+               cur = 0;
+            }
+         }
+      }
+      uint32_t flag = 0;
+      int32_t fr = 0, tt = 0;
+      if (SPANS) {
+         if (s != 0 && mm != 0) {   // api_internal_m.F90:140-148
+            fr = (int32_t)(s - 1);
+            if (fr == 0) fr = 1;
+            tt = mm >= (uint32_t)L + 2 ? L : (int32_t)mm - 2;
+            if (fr > 0 && tt > 0) flag = 1;
+            else { fr = 0; tt = 0; }
+         }
+      } else {
+         flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
+      }
+      if (nonascii) flag = FX_NEEDS_GENERAL;
+      if (row < n) {
+         flags[row] = (uint8_t)flag;
+         if (SPANS) {
+            from[row] = fr;
+            to[row] = tt;
+         }
+      }
+   }
+}
+
+// =========================================================================================================
+// general kernel: one lane = one row, fxrow::run_row
+// =========================================================================================================
+struct GlobalRow {
+   const uint8_t* p;
+   __device__ __forceinline__ uint32_t operator[](int j) const { return p[j]; }
+};
+struct TileRow {
+   const uint8_t* tb;
+   uint32_t lane;
+   __device__ __forceinline__ uint32_t operator[](int j) const {
+      uint32_t k = (uint32_t)j >> 4;
+      return tb[(tile_cell(lane, k) << 4) + ((uint32_t)j & 15u)];
+   }
+};
+
+// fixup != 0: only rows whose flag is FX_NEEDS_GENERAL are processed
+__global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
+                                                   uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
+                                                   int fixup) {
+   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (row >= n) return;
+   if (fixup && flags[row] != FX_NEEDS_GENERAL) return;
+   fxrow::ProgView pv{prog};
+   GlobalRow r{rows + row * (int64_t)L};
+   fxrow::Result res;
+   fxrow::run_row(pv, r, L, res);
+   flags[row] = (uint8_t)res.flag;
+   if (from) from[row] = res.from;
+   if (to) to[row] = res.to;
+}
+
+// LDS-staged variant for 16-byte-multiple rows: one wave per block, dynamic LDS = 64*L bytes (L <= 1024)
+__global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
+                                                        uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to) {
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
+   const uint32_t lane = threadIdx.x;
+   const int CH = L >> 4;
+   const int64_t row0 = (int64_t)blockIdx.x << 6;
+   const uint4* src = reinterpret_cast<const uint4*>(rows + row0 * (int64_t)L);
+   const int64_t rows_left = n - row0;
+   const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (uint32_t)rows_left * CH;
+   for (int q = 0; q < CH; ++q) {
+      uint32_t p = q * 64 + lane;
+      uint4 v = p < valid_pieces ? src[p] : make_uint4(0, 0, 0, 0);
+      tiles[tile_cell(p / CH, p % CH)] = v;
+   }
+   __syncthreads();
+   const int64_t row = row0 + lane;
+   if (row >= n) return;
+   fxrow::ProgView pv{prog};
+   TileRow r{reinterpret_cast<const uint8_t*>(tiles), lane};
+   fxrow::Result res;
+   fxrow::run_row(pv, r, L, res);
+   flags[row] = (uint8_t)res.flag;
+   if (from) from[row] = res.from;
+   if (to) to[row] = res.to;
+}
+
+__global__ void fx_fill(uint8_t* flags, int32_t* from, int32_t* to, int64_t n) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   flags[i] = 0;
+   if (from) from[i] = 0;
+   if (to) to[i] = 0;
+}
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+struct fxamd_program {
+   fxc::Program prog;
+   std::mutex mu;
+   int device = -1;
+   uint8_t* d_blob = nullptr;
+   int last_path = 0;
+};
+
+static thread_local int g_last_hip_error = 0;
+static int hip_fail(hipError_t e) {
+   g_last_hip_error = (int)e;
+   return FXAMD_E_HIP;
+}
+#define FX_HIP(call)                                  \
+   do {                                               \
+      hipError_t _e = (call);                         \
+      if (_e != hipSuccess) return hip_fail(_e);      \
+   } while (0)
+
+template <int CH>
+static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
+                              int32_t* to, hipStream_t st) {
+   const int64_t n_tiles = (n + 63) >> 6;
+   int64_t blocks = (n_tiles + 3) / 4;
+   const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
+   if (blocks > cap) blocks = cap;
+   const size_t lds = (size_t)4 * 64 * CH * 16;
+   if (from && to)
+      hipLaunchKernelGGL((fx_search_fast<CH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to);
+   else
+      hipLaunchKernelGGL((fx_search_fast<CH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to);
+   return hipGetLastError();
+}
+
+extern "C" {
+
+int fxamd_last_hip_error(void) { return g_last_hip_error; }
+int fxamd_device_count(void) {
+   int c = 0;
+   if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+   return c;
+}
+
+int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status) {
+   if (!out || pattern_len < 0 || (!pattern && pattern_len > 0) || (op != FXAMD_OP_SEARCH && op != FXAMD_OP_MATCH)) return FXAMD_E_ARG;
+   fxamd_program* p = new (std::nothrow) fxamd_program();
+   if (!p) return FXAMD_E_NOMEM;
+   try {
+      p->prog = fxc::compile(std::string(pattern ? pattern : "", (size_t)pattern_len), op);
+   } catch (const std::bad_alloc&) {
+      delete p;
+      return FXAMD_E_NOMEM;
+   }
+   if (status) *status = p->prog.status;
+   *out = p;
+   return FXAMD_OK;
+}
+
+int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64_t n_transitions, const int32_t* src, const int32_t* dst,
+                      const int64_t* seg_begin, const int32_t* seg_min, const int32_t* seg_max, const char* lit_all, int64_t len_all,
+                      const char* lit_prefix, int64_t len_prefix, const char* lit_suffix, int64_t len_suffix, int op, fxamd_program** out,
+                      int32_t* status) {
+   if (!out || n_states < 2 || entry < 1 || entry > n_states || exit_state < 1 || exit_state > n_states || n_transitions < 0) return FXAMD_E_ARG;
+   if (n_transitions > 0 && (!src || !dst || !seg_begin || !seg_min || !seg_max)) return FXAMD_E_ARG;
+   if (op != FXAMD_OP_SEARCH && op != FXAMD_OP_MATCH) return FXAMD_E_ARG;
+   fxfe::Nfa nfa;
+   nfa.nfa_top = n_states;
+   nfa.entry = entry;
+   nfa.exit = exit_state;
+   nfa.nodes.resize((size_t)n_states + 1);
+   for (int64_t t = 0; t < n_transitions; ++t) {
+      if (src[t] < 1 || src[t] > n_states || dst[t] < 1 || dst[t] > n_states || seg_begin[t + 1] < seg_begin[t]) return FXAMD_E_ARG;
+      fxfe::NfaTransition tr;
+      tr.dst = dst[t];
+      for (int64_t k = seg_begin[t]; k < seg_begin[t + 1]; ++k) tr.c.emplace_back(seg_min[k], seg_max[k]);
+      tr.c_top = (int)tr.c.size();
+      nfa.nodes[(size_t)src[t]].forward.push_back(tr);
+   }
+   fxfe::Literals lit;
+   lit.all.assign(lit_all ? lit_all : "", (size_t)(lit_all ? len_all : 0));
+   lit.prefix.assign(lit_prefix ? lit_prefix : "", (size_t)(lit_prefix ? len_prefix : 0));
+   lit.suffix.assign(lit_suffix ? lit_suffix : "", (size_t)(lit_suffix ? len_suffix : 0));
+   fxamd_program* p = new (std::nothrow) fxamd_program();
+   if (!p) return FXAMD_E_NOMEM;
+   if (op == FXAMD_OP_SEARCH && !fxfe::f_eq(lit.all, ""))
+      p->prog = fxc::make_search_literal(lit.all);   // whole-pattern literal: raw-byte INDEX path (forgex.F90:111-130)
+   else
+      p->prog = fxc::compile_from_nfa(nfa, lit, op);
+   if (status) *status = p->prog.status;
+   *out = p;
+   return FXAMD_OK;
+}
+
+void fxamd_program_free(fxamd_program* p) {
+   if (!p) return;
+   if (p->d_blob) (void)hipFree(p->d_blob);
+   delete p;
+}
+int32_t fxamd_program_status(const fxamd_program* p) { return p ? p->prog.status : FXAMD_E_ARG; }
+int64_t fxamd_program_blob_size(const fxamd_program* p) { return p ? (int64_t)p->prog.blob.size() : FXAMD_E_ARG; }
+int fxamd_program_blob(const fxamd_program* p, void* buf, int64_t capacity) {
+   if (!p || !buf || capacity < (int64_t)p->prog.blob.size()) return FXAMD_E_ARG;
+   std::memcpy(buf, p->prog.blob.data(), p->prog.blob.size());
+   return FXAMD_OK;
+}
+int fxamd_program_from_blob(const void* blob, int64_t size, fxamd_program** out) {
+   if (!blob || !out || size < (int64_t)sizeof(FxpHeader)) return FXAMD_E_ARG;
+   FxpHeader h;
+   std::memcpy(&h, blob, sizeof(h));
+   if (h.magic != FXP_MAGIC || h.version != FXP_VERSION || h.total_bytes != (uint64_t)size) return FXAMD_E_BLOB;
+   const uint32_t offs[] = {h.off_bounds, h.off_bound_cls, h.off_ascii_cls, h.off_TA, h.off_TR, h.off_accA, h.off_hitR,
+                            h.off_finalM, h.off_prefix, h.off_suffix, h.off_all, h.off_fastA, h.off_fastR};
+   for (uint32_t o : offs)
+      if (o > h.total_bytes) return FXAMD_E_BLOB;
+   fxamd_program* p = new (std::nothrow) fxamd_program();
+   if (!p) return FXAMD_E_NOMEM;
+   p->prog.blob.assign((const uint8_t*)blob, (const uint8_t*)blob + size);
+   p->prog.status = (int)h.status;
+   *out = p;
+   return FXAMD_OK;
+}
+int fxamd_program_info(const fxamd_program* p, int32_t* info) {
+   if (!p || !info) return FXAMD_E_ARG;
+   const FxpHeader& h = p->prog.hdr();
+   info[0] = (int32_t)h.mode;
+   info[1] = (int32_t)h.flags;
+   info[2] = (int32_t)h.nA;
+   info[3] = (int32_t)h.nR;
+   info[4] = (int32_t)h.n_classes;
+   info[5] = p->prog.status;
+   info[6] = (int32_t)h.total_bytes;
+   info[7] = (int32_t)h.n_bounds;
+   return FXAMD_OK;
+}
+const char* fxamd_strerror(int32_t status) { return fxfe::status_message(status); }
+
+int fxamd_program_upload(fxamd_program* p) {
+   if (!p) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(p->mu);
+   int dev = -1;
+   FX_HIP(hipGetDevice(&dev));
+   if (p->d_blob && p->device == dev) return FXAMD_OK;
+   if (p->d_blob) {
+      (void)hipFree(p->d_blob);
+      p->d_blob = nullptr;
+   }
+   FX_HIP(hipMalloc((void**)&p->d_blob, p->prog.blob.size()));
+   FX_HIP(hipMemcpy(p->d_blob, p->prog.blob.data(), p->prog.blob.size(), hipMemcpyHostToDevice));
+   p->device = dev;
+   return FXAMD_OK;
+}
+
+int fxamd_last_path(const fxamd_program* p) { return p ? p->last_path : FXAMD_E_ARG; }
+
+static bool fast_applies(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
+   return (h.flags & FXP_F_FAST_OK) && h.mode == FXP_MODE_SEARCH_ENGINE && aligned16 &&
+          (row_len == 32 || row_len == 64 || row_len == 128 || row_len == 256);
+}
+
+static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                                  uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
+   FastParams fp{h.fast_R_start, h.fast_A_init, h.fast_hitR_min, h.fast_accA_min};
+   switch (row_len >> 4) {
+      case 2: return launch_fast<2>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
+      case 4: return launch_fast<4>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
+      case 8: return launch_fast<8>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
+      default: return launch_fast<16>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
+   }
+}
+
+int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
+                           int32_t* d_to, void* hip_stream) {
+   if (!p || n <= 0 || !d_rows || !d_flags || (d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
+   if (p->prog.status != 0) return FXAMD_E_ARG;
+   const FxpHeader& h = p->prog.hdr();
+   if (!fast_applies(h, d_rows, row_len)) return FXAMD_E_ARG;
+   int rc = fxamd_program_upload(p);
+   if (rc != FXAMD_OK) return rc;
+   FX_HIP(launch_fast_any(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, (hipStream_t)hip_stream));
+   return FXAMD_OK;
+}
+
+int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
+                             int32_t* d_to, void* hip_stream) {
+   if (!p || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || !d_flags || (n > 0 && row_len > 0 && !d_rows)) return FXAMD_E_ARG;
+   if ((d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
+   if (p->prog.status >= 100) return FXAMD_E_UNSUPPORTED;
+   if (n == 0) return FXAMD_OK;
+   hipStream_t st = (hipStream_t)hip_stream;
+   const FxpHeader& h = p->prog.hdr();
+   const unsigned gblocks = (unsigned)((n + 255) / 256);
+   if (h.mode == FXP_MODE_INVALID) {
+      hipLaunchKernelGGL(fx_fill, dim3(gblocks), dim3(256), 0, st, d_flags, d_from, d_to, n);
+      FX_HIP(hipGetLastError());
+      p->last_path = 0;
+      return FXAMD_OK;
+   }
+   int rc = fxamd_program_upload(p);
+   if (rc != FXAMD_OK) return rc;
+   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
+   const bool fast = fast_applies(h, d_rows, row_len);
+   if (fast) {
+      FX_HIP(launch_fast_any(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
+      // fix-up pass for rows holding bytes >= 0x80 (on-device UTF-8 decode path); a no-op read of the flags otherwise
+      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1);
+      FX_HIP(hipGetLastError());
+      p->last_path = 3;
+      return FXAMD_OK;
+   }
+   if (aligned16 && row_len <= 1024) {
+      const unsigned tblocks = (unsigned)((n + 63) / 64);
+      hipLaunchKernelGGL(fx_general_tiled, dim3(tblocks), dim3(64), (size_t)64 * row_len, st, d_rows, n, (int32_t)row_len, p->d_blob,
+                         d_flags, d_from, d_to);
+   } else {
+      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 0);
+   }
+   FX_HIP(hipGetLastError());
+   p->last_path = 2;
+   return FXAMD_OK;
+}
+
+int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags, int32_t* h_from,
+                           int32_t* h_to) {
+   if (!p || n < 0 || row_len < 0 || !h_flags || (n > 0 && row_len > 0 && !h_rows)) return FXAMD_E_ARG;
+   if ((h_from == nullptr) != (h_to == nullptr)) return FXAMD_E_ARG;
+   if (n == 0) return FXAMD_OK;
+   uint8_t *d_rows = nullptr, *d_flags = nullptr;
+   int32_t *d_from = nullptr, *d_to = nullptr;
+   int rc = FXAMD_OK;
+   const size_t bytes = (size_t)n * (size_t)row_len;
+   auto cleanup = [&]() {
+      if (d_rows) (void)hipFree(d_rows);
+      if (d_flags) (void)hipFree(d_flags);
+      if (d_from) (void)hipFree(d_from);
+      if (d_to) (void)hipFree(d_to);
+   };
+#define FX_HIP_C(call)                    \
+   do {                                   \
+      hipError_t _e = (call);             \
+      if (_e != hipSuccess) {             \
+         cleanup();                       \
+         return hip_fail(_e);             \
+      }                                   \
+   } while (0)
+   FX_HIP_C(hipMalloc((void**)&d_rows, bytes ? bytes : 16));
+   FX_HIP_C(hipMalloc((void**)&d_flags, (size_t)n));
+   if (h_from) {
+      FX_HIP_C(hipMalloc((void**)&d_from, (size_t)n * 4));
+      FX_HIP_C(hipMalloc((void**)&d_to, (size_t)n * 4));
+   }
+   if (bytes) FX_HIP_C(hipMemcpy(d_rows, h_rows, bytes, hipMemcpyHostToDevice));
+   rc = fxamd_match_batch_device(p, d_rows, n, row_len, d_flags, d_from, d_to, nullptr);
+   if (rc != FXAMD_OK) {
+      cleanup();
+      return rc;
+   }
+   FX_HIP_C(hipDeviceSynchronize());
+   FX_HIP_C(hipMemcpy(h_flags, d_flags, (size_t)n, hipMemcpyDeviceToHost));
+   if (h_from) {
+      FX_HIP_C(hipMemcpy(h_from, d_from, (size_t)n * 4, hipMemcpyDeviceToHost));
+      FX_HIP_C(hipMemcpy(h_to, d_to, (size_t)n * 4, hipMemcpyDeviceToHost));
+   }
+   cleanup();
+   return FXAMD_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,64 @@
+"""Multi-GPU plumbing for the batch path: rows are independent units, so the batch shards into contiguous index
+ranges with NO data-path collective; the only exchange is one gather of PACKED results to rank 0
+(1 bit per flag + from/to narrowed to the row length) over RCCL -- a direct gather uses the root's 7 inbound xGMI
+links in parallel.  Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous [start, stop) of `rank`: shard i gets indices [i*n/world, (i+1)*n/world)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def span_dtype(row_len):
+    return torch.uint8 if row_len <= 255 else (torch.int16 if row_len <= 32767 else torch.int32)
+
+
+def pack_results(flags, frm, to, row_len):
+    """flags uint8[n] (0/1), frm/to int32[n] -> (bits uint8[ceil(n/8)], from narrow[n], to narrow[n])."""
+    n = flags.shape[0]
+    pad = (-n) % 8
+    f = torch.cat([flags, flags.new_zeros(pad)]) if pad else flags
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=flags.device)
+    bits = (f.view(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8)
+    dt = span_dtype(row_len)
+    return bits, frm.to(dt), to.to(dt)
+
+
+def unpack_results(bits, frm, to, n):
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=bits.device)
+    flags = ((bits.to(torch.int32)[:, None] & w) != 0).to(torch.uint8).reshape(-1)[:n]
+    return flags, frm.to(torch.int32), to.to(torch.int32)
+
+
+def gather_results(flags, frm, to, n_total, row_len, dst=0):
+    """Every rank passes its shard's results; rank `dst` returns (flags, from, to) for all n_total rows, others None."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bits, f8, t8 = pack_results(flags, frm, to, row_len)
+    out = None
+    pieces = []
+    for tns, per_row in ((bits, False), (f8, True), (t8, True)):
+        sizes = []
+        for r in range(world):
+            a, b = shard_bounds(n_total, r, world)
+            sizes.append((b - a + 7) // 8 if not per_row else b - a)
+        mx = max(sizes)
+        buf = tns.new_zeros(mx)
+        buf[:tns.shape[0]] = tns
+        if rank == dst:
+            lst = [tns.new_zeros(mx) for _ in range(world)]
+            dist.gather(buf, lst, dst=dst)
+            pieces.append([lst[r][:sizes[r]] for r in range(world)])
+        else:
+            dist.gather(buf, None, dst=dst)
+    if rank == dst:
+        fl, fr, tt = [], [], []
+        for r in range(world):
+            a, b = shard_bounds(n_total, r, world)
+            f, x, y = unpack_results(pieces[0][r], pieces[1][r], pieces[2][r], b - a)
+            fl.append(f)
+            fr.append(x)
+            tt.append(y)
+        out = (torch.cat(fl), torch.cat(fr), torch.cat(tt))
+    return out

@@ -1,0 +1,98 @@
+/* forgex_amd.h -- C ABI of the MI355X batch regex-match path (libforgex_amd.so).
+ *
+ * The reference (ShinobuAmasaki/forgex) has no FFI layer: its boundary is the Fortran module `forgex`
+ * (reference src/forgex.F90:14-54).  These entry points are what a Fortran `iso_c_binding` interface block
+ * for that module binds for the batch match path (see INTEGRATION.md and forgex_amd/fortran/forgex.F90):
+ *
+ *   fxamd_compile            replaces the per-element  buff=trim(pattern); tree%build; extract_literal;
+ *                            automaton%preprocess; automaton%init   (reference src/forgex.F90:95-140, :182-223,
+ *                            :260-317) by ONE compile per batch; status codes are the reference's
+ *                            src/essential/error_m.F90:12-38 enum values.
+ *   fxamd_compile_nfa        same, for a host that keeps its own parser/NFA builder and hands over the
+ *                            range-NFA of `nfa_graph_t` (reference src/nfa/nfa_graph_m.F90:24-37) plus the
+ *                            literals of `extract_literal` (reference src/ast/syntax_tree_optimize_m.F90:42-55).
+ *   fxamd_match_batch_*      replaces the elemental evaluation of `pattern .in. str(:)`, `pattern .match. str(:)`
+ *                            and `regex` over a rank-1 character array, i.e. do_matching_including /
+ *                            do_matching_exactly (reference src/api_internal_m.F90:31-167, :171-303) for every row.
+ *   fxamd_strerror           get_error_message (reference src/essential/error_m.F90:127-211).
+ *
+ * Rows are the storage of a Fortran `character(row_len) :: s(n)`: n*row_len contiguous bytes, no terminators.
+ * All functions return 0 on success or a negative FXAMD_E_* code; they never abort the process.
+ * A program handle may be used from several host threads; distinct handles are independent.
+ * There is NO CPU matching path: every match call needs a HIP device and fails with FXAMD_E_HIP otherwise.
+ */
+#ifndef FORGEX_AMD_H
+#define FORGEX_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fxamd_program fxamd_program;
+
+/* op */
+#define FXAMD_OP_SEARCH 0 /* `.in.`, `regex`, `regex_f` */
+#define FXAMD_OP_MATCH 1  /* `.match.` */
+
+/* return codes */
+#define FXAMD_OK 0
+#define FXAMD_E_ARG -1     /* bad argument */
+#define FXAMD_E_HIP -2     /* HIP runtime error / no device (fxamd_last_hip_error() has the hipError_t) */
+#define FXAMD_E_NOMEM -3
+#define FXAMD_E_BLOB -4    /* malformed program blob */
+#define FXAMD_E_UNSUPPORTED -5 /* valid pattern the device path cannot run (status >= 100, e.g. DFA state explosion) */
+
+/* Values written to from/to for an INVALID pattern by the regex-style entry (reference forgex.F90:266-274). */
+#define FXAMD_INVALID_CHAR_INDEX (-9999)
+
+/* ---- compile (host only; works without a GPU) -------------------------------------------------------- */
+int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status);
+
+/* Range-NFA hand-over.  States are 1..n_states; transition t goes src[t] -> dst[t] and carries the segments
+ * seg_min/seg_max[seg_begin[t] .. seg_begin[t+1]) ; a segment (-1,-1) marks an epsilon transition (SEG_EPSILON,
+ * reference src/essential/segment_m.F90:48).  Literals may be empty (len 0). */
+int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64_t n_transitions, const int32_t* src,
+                      const int32_t* dst, const int64_t* seg_begin, const int32_t* seg_min, const int32_t* seg_max,
+                      const char* lit_all, int64_t len_all, const char* lit_prefix, int64_t len_prefix,
+                      const char* lit_suffix, int64_t len_suffix, int op, fxamd_program** out, int32_t* status);
+
+void fxamd_program_free(fxamd_program* p);
+int32_t fxamd_program_status(const fxamd_program* p);          /* 0 = valid pattern */
+int64_t fxamd_program_blob_size(const fxamd_program* p);       /* flattened table image (program.h wire format) */
+int fxamd_program_blob(const fxamd_program* p, void* buf, int64_t capacity);
+int fxamd_program_from_blob(const void* blob, int64_t size, fxamd_program** out);
+/* facts for tests/diagnostics: info[0..7] = mode, flags, nA, nR, n_classes, status, total_bytes, n_bounds */
+int fxamd_program_info(const fxamd_program* p, int32_t* info8);
+const char* fxamd_strerror(int32_t status);
+
+/* ---- match (HIP device required) --------------------------------------------------------------------- */
+/* Upload the tables to the current HIP device (idempotent; done lazily by the match calls otherwise). */
+int fxamd_program_upload(fxamd_program* p);
+
+/* Device-resident batch: d_rows, d_flags (n bytes: 0/1), d_from, d_to (n int32 each, may both be NULL) are
+ * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
+ * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
+ * `.match.`: flags = verdict, from/to untouched.  Invalid pattern: all flags 0, from/to 0. */
+int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
+                             int32_t* d_from, int32_t* d_to, void* hip_stream);
+
+/* Host-buffer convenience used by the Fortran module: H2D copy, match, D2H copy, synchronous. */
+int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
+                           int32_t* h_from, int32_t* h_to);
+
+/* Measurement hook (bench.py roofline leg only): enqueue ONLY the dominant fast kernel, without the fix-up pass, so
+ * its launch duration can be bracketed with HIP events.  FXAMD_E_ARG when the fast path does not apply. */
+int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
+                           int32_t* d_from, int32_t* d_to, void* hip_stream);
+
+/* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast (LDS tile + v_perm
+ * byte tables), 2 = general, 3 = fast + general fix-up pass for non-ASCII rows. */
+int fxamd_last_path(const fxamd_program* p);
+int fxamd_last_hip_error(void);
+int fxamd_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, through the C ABI, against the oracle
+(oracle/liboracle.so), the golden vectors recorded from the real reference, and -- at BASELINE.json's full sizes --
+size-independent properties of the generators.  Bit-exact: flags and (from,to) are integers."""
+import os
+
+import numpy as np
+import pytest
+
+import golden
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+NT = os.cpu_count() or 1
+
+
+@pytest.fixture(scope="module")
+def fx(built):
+    import torch
+    import forgex_amd
+    assert torch.cuda.is_available()
+    assert forgex_amd.lib().fxamd_device_count() >= 1
+    return forgex_amd
+
+
+def _device_run(fx, pattern, op, rows_np, spans=True):
+    import torch
+    prog = fx.Program(pattern, op)
+    rows = torch.from_numpy(np.ascontiguousarray(rows_np)).cuda()
+    f, a, b = prog.match_device(rows, spans=spans)
+    torch.cuda.synchronize()
+    return prog, f.cpu().numpy(), (a.cpu().numpy() if spans else None), (b.cpu().numpy() if spans else None)
+
+
+def test_golden_vectors_through_c_abi(fx):
+    """Every .in./.match./regex assertion of the reference's own tests, as recorded from the real reference."""
+    recs = golden.load_ref_tests()
+    n_checked = n_unsupported = 0
+    for prog_name, kind, f in recs:
+        if kind not in ("in", "match", "regex"):
+            continue
+        pat, txt = golden.unhx(f[0]), golden.unhx(f[1])
+        op = fx.OP_MATCH if kind == "match" else fx.OP_SEARCH
+        p = fx.Program(pat, op)
+        if not p.supported:
+            n_unsupported += 1
+            continue
+        rows = np.frombuffer(txt, dtype=np.uint8).reshape(1, len(txt))
+        if p.status != 0:
+            flag, frm, to = 0, fx.INVALID_CHAR_INDEX, fx.INVALID_CHAR_INDEX
+        else:
+            fl, a, b = p.match_host(rows, spans=True)
+            flag, frm, to = int(fl[0]), int(a[0]), int(b[0])
+        if kind == "match":
+            assert (flag != 0) == (f[3] == "T"), (prog_name, pat, txt)
+        elif kind == "in":
+            assert (flag != 0) == (f[3] == "T"), (prog_name, pat, txt)
+            assert (frm, to) == (int(f[4]), int(f[5])), (prog_name, pat, txt, frm, to)
+        else:
+            assert (frm, to) == (int(f[4]), int(f[5])), (prog_name, pat, txt, frm, to)
+            sub = txt[frm - 1:to] if frm > 0 and to > 0 else b""
+            assert sub == golden.unhx(f[3]), (prog_name, pat, txt)
+        n_checked += 1
+    assert n_checked > 900 and n_unsupported <= 8
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg1", 1000), ("cfg2", 30000), ("cfg3", 20000), ("cfg4", 6000), ("cfg5", 30000)])
+def test_config_rows_vs_oracle(fx, cfg, n):
+    import torch
+    from forgex_amd import synth
+    pat = synth.PATTERNS[cfg].encode()
+    rows = synth.batch(cfg, 0, n, torch.device("cuda")).cpu().numpy()
+    if cfg == "cfg1":
+        prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows)
+        of, _, _ = oracle_lib.batch(1, pat, rows, NT)
+        assert np.array_equal(f, of)
+        assert 400 < int(f.sum()) < 600
+        return
+    prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+    of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+    assert np.array_equal(f, of), cfg
+    assert np.array_equal(a, oa) and np.array_equal(b, ob), cfg
+    assert int(f.sum()) > 0
+    # flags-only entry (what `.in.` returns) agrees with the span entry
+    _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+    assert np.array_equal(f2, of)
+    if cfg in ("cfg2", "cfg3", "cfg5"):
+        assert prog.last_path() == 3   # fast kernel (+ no-op fix-up)
+
+
+def test_fast_and_general_kernels_agree(fx):
+    """The same rows through the fast kernel (aligned [n,256]) and through the general kernel (an odd row length forces it)."""
+    import torch
+    from forgex_amd import synth
+    rows = synth.batch("cfg3", 5000, 8192, torch.device("cuda"))
+    pat = synth.PATTERNS["cfg3"]
+    p = fx.Program(pat, fx.OP_SEARCH)
+    f1, a1, b1 = p.match_device(rows)
+    assert p.last_path() == 3
+    wide = torch.cat([rows, torch.full((rows.shape[0], 1), 33, dtype=torch.uint8, device=rows.device)], dim=1).contiguous()  # '!' appended
+    f2, a2, b2 = p.match_device(wide)
+    assert p.last_path() == 2
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2)
+
+
+def test_non_ascii_rows_take_the_fixup_pass(fx):
+    """Rows with bytes >= 0x80 inside an otherwise fast batch are redone by the general kernel (on-device UTF-8 decode)."""
+    import torch
+    from forgex_amd import synth
+    rows = synth.batch("cfg3", 0, 4096, torch.device("cuda")).cpu().numpy().copy()
+    rng = np.random.default_rng(7)
+    for i in rng.choice(rows.shape[0], 600, replace=False):
+        k = int(rng.integers(0, 250))
+        rows[i, k:k + 3] = np.frombuffer("あ".encode(), dtype=np.uint8)
+        if i % 3 == 0:
+            rows[i, 255] = 0xE3   # truncated lead byte at the very end
+    pat = "[a-zぁ-ん]+\\d+".encode()
+    prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+    of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+    assert np.array_equal(f, of) and np.array_equal(a, oa) and np.array_equal(b, ob)
+
+
+PATTERNS_MISC = [rb"aa[bc]", rb"^abc$", rb"abc$", rb"a*", rb"b*", rb"(|^)a", rb"\s+\d", rb"[^a-z]", rb"x*$", rb"\w+@\w+", rb"ab(c|d)e", rb"ab[cd]e*f",
+                 rb"foo", rb"a{2}[xy]", rb".", rb"\D\d", rb"(a|b)*c", rb"[a-c]{2,3}z"]
+
+
+def test_misc_patterns_random_rows_vs_oracle(fx):
+    """Quirk probes of SURVEY Appendix A (prefilter with overlapping prefix, anchors as NUL symbols, empty matches,
+    literal paths) on random short rows, both operators."""
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"abcxyz019 \n\r\t@.f o", dtype=np.uint8)
+    for L in (1, 3, 7, 16, 33):
+        rows = alphabet[rng.integers(0, len(alphabet), size=(3000, L))]
+        for pat in PATTERNS_MISC:
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            assert np.array_equal(f, of), (pat, L)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
+            prog, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows)
+            om, _, _ = oracle_lib.batch(1, pat, rows, NT)
+            assert np.array_equal(fm, om), (pat, L, "match")
+
+
+def test_invalid_pattern_and_empty_batch(fx):
+    rows = np.frombuffer(b"abcdabcd", dtype=np.uint8).reshape(2, 4)
+    p = fx.Program(b"a(", fx.OP_SEARCH)
+    assert p.status == 2
+    f, a, b = p.match_host(rows)
+    assert not f.any() and not a.any() and not b.any()
+    assert fx.regex(b"a(", b"zz")[2:5] == (fx.INVALID_CHAR_INDEX, fx.INVALID_CHAR_INDEX, 2)
+    assert fx.in_(b"b*", b"") is True and fx.in_(b"b*", b"aaa") is False
+    assert fx.regex(rb"[a-z]+\d+", b"ab12  cd345")[:4] == (b"ab12", 4, 1, 4)
+    assert list(fx.in_(rb"\d", [b"a1", b"bcd", b"", b"7"])) == [True, False, False, True]
+
+
+def test_full_size_cfg3_properties(fx):
+    """BASELINE config 3 at full size (10M x 256 B): the generator knows the answer for every row."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    n, L = synth.SHAPES["cfg3"]
+    prog = fx.Program(synth.PATTERNS["cfg3"], fx.OP_SEARCH)
+    step = 2_000_000
+    for start in range(0, n, step):
+        rows = synth.batch("cfg3", start, step, dev)
+        f, a, b = prog.match_device(rows)
+        idx = torch.arange(start, start + step, dtype=torch.int64, device=dev)
+        r = synth._rowhash(idx, synth.SEEDS["cfg3"], 0)
+        is_match = (r & 1) == 1
+        nd = 1 + (synth._lsr(r, 1) % 3)
+        off = 192 + (synth._lsr(r, 8) % 61)
+        assert torch.equal(f != 0, is_match)
+        assert torch.equal(b.to(torch.int64)[is_match], (off + nd)[is_match])          # longest end = last planted digit
+        am = a.to(torch.int64)[is_match]
+        rm = rows[is_match]
+        ar = torch.arange(rm.shape[0], device=dev)
+        assert bool(((rm[ar, am - 1] >= 97) & (rm[ar, am - 1] <= 122)).all())            # span starts on a letter ...
+        prev = torch.where(am >= 2, rm[ar, (am - 2).clamp(min=0)], torch.full_like(rm[:, 0], 32))
+        assert bool((prev == 32).all())                                                  # ... right after a blank or at the row start
+        assert int(a[~is_match].abs().sum()) == 0 and int(b[~is_match].abs().sum()) == 0
+        # no blank inside [from, off): the leftmost start of the letter run that reaches the digits
+        j = torch.arange(L, device=dev)[None, :]
+        inside = (j >= (am - 1)[:, None]) & (j < off[is_match][:, None])
+        assert not bool(((rm == 32) & inside).any())

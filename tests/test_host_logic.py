@@ -1,0 +1,108 @@
+"""CPU tests (no GPU) of the product's host side: the table compiler + per-row procedure (compiled for the host by the
+TEST-ONLY harness tests/support/host_walk.cpp) against the golden vectors and the oracle; the C ABI loads and exports
+every symbol of include/forgex_amd.h; compile/status/blob behaviour through the ABI (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden
+import fuzz_diff
+
+HW = os.path.join(golden.ROOT, "tests", "support", "host_walk")
+
+
+def test_tables_reproduce_golden_vectors(built):
+    pairs = [(c, e) for c, e in golden.expected_lines_from_golden(golden.load_ref_tests()) if c[0] in "IMRV"]
+    out = golden.run_protocol(HW, [c for c, _ in pairs])
+    bad = [(c, e, a) for (c, e), a in zip(pairs, out) if not a.startswith("U") and not golden.line_matches(e, a)]
+    unsupported = [c for (c, e), a in zip(pairs, out) if a.startswith("U")]
+    assert not bad, bad[:5]
+    assert len(unsupported) <= 8     # DFA state explosion (e.g. `.*a(a|b){500}c{20}`): reported, not silently wrong
+
+
+def test_tables_equal_oracle_on_fuzz(built):
+    total = 0
+    for seed in (7, 8):
+        cases = [c for c in fuzz_diff.gen_cases(seed, 4000) if c[0] in "IMRV"]
+        a = golden.run_protocol(HW, cases)
+        b = golden.run_protocol(golden.ORACLE_CLI, cases)
+        diffs = [(c, x, y) for c, x, y in zip(cases, a, b) if not x.startswith("U") and x != y]
+        assert not diffs, diffs[:5]
+        total += len(cases)
+    assert total > 5000
+
+
+def test_config_rows_tables_vs_oracle(built):
+    """Small slices of the five BASELINE configs through the host walker (one compile per batch) and the oracle."""
+    import torch
+    import oracle_lib
+    from forgex_amd import synth
+    lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.hw_batch.argtypes = [ctypes.c_char_p, i64, ctypes.c_int, vp, i64, i64, vp, vp, vp]
+    for cfg, n, op in (("cfg1", 1000, 1), ("cfg2", 3000, 0), ("cfg3", 400, 0), ("cfg4", 600, 0), ("cfg5", 800, 0)):
+        pat = synth.PATTERNS[cfg].encode()
+        rows = synth.batch(cfg, 0, n, torch.device("cpu")).numpy()
+        f = np.zeros(n, np.uint8)
+        a = np.zeros(n, np.int32)
+        b = np.zeros(n, np.int32)
+        st = lib.hw_batch(pat, len(pat), op, rows.ctypes.data_as(vp), n, rows.shape[1], f.ctypes.data_as(vp), a.ctypes.data_as(vp), b.ctypes.data_as(vp))
+        assert st == 0
+        of, oa, ob = oracle_lib.batch(1 if op == 1 else 2, pat, rows, os.cpu_count() or 1)
+        assert np.array_equal(f, of), cfg
+        if op == 0:
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), cfg
+        assert 0 < int(f.sum()) < n
+
+
+def test_c_abi_exports_every_declared_symbol(built):
+    import forgex_amd
+    from forgex_amd import _lib
+    header = open(os.path.join(golden.ROOT, "include", "forgex_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(fxamd_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(_lib.EXPORTED_SYMBOLS)
+    L = forgex_amd.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_compile_status_and_blob_roundtrip(built):
+    import forgex_amd as fx
+    p = fx.Program(r"[a-z]+\d+", fx.OP_SEARCH)
+    info = p.info()
+    assert p.status == 0 and info["mode"] == 1 and info["nA"] <= 8 and info["nR"] <= 8 and (info["flags"] & 8)
+    q = fx.Program.from_blob(p.blob(), fx.OP_SEARCH)
+    assert q.info() == info and q.blob() == p.blob()
+    with pytest.raises(ValueError):
+        fx.Program.from_blob(p.blob()[:-16], fx.OP_SEARCH)
+    bad = fx.Program("a(", fx.OP_SEARCH)
+    assert bad.status == 2 and not bad.valid and fx.strerror(2) == "ERROR: Closing parenthesis is expected."
+    assert fx.is_valid_regex("a{2,1}") is False and fx.is_valid_regex(r"\d{3}-\d{4}") is True
+    big = fx.Program(r"[ab]*a[ab]{20}", fx.OP_SEARCH)      # 2^21 DFA states: valid but unsupported on the device path
+    assert big.valid and not big.supported and big.status == 102
+    assert fx.Program("foo(bar|baz)", fx.OP_SEARCH).info()["flags"] & 2   # prefilter literal `fooba`
+    assert fx.Program("abc", fx.OP_SEARCH).info()["mode"] == 2            # whole-pattern literal -> INDEX path
+
+
+def test_error_codes_and_messages_match_reference(built):
+    import forgex_amd as fx
+    n = 0
+    for prog, kind, f in golden.load_ref_tests():
+        if kind != "error":
+            continue
+        p = fx.Program(golden.unhx(f[0]), fx.OP_SEARCH)
+        assert p.status == int(f[2]), (f, p.status)
+        assert fx.strerror(p.status).encode() == golden.unhx(f[3]), f
+        n += 1
+    assert n == 125
+
+
+def test_match_path_fails_loudly_without_gpu(built):
+    import forgex_amd as fx
+    if fx.lib().fxamd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        fx.in_("abc", [b"xabc"])
