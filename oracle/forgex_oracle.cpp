@@ -295,7 +295,8 @@ void ensure_automaton(Compiled& c) {
 // ---- public operations -------------------------------------------------------------------------------
 struct RegexResult {
    int from = 0, to = 0, length = 0, status = 0;
-   bool matched = false;
+   bool matched = false;          // a span was returned
+   bool accepted_empty = false;   // ACCEPTED_EMPTY: `.in.` is true although regex() returns '' (forgex.F90:146-149, :323-329)
 };
 
 bool op_in(const std::string& pattern, const std::string& str) {   // forgex.F90:74-160
@@ -362,7 +363,10 @@ RegexResult op_regex(const std::string& pattern, const std::string& text) {   //
    ensure_automaton(c);
    int from_l, to_l;
    do_matching_including(c.a, text, from_l, to_l, c.lit.prefix, c.lit.suffix);
-   if (from_l == ACCEPTED_EMPTY && to_l == ACCEPTED_EMPTY) return r;
+   if (from_l == ACCEPTED_EMPTY && to_l == ACCEPTED_EMPTY) {
+      r.accepted_empty = true;
+      return r;
+   }
    if (from_l > 0 && to_l > 0) {
       r.from = from_l;
       r.to = to_l;
@@ -415,7 +419,7 @@ int fxo_valid(const char* pat, int64_t plen) {
    t.build(f_trim(std::string(pat, static_cast<size_t>(plen))));
    return t.is_valid ? 1 : 0;
 }
-// op: 0 = .in. (flags only), 1 = .match., 2 = regex (flags + from/to).  Every row pays the full per-call
+// op: 0 = .in. (flags only), 1 = .match., 2 = regex (`.in.` verdict in flags + from/to; invalid pattern: -9999).  Every row pays the full per-call
 // compile, exactly as the reference's elemental operators do (forgex.F90:98,139-140).
 void fxo_batch(int op, const char* pat, int64_t plen, const uint8_t* rows, int64_t n, int64_t row_len, uint8_t* flags,
                int32_t* from, int32_t* to, int nthreads) {
@@ -430,7 +434,7 @@ void fxo_batch(int op, const char* pat, int64_t plen, const uint8_t* rows, int64
          flags[i] = op_match(p, s) ? 1 : 0;
       } else {
          RegexResult r = op_regex(p, s);
-         flags[i] = r.matched ? 1 : 0;
+         flags[i] = (r.matched || r.accepted_empty) ? 1 : 0;   // the `.in.` verdict of the same call
          if (from) from[i] = r.from;
          if (to) to[i] = r.to;
       }

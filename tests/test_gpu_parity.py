@@ -182,3 +182,16 @@ def test_full_size_cfg3_properties(fx):
         j = torch.arange(L, device=dev)[None, :]
         inside = (j >= (am - 1)[:, None]) & (j < off[is_match][:, None])
         assert not bool(((rm == 32) & inside).any())
+
+
+def test_fortran_dropin_module(fx):
+    """`use forgex` from Fortran (flang): operators on scalars and rank-1 arrays, regex, regex_f -- through iso_c_binding."""
+    import subprocess
+    fdir = os.path.join(golden.ROOT, "forgex_amd", "fortran")
+    exe = os.path.join(fdir, "build", "fortran_dropin_test")
+    if not os.path.exists(exe):
+        if not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
+            pytest.skip("flang not available")
+        subprocess.check_call(["make", "-C", fdir])
+    r = subprocess.run([exe], capture_output=True, timeout=300)
+    assert r.returncode == 0 and b"FORTRAN DROP-IN OK" in r.stdout, (r.stdout[-500:], r.stderr[-500:])

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_round.sh: per-kernel stats (count, avg/min/max ns) and, for the dominant
+kernel, HBM traffic per launch from the PMC passes with the gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE counts
+half of a wide coalesced read stream -> doubled; counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+summary = {"tag": tag, "config": cfg}
+kt = find("kt", "*kernel_stats.csv")
+if kt:
+    rows = list(csv.DictReader(open(kt)))
+    summary["kernel_stats"] = [{k: r.get(k) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
+    print("== kernel stats (%s)" % kt)
+    for r in rows:
+        print("  %-70s calls=%s avg=%s ns  min=%s max=%s  %s%%" % (r.get("Name", "")[:70], r.get("Calls"), r.get("AverageNs"), r.get("MinNs"), r.get("MaxNs"), r.get("Percentage")))
+
+
+def pmc(sub):
+    f = find(sub, "*counter_collection.csv")
+    acc = {}
+    if not f:
+        return acc
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "")
+        key = (name, r.get("Counter_Name"))
+        acc.setdefault(key, []).append(float(r.get("Counter_Value", 0)))
+    return acc
+
+
+fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
+dom = None
+for (name, ctr), vals in fetch.items():
+    if "fx_search_fast" in name or "fx_general_tiled" in name:
+        dom = name
+if dom:
+    f = fetch.get((dom, "FETCH_SIZE"), [])
+    w = write.get((dom, "WRITE_SIZE"), [])
+    if f and w:
+        fetch_kib = sum(f) / len(f)
+        write_kib = sum(w) / len(w)
+        traffic = (2.0 * fetch_kib + write_kib) * 1024.0
+        summary["dominant_kernel"] = dom
+        summary["FETCH_SIZE_KiB_per_launch_raw"] = fetch_kib
+        summary["WRITE_SIZE_KiB_per_launch"] = write_kib
+        summary["traffic_bytes_per_launch"] = traffic
+        print("== traffic of %s: FETCH_SIZE raw %.0f KiB (x2 gfx950 correction), WRITE_SIZE %.0f KiB -> %.3f GB per launch" % (
+            dom[:60], fetch_kib, write_kib, traffic / 1e9))
+    sqv = {c: sum(v) / len(v) for (n, c), v in sq.items() if n == dom}
+    if sqv:
+        summary["sq_counters_per_launch"] = sqv
+        print("== SQ counters per launch:", json.dumps(sqv))
+json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
