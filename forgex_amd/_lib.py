@@ -6,7 +6,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libforgex_amd.so")
+LIB_PATH = os.environ.get("FXAMD_LIB") or os.path.join(_HERE, "libforgex_amd.so")   # FXAMD_LIB: kernel-experiment builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 OP_SEARCH, OP_MATCH = 0, 1

@@ -34,30 +34,35 @@
 __device__ __forceinline__ uint32_t tile_cell(uint32_t R, uint32_t k) { return (k << 6) + (R ^ (k & 63u)); }
 
 template <int CH>
-__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint4* tile, uint32_t lane) {
+__device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane) {
    // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH
    const uint4* src = reinterpret_cast<const uint4*>(rows + row0 * (int64_t)(16 * CH));
    const int64_t rows_left = n - row0;
-   const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (uint32_t)rows_left * CH;
-   uint4 v[CH];
+   const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (rows_left > 0 ? (uint32_t)rows_left * CH : 0u);
 #pragma unroll
    for (int q = 0; q < CH; ++q) {
       uint32_t p = q * 64 + lane;
       v[q] = p < valid_pieces ? src[p] : make_uint4(0, 0, 0, 0);
    }
+}
+
+template <int CH>
+__device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, uint32_t lane) {
 #pragma unroll
    for (int q = 0; q < CH; ++q) {
       uint32_t p = q * 64 + lane;
-      uint32_t R = p / CH, k = p % CH;
-      tile[tile_cell(R, k)] = v[q];
+      tile[tile_cell(p / CH, p % CH)] = v[q];
    }
 }
 
 // =========================================================================================================
 // fast search kernel
 // =========================================================================================================
+// every value is a state id replicated into all four bytes (id * 0x01010101): v_perm_b32 then advances four identical
+// copies of the automaton and `state >= hit_min` can compare whole registers without masking
 struct FastParams {
    uint32_t R_start, A_init, hit_min, acc_min;
+   uint2 H;   // hit table of R: byte q = 0xFF when state q is a hit state
 };
 
 // 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
@@ -66,15 +71,20 @@ __device__ __forceinline__ void lookup8(uint2 (&f)[8], uint32_t lo, uint32_t hi,
    for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
 }
 
-// right-to-left state chain over 8 bytes; records the lowest byte index whose state is a hit
-__device__ __forceinline__ void chain8_back(const uint2 (&f)[8], uint32_t& state, uint32_t& s, uint32_t hit_min, int base) {
-   uint32_t loc = 8;
+// Right-to-left state chain over 8 bytes.  All four bytes of `state` carry the same state id (v_perm_b32 advances four
+// identical copies), so whole registers compare like ids and no masking is needed.  Hit states have the LARGEST ids, so
+// the group's "any hit" is max(states) >= hit_min: one v_max3_u32 per two bytes instead of a compare+select per byte.
+__device__ __forceinline__ uint32_t chain8_back(const uint2 (&f)[8], uint32_t& state) {
+   uint32_t st[8];
 #pragma unroll
    for (int i = 7; i >= 0; --i) {
-      state = __builtin_amdgcn_perm(f[i].y, f[i].x, state) & 0xFFu;
-      loc = state >= hit_min ? (uint32_t)i : loc;
+      state = __builtin_amdgcn_perm(f[i].y, f[i].x, state);
+      st[i] = state;
    }
-   s = loc != 8u ? (uint32_t)(base + 2) + loc : s;
+   uint32_t m0 = max(max(st[0], st[1]), st[2]);
+   uint32_t m1 = max(max(st[3], st[4]), st[5]);
+   uint32_t m2 = max(st[6], st[7]);
+   return max(max(m0, m1), m2);
 }
 
 template <int CH, bool SPANS>
@@ -100,18 +110,21 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
 
+   uint4 stage[CH];   // next tile's global loads stay in flight while the current tile is scanned
+   if (wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
-      stage_tile<CH>(rows, row0, n, tile, lane);
+      store_tile<CH>(stage, tile, lane);
       // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
+      if (t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
 
       // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
-      // software pipeline: table lookups of chunk k-1 are in flight while the state chain of chunk k runs
-      uint32_t state = fp.R_start;
-      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
-      uint32_t na = 0;
       // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
-      // expressible) while the state chain of the current group runs
+      // expressible) while the state chain of the current group runs.  Per group only "did any state hit" and the
+      // group's entry state are kept; the exact byte is recovered afterwards by re-walking ONE group per row.
+      uint32_t state = fp.R_start;
+      uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
+      uint32_t na = 0;
       uint2 fa[8], fb[8];
       uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
       if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
@@ -121,7 +134,12 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          na |= wk.x | wk.y | wk.z | wk.w;
          lookup8(fb, wk.x, wk.y, tabR);
          __builtin_amdgcn_sched_barrier(0);
-         chain8_back(fa, state, s, fp.hit_min, k * 16 + 8);
+         {
+            const uint32_t entry = state;
+            const uint32_t mx = chain8_back(fa, state);
+            gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
+            esel = mx >= fp.hit_min ? entry : esel;
+         }
          __builtin_amdgcn_sched_barrier(0);
          if (k >= 1) {
             wk = wn;
@@ -129,49 +147,89 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
          }
          __builtin_amdgcn_sched_barrier(0);
-         chain8_back(fb, state, s, fp.hit_min, k * 16);
+         {
+            const uint32_t entry = state;
+            const uint32_t mx = chain8_back(fb, state);
+            gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
+            esel = mx >= fp.hit_min ? entry : esel;
+         }
          __builtin_amdgcn_sched_barrier(0);
       }
+      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
       {
-         uint2 f = tabR[0];   // leading NUL
-         state = __builtin_amdgcn_perm(f.y, f.x, state) & 0xFFu;
+         // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
+         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
+         const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+         uint2 f[8];
+         lookup8(f, rw.x, rw.y, tabR);
+         uint32_t st = esel, loc = 8;
+#pragma unroll
+         for (int i = 7; i >= 0; --i) {
+            st = __builtin_amdgcn_perm(f[i].y, f[i].x, st);
+            loc = st >= fp.hit_min ? (uint32_t)i : loc;
+         }
+         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
+         uint2 fz = tabR[0];   // leading NUL
+         state = __builtin_amdgcn_perm(fz.y, fz.x, state);
          s = state >= fp.hit_min ? 1u : s;
       }
-      const bool nonascii = (na & 0x80808080u) != 0;
+   const bool nonascii = (na & 0x80808080u) != 0;
       const int64_t row = row0 + lane;
 
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
-      // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk
+      // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk.
+      // The row is extended virtually: position L holds the trailing NUL (byte 0 -> F[0]), later positions kill the state;
+      // an accept after consuming position `pos` gives max_match = pos + 3 for text bytes and for the trailing NUL alike.
       uint32_t cur = (s != 0 && !nonascii && (SPANS || s == 1)) ? fp.A_init : 0u;
       uint32_t mm = 0;                      // max_match (wrapped index of the byte after the longest match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
          uint2 f = tabA[0];
-         cur = __builtin_amdgcn_perm(f.y, f.x, cur) & 0xFFu;
+         cur = __builtin_amdgcn_perm(f.y, f.x, cur);
          mm = cur >= fp.acc_min ? 2u : 0u;
       }
-      while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-         if (cur != 0) {
-            const uint32_t jal = j & ~7u;                  // 8 bytes per round trip: one row read + 8 table lookups
-            const uint32_t k = jal >> 4;
-            const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, k) << 4) + (jal & 15u));
-            uint2 f[8];
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         // first 32 bytes: straight-line code, so all row reads and all 32 table lookups are issued before the chain
+         const uint32_t jal0 = j & ~7u;
+         uint2 rw[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) f[q] = tabA[((q < 4 ? rw.x : rw.y) >> ((q & 3) * 8)) & 0xFFu];
-            uint32_t loc = 0;                               // 1 + index of the last accepting byte in this group
+         for (int g = 0; g < 4; ++g) {
+            const uint32_t p = jal0 + 8u * g;
+            const uint32_t pc = p < (uint32_t)L ? p : 0u;
+            rw[g] = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
+            if (p >= (uint32_t)L) rw[g] = make_uint2(0, 0);
+         }
+         uint2 f[32];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-               const uint32_t nx = __builtin_amdgcn_perm(f[q].y, f[q].x, cur) & 0xFFu;
-               cur = jal + q >= j ? nx : cur;
-               loc = (jal + q >= j && cur >= fp.acc_min) ? (uint32_t)(q + 1) : loc;
-            }
-            mm = loc != 0 ? jal + loc + 2 : mm;
-            j = jal + 8;
-            if (j >= (uint32_t)L && cur != 0) {             // trailing NUL, then stop
-               uint2 fz = tabA[0];
-               cur = __builtin_amdgcn_perm(fz.y, fz.x, cur) & 0xFFu;
-               mm = cur >= fp.acc_min ? (uint32_t)L + 3 : mm;
-               cur = 0;
+         for (int g = 0; g < 4; ++g) lookup8(*reinterpret_cast<uint2(*)[8]>(&f[8 * g]), rw[g].x, rw[g].y, tabA);
+#pragma unroll
+         for (int q = 0; q < 32; ++q) {
+            const uint32_t pos = jal0 + q;
+            const uint32_t nx = __builtin_amdgcn_perm(f[q].y, f[q].x, cur);
+            cur = pos >= j ? nx : cur;
+            cur = pos > (uint32_t)L ? 0u : cur;
+            mm = (pos >= j && cur >= fp.acc_min) ? pos + 3u : mm;
+            cur = pos == (uint32_t)L ? 0u : cur;   // nothing follows the trailing NUL
+         }
+         j = jal0 + 32u;
+         // rare: matches longer than the window
+         while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+            if (cur != 0) {
+               const uint32_t p = j;   // multiple of 8, <= L here
+               const uint32_t pc = p < (uint32_t)L ? p : 0u;
+               uint2 r8 = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
+               if (p >= (uint32_t)L) r8 = make_uint2(0, 0);
+               uint2 f8[8];
+               lookup8(f8, r8.x, r8.y, tabA);
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  const uint32_t pos = p + q;
+                  cur = __builtin_amdgcn_perm(f8[q].y, f8[q].x, cur);
+                  cur = pos > (uint32_t)L ? 0u : cur;
+                  mm = cur >= fp.acc_min ? pos + 3u : mm;
+                  cur = pos == (uint32_t)L ? 0u : cur;
+               }
+               j = p + 8u;
             }
          }
       }
@@ -431,7 +489,14 @@ static bool fast_applies(const FxpHeader& h, const uint8_t* d_rows, int64_t row_
 
 static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                   uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
-   FastParams fp{h.fast_R_start, h.fast_A_init, h.fast_hitR_min, h.fast_accA_min};
+   FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
+                 make_uint2(0, 0)};
+   {
+      uint64_t hb = 0;
+      for (uint32_t q = 0; q < 8; ++q)
+         if (q >= h.fast_hitR_min && q < h.nR) hb |= (uint64_t)0xFF << (8 * q);
+      fp.H = make_uint2((uint32_t)hb, (uint32_t)(hb >> 32));
+   }
    switch (row_len >> 4) {
       case 2: return launch_fast<2>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
       case 4: return launch_fast<4>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
