@@ -66,7 +66,7 @@ struct FastParams {
 };
 
 // 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
-__device__ __forceinline__ void lookup8(uint2 (&f)[8], uint32_t lo, uint32_t hi, const uint2* __restrict__ tab) {
+__device__ __forceinline__ void lookup8(uint2* __restrict__ f, uint32_t lo, uint32_t hi, const uint2* __restrict__ tab) {
 #pragma unroll
    for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
 }
@@ -85,6 +85,39 @@ __device__ __forceinline__ uint32_t chain8_back(const uint2 (&f)[8], uint32_t& s
    uint32_t m1 = max(max(st[3], st[4]), st[5]);
    uint32_t m2 = max(st[6], st[7]);
    return max(max(m0, m1), m2);
+}
+
+// Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
+// at index L, then 0x80 (a byte whose table row is all-dead) -- so end-of-row needs no per-byte test.
+__device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
+   const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8
+   const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
+   lo = p < L ? r.x : (p == L ? 0x80808000u : 0x80808080u);
+   hi = p < L ? r.y : 0x80808080u;
+}
+__device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
+   const uint32_t base = j & ~7u, sh = j & 7u;
+   uint32_t d[10];
+#pragma unroll
+   for (int g = 0; g < 5; ++g) group_words(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
+   const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
+   uint32_t e[9];
+#pragma unroll
+   for (int k = 0; k < 9; ++k) e[k] = (up & d[k + 1]) | (~up & d[k]);
+#pragma unroll
+   for (int k = 0; k < 8; ++k) o[k] = __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u);
+}
+__device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
+   const uint32_t base = j & ~7u, sh = j & 7u;
+   uint32_t d[4];
+   group_words(d[0], d[1], tb, lane, base, L);
+   group_words(d[2], d[3], tb, lane, base + 8u, L);
+   const uint32_t up = 0u - ((sh >> 2) & 1u);
+   uint32_t e[3];
+#pragma unroll
+   for (int k = 0; k < 3; ++k) e[k] = (up & d[k + 1]) | (~up & d[k]);
+   o[0] = __builtin_amdgcn_alignbyte(e[1], e[0], sh & 3u);
+   o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
 }
 
 template <int CH, bool SPANS>
@@ -189,47 +222,58 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          mm = cur >= fp.acc_min ? 2u : 0u;
       }
       if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-         // first 32 bytes: straight-line code, so all row reads and all 32 table lookups are issued before the chain
-         const uint32_t jal0 = j & ~7u;
-         uint2 rw[4];
-#pragma unroll
-         for (int g = 0; g < 4; ++g) {
-            const uint32_t p = jal0 + 8u * g;
-            const uint32_t pc = p < (uint32_t)L ? p : 0u;
-            rw[g] = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
-            if (p >= (uint32_t)L) rw[g] = make_uint2(0, 0);
-         }
+         // First 32 symbols from j, straight-line: five aligned 8-byte row reads, a byte shift to start exactly at j,
+         // all 32 table lookups issued before the chain; per 8-byte group only "any accept" (v_max3) + entry state
+         // are kept and the last accepting group is re-walked for the exact byte.
+         uint32_t o[8];
+         fetch32(o, tb, lane, j, (uint32_t)L);
          uint2 f[32];
 #pragma unroll
-         for (int g = 0; g < 4; ++g) lookup8(*reinterpret_cast<uint2(*)[8]>(&f[8 * g]), rw[g].x, rw[g].y, tabA);
+         for (int g = 0; g < 4; ++g) lookup8(&f[8 * g], o[2 * g], o[2 * g + 1], tabA);
+         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
-         for (int q = 0; q < 32; ++q) {
-            const uint32_t pos = jal0 + q;
-            const uint32_t nx = __builtin_amdgcn_perm(f[q].y, f[q].x, cur);
-            cur = pos >= j ? nx : cur;
-            cur = pos > (uint32_t)L ? 0u : cur;
-            mm = (pos >= j && cur >= fp.acc_min) ? pos + 3u : mm;
-            cur = pos == (uint32_t)L ? 0u : cur;   // nothing follows the trailing NUL
+         for (int g = 0; g < 4; ++g) {
+            const uint32_t entry = cur;
+            uint32_t st[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               cur = __builtin_amdgcn_perm(f[8 * g + q].y, f[8 * g + q].x, cur);
+               st[q] = cur;
+            }
+            const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+            const bool hit = mx >= fp.acc_min;
+            gl = hit ? (uint32_t)g : gl;
+            el = hit ? entry : el;
+            blo = hit ? o[2 * g] : blo;
+            bhi = hit ? o[2 * g + 1] : bhi;
          }
-         j = jal0 + 32u;
-         // rare: matches longer than the window
+         {
+            uint2 fr8[8];
+            lookup8(fr8, blo, bhi, tabA);
+            uint32_t st = el, loc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               st = __builtin_amdgcn_perm(fr8[q].y, fr8[q].x, st);
+               loc = st >= fp.acc_min ? (uint32_t)q : loc;
+            }
+            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+         }
+         j += 32u;
+         // matches longer than the window: 8 symbols per round trip
          while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             if (cur != 0) {
-               const uint32_t p = j;   // multiple of 8, <= L here
-               const uint32_t pc = p < (uint32_t)L ? p : 0u;
-               uint2 r8 = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
-               if (p >= (uint32_t)L) r8 = make_uint2(0, 0);
+               uint32_t o8[2];
+               fetch8(o8, tb, lane, j, (uint32_t)L);
                uint2 f8[8];
-               lookup8(f8, r8.x, r8.y, tabA);
+               lookup8(f8, o8[0], o8[1], tabA);
+               uint32_t loc = 8;
 #pragma unroll
                for (int q = 0; q < 8; ++q) {
-                  const uint32_t pos = p + q;
                   cur = __builtin_amdgcn_perm(f8[q].y, f8[q].x, cur);
-                  cur = pos > (uint32_t)L ? 0u : cur;
-                  mm = cur >= fp.acc_min ? pos + 3u : mm;
-                  cur = pos == (uint32_t)L ? 0u : cur;
+                  loc = cur >= fp.acc_min ? (uint32_t)q : loc;
                }
-               j = p + 8u;
+               mm = loc != 8u ? j + loc + 3u : mm;
+               j += 8u;
             }
          }
       }

@@ -195,3 +195,45 @@ def test_fortran_dropin_module(fx):
         subprocess.check_call(["make", "-C", fdir])
     r = subprocess.run([exe], capture_output=True, timeout=300)
     assert r.returncode == 0 and b"FORTRAN DROP-IN OK" in r.stdout, (r.stdout[-500:], r.stderr[-500:])
+
+
+def test_fuzzed_patterns_through_gpu_vs_oracle(fx):
+    """Random patterns x random texts (the generator that pinned the oracle to the real reference), grouped by pattern so
+    that every pattern is compiled once and its texts go through the kernels as small batches -- vs the oracle CLI."""
+    import fuzz_diff
+    cases = [c for c in fuzz_diff.gen_cases(4242, 6000) if c[0] in "IMR"]
+    expect = golden.run_protocol(golden.ORACLE_CLI, cases)
+    n_checked = n_unsupported = 0
+    for (op, pat, txt), exp in zip(cases, expect):
+        p = fx.Program(pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH)
+        if not p.supported:
+            n_unsupported += 1
+            continue
+        rows = np.frombuffer(txt, dtype=np.uint8).reshape(1, len(txt))
+        if p.status != 0:
+            got = "%s F" % op if op in "IM" else "R -9999 -9999 0 %d -" % p.status
+        else:
+            f, a, b = p.match_host(rows, spans=True)
+            if op in "IM":
+                got = "%s %s" % (op, "T" if f[0] else "F")
+            else:
+                m = a[0] > 0 and b[0] > 0
+                sub = txt[a[0] - 1:b[0]] if m else b""
+                got = "R %d %d %d 0 %s" % (a[0] if m else 0, b[0] if m else 0, (b[0] - a[0] + 1) if m else 0, golden.hx(sub))
+        assert got == exp, (op, pat, txt, got, exp)
+        n_checked += 1
+    assert n_checked > 4000 and n_unsupported < 60
+
+
+def test_python_api_mirror(fx):
+    """forgex_amd.in_/match/regex/regex_f/is_valid_regex behave like the reference's public names."""
+    assert fx.match(rb"\d{3}-\d{4}", b"100-1002") is True and fx.match(rb"\d{3}-\d{4}", b"1234567") is False
+    res = fx.match(rb"\d{3}-\d{4}", [b"100-1002", b"1234567 ", b"999-0000"])
+    assert list(res) == [True, False, True]
+    assert fx.regex_f(r"foo(bar|baz)", "xxfoobarbaz") == b"foobar"
+    sub, length, frm, to, status, msg = fx.regex(r"foo(bar|baz)", "xxfoobarbaz")
+    assert (sub, length, frm, to, status, msg) == (b"foobar", 6, 3, 8, 0, "Given pattern is valid.")
+    subs, lens, frms, tos, status, _ = fx.regex(rb"[a-z]+\d+", [b"ab12  cd345", b"nothing", b"   z9"])
+    assert subs == [b"ab12", b"", b"z9"] and list(frms) == [1, 0, 4] and list(tos) == [4, 0, 5] and list(lens) == [4, 0, 2]
+    assert fx.is_valid_regex("[a-z") is False
+    assert fx.in_("あ+", "かあああ") is True and fx.regex_f("あ+", "かあああ") == "あああ".encode()
