@@ -398,6 +398,31 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
          ta[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(t | (A.out[static_cast<size_t>(t)] ? FXP_FLAG_BIT : 0));
       }
    h.off_TA = bl.put(ta.data(), ta.size() * 2);
+   {
+      // two-level class map of the BMP: the on-device decoder classifies a 2-/3-byte character with two table reads
+      // instead of a binary search over the interval starts
+      std::vector<uint16_t> page_of(1024);
+      std::vector<uint16_t> pages;
+      std::map<std::vector<uint16_t>, uint16_t> seen;
+      for (int pg = 0; pg < 1024; ++pg) {
+         std::vector<uint16_t> v(64);
+         int iv = interval_of(pg * 64);
+         for (int k = 0; k < 64; ++k) {
+            int32_t code = pg * 64 + k;
+            while (iv + 1 < nI && bounds[static_cast<size_t>(iv) + 1] <= code) ++iv;
+            v[static_cast<size_t>(k)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(iv)]);
+         }
+         auto it = seen.find(v);
+         if (it == seen.end()) {
+            it = seen.emplace(v, static_cast<uint16_t>(seen.size())).first;
+            pages.insert(pages.end(), v.begin(), v.end());
+         }
+         page_of[static_cast<size_t>(pg)] = it->second;
+      }
+      h.n_pages = static_cast<uint32_t>(seen.size());
+      h.off_cls_page = bl.put(page_of.data(), page_of.size() * 2);
+      h.off_cls_pages = bl.put(pages.data(), pages.size() * 2);
+   }
    std::vector<uint16_t> tr;
    if (R.ok) {
       tr.resize(static_cast<size_t>(R.n) * ncls);

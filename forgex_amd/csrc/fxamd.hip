@@ -317,14 +317,30 @@ struct TileRow {
    }
 };
 
+// Copy the program blob into LDS (prog_lds_bytes > 0) so that every table read of the row procedure is an LDS read.
+__device__ __forceinline__ const uint8_t* stage_program(const uint8_t* __restrict__ prog, uint8_t* lds, uint32_t prog_lds_bytes) {
+   if (prog_lds_bytes == 0) return prog;
+   const uint4* src = reinterpret_cast<const uint4*>(prog);
+   uint4* dst = reinterpret_cast<uint4*>(lds);
+   for (uint32_t i = threadIdx.x; i < prog_lds_bytes / 16; i += blockDim.x) dst[i] = src[i];
+   __syncthreads();
+   return lds;
+}
+
 // fixup != 0: only rows whose flag is FX_NEEDS_GENERAL are processed
 __global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
                                                    uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
-                                                   int fixup) {
+                                                   int fixup, uint32_t prog_lds_bytes) {
+   extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (fixup) {   // nothing to redo in this block: leave before touching the tables
+      const bool mine = row < n && flags[row] == FX_NEEDS_GENERAL;
+      if (!__syncthreads_or(mine ? 1 : 0)) return;
+   }
+   const uint8_t* pbase = stage_program(prog, reinterpret_cast<uint8_t*>(dyn_lds), prog_lds_bytes);
    if (row >= n) return;
    if (fixup && flags[row] != FX_NEEDS_GENERAL) return;
-   fxrow::ProgView pv{prog};
+   fxrow::ProgView pv(pbase);
    GlobalRow r{rows + row * (int64_t)L};
    fxrow::Result res;
    fxrow::run_row(pv, r, L, res);
@@ -335,8 +351,11 @@ __global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ ro
 
 // LDS-staged variant for 16-byte-multiple rows: one wave per block, dynamic LDS = 64*L bytes (L <= 1024)
 __global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
-                                                        uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to) {
-   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
+                                                        uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
+                                                        uint32_t prog_lds_bytes) {
+   extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
+   uint4* tiles = dyn_lds + prog_lds_bytes / 16;
+   const uint8_t* pbase = stage_program(prog, reinterpret_cast<uint8_t*>(dyn_lds), prog_lds_bytes);
    const uint32_t lane = threadIdx.x;
    const int CH = L >> 4;
    const int64_t row0 = (int64_t)blockIdx.x << 6;
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict
    __syncthreads();
    const int64_t row = row0 + lane;
    if (row >= n) return;
-   fxrow::ProgView pv{prog};
+   fxrow::ProgView pv(pbase);
    TileRow r{reinterpret_cast<const uint8_t*>(tiles), lane};
    fxrow::Result res;
    fxrow::run_row(pv, r, L, res);
@@ -579,21 +598,22 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
+   const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
    const bool fast = fast_applies(h, d_rows, row_len);
    if (fast) {
       FX_HIP(launch_fast_any(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
       // fix-up pass for rows holding bytes >= 0x80 (on-device UTF-8 decode path); a no-op read of the flags otherwise
-      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1);
+      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
       FX_HIP(hipGetLastError());
       p->last_path = 3;
       return FXAMD_OK;
    }
    if (aligned16 && row_len <= 1024) {
       const unsigned tblocks = (unsigned)((n + 63) / 64);
-      hipLaunchKernelGGL(fx_general_tiled, dim3(tblocks), dim3(64), (size_t)64 * row_len, st, d_rows, n, (int32_t)row_len, p->d_blob,
-                         d_flags, d_from, d_to);
+      hipLaunchKernelGGL(fx_general_tiled, dim3(tblocks), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob,
+                         d_flags, d_from, d_to, prog_lds);
    } else {
-      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 0);
+      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 0, prog_lds);
    }
    FX_HIP(hipGetLastError());
    p->last_path = 2;

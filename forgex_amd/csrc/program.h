@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 3u
+#define FXP_VERSION 4u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -51,7 +51,10 @@ struct FxpHeader {
    uint32_t off_fastA;       // uint8 [128][8]   next state of each of 8 states on an ASCII byte (fast path)
    uint32_t off_fastR;       // uint8 [128][8]
    uint32_t total_bytes;
-   uint32_t reserved[4];
+   uint32_t n_pages;         // distinct 64-code-point pages of the BMP class map
+   uint32_t off_cls_page;    // uint16 [1024]          page id of code points [64p, 64p+63], p = cp >> 6 (cp < 0x10000)
+   uint32_t off_cls_pages;   // uint16 [n_pages][64]   class of each code point of a page
+   uint32_t reserved[1];
 };
 
 #define FXP_STATE_MASK 0x7FFFu

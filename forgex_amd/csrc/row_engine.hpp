@@ -24,26 +24,54 @@
 
 namespace fxrow {
 
+// View of a program blob with every table pointer and scalar resolved ONCE (the blob may live in LDS or in global
+// memory; all reads below are single loads, no header indirection in the per-symbol loops).
 struct ProgView {
    const uint8_t* base;
-   FX_HD const FxpHeader& h() const { return *reinterpret_cast<const FxpHeader*>(base); }
-   FX_HD int32_t bound(uint32_t i) const { return reinterpret_cast<const int32_t*>(base + h().off_bounds)[i]; }
-   FX_HD uint32_t bound_cls(uint32_t i) const { return reinterpret_cast<const uint16_t*>(base + h().off_bound_cls)[i]; }
-   FX_HD uint32_t ascii_cls(uint32_t b) const { return reinterpret_cast<const uint16_t*>(base + h().off_ascii_cls)[b]; }
-   FX_HD uint32_t TA(uint32_t s, uint32_t c) const { return reinterpret_cast<const uint16_t*>(base + h().off_TA)[s * h().n_classes + c]; }
-   FX_HD uint32_t TR(uint32_t s, uint32_t c) const { return reinterpret_cast<const uint16_t*>(base + h().off_TR)[s * h().n_classes + c]; }
-   FX_HD uint32_t finalM(uint32_t s) const { return (base + h().off_finalM)[s]; }
-   FX_HD uint32_t prefix(uint32_t i) const { return (base + h().off_prefix)[i]; }
-   FX_HD uint32_t suffix(uint32_t i) const { return (base + h().off_suffix)[i]; }
-   FX_HD uint32_t all(uint32_t i) const { return (base + h().off_all)[i]; }
+   const FxpHeader* hd;
+   const int32_t* bounds;
+   const uint16_t *bound_cls_p, *ascii_p, *ta_p, *tr_p, *page_p, *pages_p;
+   const uint8_t *finalM_p, *prefix_p, *suffix_p, *all_p;
+   uint32_t ncls, n_bounds, cls_nul_v, cls_ffff_v;
+   FX_HD explicit ProgView(const uint8_t* b) : base(b) {
+      hd = reinterpret_cast<const FxpHeader*>(b);
+      const FxpHeader hh = *hd;
+      bounds = reinterpret_cast<const int32_t*>(b + hh.off_bounds);
+      bound_cls_p = reinterpret_cast<const uint16_t*>(b + hh.off_bound_cls);
+      ascii_p = reinterpret_cast<const uint16_t*>(b + hh.off_ascii_cls);
+      ta_p = reinterpret_cast<const uint16_t*>(b + hh.off_TA);
+      tr_p = reinterpret_cast<const uint16_t*>(b + hh.off_TR);
+      page_p = reinterpret_cast<const uint16_t*>(b + hh.off_cls_page);
+      pages_p = reinterpret_cast<const uint16_t*>(b + hh.off_cls_pages);
+      finalM_p = b + hh.off_finalM;
+      prefix_p = b + hh.off_prefix;
+      suffix_p = b + hh.off_suffix;
+      all_p = b + hh.off_all;
+      ncls = hh.n_classes;
+      n_bounds = hh.n_bounds;
+      cls_nul_v = hh.cls_nul;
+      cls_ffff_v = hh.cls_ffff;
+   }
+   FX_HD const FxpHeader& h() const { return *hd; }
+   FX_HD uint32_t ascii_cls(uint32_t b) const { return ascii_p[b]; }
+   FX_HD uint32_t TA(uint32_t s, uint32_t c) const { return ta_p[s * ncls + c]; }
+   FX_HD uint32_t TR(uint32_t s, uint32_t c) const { return tr_p[s * ncls + c]; }
+   FX_HD uint32_t finalM(uint32_t s) const { return finalM_p[s]; }
+   FX_HD uint32_t prefix(uint32_t i) const { return prefix_p[i]; }
+   FX_HD uint32_t suffix(uint32_t i) const { return suffix_p[i]; }
+   FX_HD uint32_t all(uint32_t i) const { return all_p[i]; }
    FX_HD uint32_t class_of_code(int32_t code) const {
-      uint32_t lo = 0, hi = h().n_bounds;   // last interval whose first code point is <= code
+      if (code < 0x10000) {   // BMP: page table (two reads)
+         const uint32_t pg = page_p[static_cast<uint32_t>(code) >> 6];
+         return pages_p[pg * 64u + (static_cast<uint32_t>(code) & 63u)];
+      }
+      uint32_t lo = 0, hi = n_bounds;   // last interval whose first code point is <= code
       while (hi - lo > 1) {
          uint32_t mid = (lo + hi) >> 1;
-         if (bound(mid) <= code) lo = mid;
+         if (bounds[mid] <= code) lo = mid;
          else hi = mid;
       }
-      return bound_cls(lo);
+      return bound_cls_p[lo];
    }
 };
 
@@ -80,7 +108,7 @@ FX_HD uint32_t fwd_symbol(const ProgView& pv, const Row& r, int L, int j, int& n
       }
    }
    next = j + 1;
-   return pv.h().cls_ffff;
+   return pv.cls_ffff_v;
 }
 
 // symbol that ENDS at 0-based text index j, given that j+1 is a character start (or the end of the text)
@@ -99,7 +127,7 @@ FX_HD uint32_t back_symbol(const ProgView& pv, const Row& r, int j, int& start) 
          return pv.class_of_code(decode(r, start, n));
       }
    }
-   return pv.h().cls_ffff;
+   return pv.cls_ffff_v;
 }
 
 // byte i (1-based) of NUL // text // NUL
@@ -117,7 +145,7 @@ FX_HD int anchored_max_match(const ProgView& pv, const Row& r, int L, int st) {
    int mm = 0;
    int j;   // 0-based text index of the next symbol
    if (st == 1) {
-      uint32_t e = pv.TA(cur, h.cls_nul);
+      uint32_t e = pv.TA(cur, pv.cls_nul_v);
       cur = e & FXP_STATE_MASK;
       if (e & FXP_FLAG_BIT) mm = 2;
       j = 0;
@@ -133,7 +161,7 @@ FX_HD int anchored_max_match(const ProgView& pv, const Row& r, int L, int st) {
       if (e & FXP_FLAG_BIT) mm = j + 2;
    }
    if (cur != 0) {   // trailing NUL
-      uint32_t e = pv.TA(cur, h.cls_nul);
+      uint32_t e = pv.TA(cur, pv.cls_nul_v);
       if (e & FXP_FLAG_BIT) mm = L + 3;
    }
    return mm;
@@ -209,7 +237,7 @@ FX_HD void search_engine(const ProgView& pv, const Row& r, int L, Result& out) {
             if (e & FXP_FLAG_BIT) s = start + 2;
             j = start - 1;
          }
-         uint32_t e = pv.TR(state, h.cls_nul);
+         uint32_t e = pv.TR(state, pv.cls_nul_v);
          if (e & FXP_FLAG_BIT) s = 1;
          if (s == 0) return;
          int mm = anchored_max_match(pv, r, L, s);

@@ -40,7 +40,7 @@ extern "C" {
 int hw_run(const char* pat, int64_t plen, int op, const uint8_t* row, int64_t L, int32_t* flag, int32_t* from, int32_t* to) {
    fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
    if (p.status != 0) return p.status;
-   fxrow::ProgView pv{p.blob.data()};
+   fxrow::ProgView pv(p.blob.data());
    HostRow r{row};
    fxrow::Result res;
    fxrow::run_row(pv, r, static_cast<int>(L), res);
@@ -54,7 +54,7 @@ int hw_batch(const char* pat, int64_t plen, int op, const uint8_t* rows, int64_t
              int32_t* to) {
    fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
    if (p.status != 0) return p.status;
-   fxrow::ProgView pv{p.blob.data()};
+   fxrow::ProgView pv(p.blob.data());
    for (int64_t i = 0; i < n; ++i) {
       HostRow r{rows + i * L};
       fxrow::Result res;
