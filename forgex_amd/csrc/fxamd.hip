@@ -349,6 +349,36 @@ __global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ ro
    if (to) to[row] = res.to;
 }
 
+// Fix-up pass after the fast kernel: every thread inspects 16 flags with one 16-byte load and only rows marked
+// FX_NEEDS_GENERAL (bytes >= 0x80: on-device UTF-8 decode needed) are re-matched, with the tables read from global memory.
+__global__ __launch_bounds__(256) void fx_fixup(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
+                                                 uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to) {
+   const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+   if (base >= n) return;
+   uint32_t marks = 0;
+   if (base + 16 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(flags + base);   // cudaMalloc'ed / torch buffers are 256-byte aligned
+      if (((v.x | v.y | v.z | v.w) & 0x80808080u) == 0) return;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) marks |= (((w[k >> 2] >> ((k & 3) * 8)) & 0xFFu) == FX_NEEDS_GENERAL ? 1u : 0u) << k;
+   } else {
+      for (int k = 0; base + k < n; ++k) marks |= (flags[base + k] == FX_NEEDS_GENERAL ? 1u : 0u) << k;
+   }
+   if (marks == 0) return;
+   fxrow::ProgView pv(prog);
+   for (int k = 0; k < 16; ++k) {
+      if (!((marks >> k) & 1u)) continue;
+      const int64_t row = base + k;
+      GlobalRow r{rows + row * (int64_t)L};
+      fxrow::Result res;
+      fxrow::run_row(pv, r, L, res);
+      flags[row] = (uint8_t)res.flag;
+      if (from) from[row] = res.from;
+      if (to) to[row] = res.to;
+   }
+}
+
 // LDS-staged variant for 16-byte-multiple rows: one wave per block, dynamic LDS = 64*L bytes (L <= 1024)
 __global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
@@ -603,7 +633,12 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    if (fast) {
       FX_HIP(launch_fast_any(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
       // fix-up pass for rows holding bytes >= 0x80 (on-device UTF-8 decode path); a no-op read of the flags otherwise
-      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
+      if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
+         const unsigned fblocks = (unsigned)((n + 4095) / 4096);
+         hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to);
+      } else {
+         hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
+      }
       FX_HIP(hipGetLastError());
       p->last_path = 3;
       return FXAMD_OK;
