@@ -265,6 +265,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    Dfa R;
    R.ncol = nI;
    R.ok = false;
+   bool r_has_skip = false;   // R distinguishes the SKIP symbol (fast path may translate UTF-8 in place)
    int R_start_raw = 0;
    const int i_nul = interval_of(0);
    if (op == OP_SEARCH) {
@@ -326,7 +327,42 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             for (int k = 0; k < nI; ++k) R.T[static_cast<size_t>(R_start_raw) * nI + k] = R.T[static_cast<size_t>(t) * nI + k];
          }
          R.init = R_start_raw;
-         minimise(R, -1);
+         // Extra column SKIP (index nI): the symbol the fast kernel substitutes for continuation bytes inside a valid
+         // multi-byte character.  It must leave W unchanged and CLEAR the hit (a hit belongs to the character's first
+         // byte only), i.e. (W,1) -> (W,0), (W,0) -> itself.  The twins (W,0) are added where missing.
+         const int nC = nI + 1;
+         {
+            std::vector<int> T2(static_cast<size_t>(R.n) * nC);
+            for (int st = 0; st < R.n; ++st)
+               for (int k = 0; k < nI; ++k) T2[static_cast<size_t>(st) * nC + k] = R.T[static_cast<size_t>(st) * nI + k];
+            std::map<std::vector<int>, int> twin_of_row;   // states with hit = 0, keyed by their transition row (same W <=> same row
+                                                           // is not guaranteed, so twins are created per hit state and merged by minimise)
+            int n0 = R.n;
+            for (int st = 0; st < n0; ++st) {
+               if (!R.out[static_cast<size_t>(st)]) {
+                  T2[static_cast<size_t>(st) * nC + nI] = st;
+                  continue;
+               }
+               int tw = R.n++;
+               R.out.push_back(0);
+               T2.resize(static_cast<size_t>(R.n) * nC);
+               for (int k = 0; k < nI; ++k) T2[static_cast<size_t>(tw) * nC + k] = T2[static_cast<size_t>(st) * nC + k];
+               T2[static_cast<size_t>(tw) * nC + nI] = tw;
+               T2[static_cast<size_t>(st) * nC + nI] = tw;
+            }
+            R.T.swap(T2);
+            R.ncol = nC;
+         }
+         Dfa Ru = R;
+         minimise(Ru, -1);
+         if (Ru.n <= 8) {
+            R = Ru;
+            r_has_skip = true;
+         } else {
+            // too many states once SKIP must be told apart: keep the ASCII-only fast path (SKIP column inert)
+            for (int st = 0; st < R.n; ++st) R.T[static_cast<size_t>(st) * nC + nI] = st;
+            minimise(R, -1);
+         }
       }
    }
 
@@ -339,7 +375,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
          std::vector<int> col;
          for (int s = 0; s < A.n; ++s) col.push_back(A.T[static_cast<size_t>(s) * nI + k]);
          if (R.ok)
-            for (int s = 0; s < R.n; ++s) col.push_back(R.T[static_cast<size_t>(s) * nI + k]);
+            for (int s = 0; s < R.n; ++s) col.push_back(R.T[static_cast<size_t>(s) * R.ncol + k]);
          auto it = m.find(col);
          if (it == m.end()) it = m.emplace(col, static_cast<int>(m.size())).first;
          cls_of[static_cast<size_t>(k)] = it->second;
@@ -350,7 +386,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    for (int k = 0; k < nI; ++k)
       if (rep_interval[static_cast<size_t>(cls_of[static_cast<size_t>(k)])] < 0) rep_interval[static_cast<size_t>(cls_of[static_cast<size_t>(k)])] = k;
    auto TA = [&](int s, int c) { return A.T[static_cast<size_t>(s) * nI + rep_interval[static_cast<size_t>(c)]]; };
-   auto TR = [&](int s, int c) { return R.T[static_cast<size_t>(s) * nI + rep_interval[static_cast<size_t>(c)]]; };
+   auto TR = [&](int s, int c) { return R.T[static_cast<size_t>(s) * R.ncol + rep_interval[static_cast<size_t>(c)]]; };
    auto class_of_code = [&](int32_t code) { return cls_of[static_cast<size_t>(interval_of(code))]; };
 
    // ---- 6. emit ---------------------------------------------------------------------------------------------------
@@ -444,7 +480,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    h.off_all = bl.put(lit.all.data(), lit.all.size());
 
    // ---- 7. fast path: <= 8 states per automaton, fused ASCII byte tables -----------------------------------------
-   bool fast = op == OP_SEARCH && R.ok && A.n <= 8 && R.n <= 8 && !has_suffix;
+   bool fast = op == OP_SEARCH && R.ok && A.n <= 8 && R.n <= 8 && !(prefilter && has_suffix);   // the suffix is only consulted by the candidate-list driver
    if (fast && prefilter) {
       // Candidate-list search == brute-force search on pure-ASCII rows iff the prefix is a NECESSARY, non-self-overlapping
       // beginning of every non-empty match.
@@ -467,7 +503,10 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       }
       fast = ok;
    }
-   std::vector<uint8_t> fa(128 * 8, 0), fr(128 * 8, 0);
+   // Symbol ids of the fast tables: 0..127 = the ASCII byte itself; 128+c = a multi-byte (or invalid) character of class c
+   // (fx_translate rewrites such bytes); 254 = KILL (all-dead row, feeds the end of a row); 255 = SKIP (continuation byte
+   // inside a valid character).
+   std::vector<uint8_t> fa(256 * 8, 0), fr(256 * 8, 0);
    if (fast) {
       for (int b = 0; b < 128; ++b)
          for (int s = 0; s < 8; ++s) {
@@ -475,6 +514,19 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             fr[static_cast<size_t>(b) * 8 + s] = s < R.n ? static_cast<uint8_t>(TR(s, ac[static_cast<size_t>(b)])) : static_cast<uint8_t>(0);
          }
       h.flags |= FXP_F_FAST_OK;
+      const bool utf8 = r_has_skip && !prefilter && ncls <= 126;   // id 254 stays an all-dead row (end-of-row kill symbol)
+      if (utf8) {
+         h.flags |= FXP_F_FAST_UTF8;
+         for (int c = 0; c < ncls; ++c)
+            for (int s = 0; s < 8; ++s) {
+               fa[static_cast<size_t>(128 + c) * 8 + s] = s < A.n ? static_cast<uint8_t>(TA(s, c)) : 0;
+               fr[static_cast<size_t>(128 + c) * 8 + s] = s < R.n ? static_cast<uint8_t>(TR(s, c)) : static_cast<uint8_t>(0);
+            }
+         for (int s = 0; s < 8; ++s) {
+            fa[255u * 8 + s] = static_cast<uint8_t>(s < A.n ? s : 0);
+            fr[255u * 8 + s] = s < R.n ? static_cast<uint8_t>(R.T[static_cast<size_t>(s) * R.ncol + nI]) : static_cast<uint8_t>(0);
+         }
+      }
       int accmin = A.n, hitmin = R.n;
       for (int s = A.n - 1; s >= 0 && A.out[static_cast<size_t>(s)]; --s) accmin = s;
       for (int s = R.n - 1; s >= 0 && R.out[static_cast<size_t>(s)]; --s) hitmin = s;

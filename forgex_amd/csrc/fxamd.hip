@@ -87,13 +87,20 @@ __device__ __forceinline__ uint32_t chain8_back(const uint2 (&f)[8], uint32_t& s
    return max(max(m0, m1), m2);
 }
 
+// ---- on-device UTF-8 decode for the fast kernel (FXP_F_FAST_UTF8) -------------------------------------------------------
+// A tile that holds any byte >= 0x80 is rewritten IN REGISTERS, before it is stored to LDS, into fast-path symbol ids:
+// ASCII bytes stay; the first byte of a structurally valid multi-byte character becomes 128 + class(code point); its
+// continuation bytes become 255 (SKIP); every byte of an invalid sequence becomes 128 + class(U+FFFF) -- the reference's
+// strict stepping (utf8_m.f90:44-140,168-246) and arithmetic decode (:338-430), decided per position from a +-3 byte
+// window (a lead byte is always a character start; a continuation byte is inside a character iff the nearest
+// non-continuation byte within 3 to its left is a lead whose whole sequence is continuation bytes).
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
-// at index L, then 0x80 (a byte whose table row is all-dead) -- so end-of-row needs no per-byte test.
+// at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
 __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
    const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8
    const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
-   lo = p < L ? r.x : (p == L ? 0x80808000u : 0x80808080u);
-   hi = p < L ? r.y : 0x80808080u;
+   lo = p < L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);   // 0xFE: the symbol id whose table row is all-dead
+   hi = p < L ? r.y : 0xFEFEFEFEu;
 }
 __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;
@@ -120,11 +127,16 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
    o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
 }
 
-template <int CH, bool SPANS>
+// FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
+//                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
+//                 the offending rows are marked individually for the general kernel's fix-up.
+// FIXUP = true:  second pass over the symbol-id workspace written by fx_translate; only marked tiles are scanned.
+template <int CH, bool SPANS, bool FIXUP>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
-                                                        int32_t* __restrict__ to) {
+                                                        int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred) {
    constexpr int L = 16 * CH;
+   if (FIXUP && *n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
    __shared__ uint2 tabR[256];
    __shared__ uint2 tabA[256];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells
@@ -132,24 +144,31 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    {
       const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
       const uint2* gA = reinterpret_cast<const uint2*>(prog + h->off_fastA);
-      uint32_t t = threadIdx.x;   // 256 threads: entries 0..127 real, 128..255 dead (rows with such bytes are redone)
-      tabR[t] = t < 128 ? gR[t] : make_uint2(0, 0);
-      tabA[t] = t < 128 ? gA[t] : make_uint2(0, 0);
+      uint32_t t = threadIdx.x;   // 256 threads = 256 symbol ids (ids >= 128 are all-dead rows unless FXP_F_FAST_UTF8)
+      tabR[t] = gR[t];
+      tabA[t] = gA[t];
    }
    __syncthreads();
    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const bool utf8 = (h->flags & FXP_F_FAST_UTF8) != 0;
    uint4* tile = tiles + wave * (64 * CH);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
 
    uint4 stage[CH];   // next tile's global loads stay in flight while the current tile is scanned
-   if (wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   if (!FIXUP && wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
+      if (FIXUP) {
+         const int64_t rr = row0 + lane;
+         const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
+         if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;   // wave-uniform: nothing deferred in this tile
+         load_tile<CH>(stage, rows, row0, n, lane);
+      }
       store_tile<CH>(stage, tile, lane);
       // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
-      if (t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+      if (!FIXUP && t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
 
       // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
       // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          state = __builtin_amdgcn_perm(fz.y, fz.x, state);
          s = state >= fp.hit_min ? 1u : s;
       }
-   const bool nonascii = (na & 0x80808080u) != 0;
+   const bool nonascii = !FIXUP && !utf8 && (na & 0x80808080u) != 0;   // such rows go to the general kernel's fix-up pass
       const int64_t row = row0 + lane;
 
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
@@ -291,12 +310,73 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
       }
       if (nonascii) flag = FX_NEEDS_GENERAL;
+      if (!FIXUP && utf8) {
+         // a tile holding any byte >= 0x80 is deferred as a whole to fx_translate + the second pass (wave-uniform decision;
+         // the scan above was done on raw bytes and is discarded for such tiles)
+         if (__builtin_amdgcn_ballot_w64((na & 0x80808080u) != 0) != 0) {
+            flag = FX_NEEDS_GENERAL;
+            if (lane == 0) atomicAdd(n_deferred, 1u);
+         }
+      }
       if (row < n) {
          flags[row] = (uint8_t)flag;
          if (SPANS) {
             from[row] = fr;
             to[row] = tt;
          }
+      }
+   }
+}
+
+// =========================================================================================================
+// fx_translate: UTF-8 decode of the deferred tiles.  One thread = one 16-byte cell (row R, chunk k) of a marked tile: it
+// reads the cell and the 4 bytes on either side from the caller's rows and writes 16 symbol ids to the workspace (same
+// layout as the rows).  Embarrassingly parallel and HBM-bound; the class tables are read from the blob through L1/L2.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void fx_translate(const uint8_t* __restrict__ rows, int64_t n, int32_t CH, const uint8_t* __restrict__ prog,
+                                                     const uint8_t* __restrict__ flags, uint8_t* __restrict__ ws, uint32_t tables_in_lds,
+                                                     const uint32_t* __restrict__ n_deferred) {
+   extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
+   if (*n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
+   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
+   if (tables_in_lds) {   // BMP class map (page index + pages) into LDS: two LDS reads per character instead of two L2 reads
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(dyn_lds);
+      const uint32_t n16 = 1024u + h->n_pages * 64u;
+      for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      __syncthreads();
+      page_p = l16;
+      pages_p = l16 + 1024;
+   }
+   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
+                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
+   const uint32_t sym_ffff = 128u + h->cls_ffff;
+   const int64_t n_tiles = (n + 63) >> 6;
+   const uint32_t lane = threadIdx.x & 63u;
+   // work item = (tile, quarter of its chunk range): four waves share a tile's cells
+   const int64_t n_items = n_tiles * 4;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wave_stride = (int64_t)gridDim.x * 4;
+   const int q_per = (CH + 3) / 4;
+   for (int64_t it = wave_global; it < n_items; it += wave_stride) {
+      const int64_t t = it >> 2;
+      const int part = (int)(it & 3);
+      const int64_t row0 = t << 6;
+      const bool marked = row0 + lane < n && flags[row0 + lane] == FX_NEEDS_GENERAL;
+      if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;
+      const int64_t rows_left = n - row0;
+      const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (uint32_t)rows_left * CH;
+      const uint4* src = reinterpret_cast<const uint4*>(rows + row0 * (int64_t)(16 * CH));
+      uint4* dst = reinterpret_cast<uint4*>(ws + row0 * (int64_t)(16 * CH));
+      for (int q = part * q_per; q < (part + 1) * q_per && q < CH; ++q) {
+         const uint32_t p = q * 64 + lane;
+         if (p >= valid_pieces) continue;
+         const uint32_t k = p % (uint32_t)CH;
+         const uint4 c = src[p];
+         const uint32_t prev = k > 0 ? reinterpret_cast<const uint32_t*>(src + p)[-1] : 0u;
+         const uint32_t next = k + 1 < (uint32_t)CH ? reinterpret_cast<const uint32_t*>(src + p)[4] : 0u;
+         const fxrow::Cell16 o = fxrow::translate_cell16(prev, c.x, c.y, c.z, c.w, next, ct, sym_ffff);
+         dst[p] = make_uint4(o.x, o.y, o.z, o.w);
       }
    }
 }
@@ -425,6 +505,9 @@ struct fxamd_program {
    std::mutex mu;
    int device = -1;
    uint8_t* d_blob = nullptr;
+   uint32_t* d_counter = nullptr;   // number of tiles the first fast pass deferred (non-ASCII), reset per call
+   uint8_t* d_ws = nullptr;     // symbol-id workspace of the UTF-8 second pass
+   size_t ws_bytes = 0;
    int last_path = 0;
 };
 
@@ -439,19 +522,49 @@ static int hip_fail(hipError_t e) {
       if (_e != hipSuccess) return hip_fail(_e);      \
    } while (0)
 
-template <int CH>
+template <int CH, bool FIXUP>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
-                              int32_t* to, hipStream_t st) {
+                              int32_t* to, uint32_t* n_deferred, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
    if (blocks > cap) blocks = cap;
    const size_t lds = (size_t)4 * 64 * CH * 16;
    if (from && to)
-      hipLaunchKernelGGL((fx_search_fast<CH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to);
+      hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred);
    else
-      hipLaunchKernelGGL((fx_search_fast<CH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to);
+      hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred);
    return hipGetLastError();
+}
+
+static bool fast_applies(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
+   return (h.flags & FXP_F_FAST_OK) && h.mode == FXP_MODE_SEARCH_ENGINE && aligned16 &&
+          (row_len == 16 || row_len == 32 || row_len == 48 || row_len == 64 || row_len == 96 || row_len == 128 || row_len == 192 ||
+           row_len == 256);
+}
+
+template <bool FIXUP>
+static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                                  uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st) {
+   FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
+                 make_uint2(0, 0)};
+   {
+      uint64_t hb = 0;
+      for (uint32_t q = 0; q < 8; ++q)
+         if (q >= h.fast_hitR_min && q < h.nR) hb |= (uint64_t)0xFF << (8 * q);
+      fp.H = make_uint2((uint32_t)hb, (uint32_t)(hb >> 32));
+   }
+   switch (row_len >> 4) {
+      case 1: return launch_fast<1, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 2: return launch_fast<2, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 3: return launch_fast<3, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 4: return launch_fast<4, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 6: return launch_fast<6, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 8: return launch_fast<8, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 12: return launch_fast<12, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      default: return launch_fast<16, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+   }
 }
 
 extern "C" {
@@ -516,6 +629,8 @@ int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64
 void fxamd_program_free(fxamd_program* p) {
    if (!p) return;
    if (p->d_blob) (void)hipFree(p->d_blob);
+   if (p->d_ws) (void)hipFree(p->d_ws);
+   if (p->d_counter) (void)hipFree(p->d_counter);
    delete p;
 }
 int32_t fxamd_program_status(const fxamd_program* p) { return p ? p->prog.status : FXAMD_E_ARG; }
@@ -567,36 +682,29 @@ int fxamd_program_upload(fxamd_program* p) {
       p->d_blob = nullptr;
    }
    FX_HIP(hipMalloc((void**)&p->d_blob, p->prog.blob.size()));
+   if (!p->d_counter) FX_HIP(hipMalloc((void**)&p->d_counter, 16));
    FX_HIP(hipMemcpy(p->d_blob, p->prog.blob.data(), p->prog.blob.size(), hipMemcpyHostToDevice));
    p->device = dev;
    return FXAMD_OK;
 }
 
+int fxamd_program_reserve(fxamd_program* p, int64_t n, int64_t row_len) {
+   if (!p || n < 0 || row_len < 0) return FXAMD_E_ARG;
+   if (p->prog.status != 0 || !(p->prog.hdr().flags & FXP_F_FAST_UTF8)) return FXAMD_OK;   // no workspace needed
+   const size_t need = (size_t)n * (size_t)row_len;
+   std::lock_guard<std::mutex> g(p->mu);
+   if (need <= p->ws_bytes) return FXAMD_OK;
+   if (p->d_ws) {
+      (void)hipFree(p->d_ws);
+      p->d_ws = nullptr;
+      p->ws_bytes = 0;
+   }
+   FX_HIP(hipMalloc((void**)&p->d_ws, need));
+   p->ws_bytes = need;
+   return FXAMD_OK;
+}
+
 int fxamd_last_path(const fxamd_program* p) { return p ? p->last_path : FXAMD_E_ARG; }
-
-static bool fast_applies(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
-   return (h.flags & FXP_F_FAST_OK) && h.mode == FXP_MODE_SEARCH_ENGINE && aligned16 &&
-          (row_len == 32 || row_len == 64 || row_len == 128 || row_len == 256);
-}
-
-static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
-                                  uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
-   FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 make_uint2(0, 0)};
-   {
-      uint64_t hb = 0;
-      for (uint32_t q = 0; q < 8; ++q)
-         if (q >= h.fast_hitR_min && q < h.nR) hb |= (uint64_t)0xFF << (8 * q);
-      fp.H = make_uint2((uint32_t)hb, (uint32_t)(hb >> 32));
-   }
-   switch (row_len >> 4) {
-      case 2: return launch_fast<2>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
-      case 4: return launch_fast<4>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
-      case 8: return launch_fast<8>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
-      default: return launch_fast<16>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, st);
-   }
-}
 
 int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
                            int32_t* d_to, void* hip_stream) {
@@ -606,7 +714,8 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (!fast_applies(h, d_rows, row_len)) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
-   FX_HIP(launch_fast_any(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, (hipStream_t)hip_stream));
+   FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, (hipStream_t)hip_stream));
+   FX_HIP(launch_fast_any<false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, (hipStream_t)hip_stream));
    return FXAMD_OK;
 }
 
@@ -631,8 +740,28 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
    const bool fast = fast_applies(h, d_rows, row_len);
    if (fast) {
-      FX_HIP(launch_fast_any(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
-      // fix-up pass for rows holding bytes >= 0x80 (on-device UTF-8 decode path); a no-op read of the flags otherwise
+      if (h.flags & FXP_F_FAST_UTF8) {
+         // workspace for the symbol-id image of deferred (non-ASCII) tiles; reserve it up front to keep this call allocation-free
+         rc = fxamd_program_reserve(p, n, row_len);
+         if (rc != FXAMD_OK) return rc;
+      }
+      FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
+      FX_HIP(launch_fast_any<false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
+      if (h.flags & FXP_F_FAST_UTF8) {
+         // tiles holding bytes >= 0x80 were deferred: decode them to symbol ids (fx_translate), then scan only those tiles
+         const int64_t n_tiles = (n + 63) >> 6;
+         int64_t tb = n_tiles;   // 4 work items (tile quarters) per tile, 4 waves per block
+         if (tb > 256 * 8) tb = 256 * 8;
+         const uint32_t tl_bytes = (1024u + h.n_pages * 64u) * 2u;
+         const uint32_t tl = tl_bytes <= 48u * 1024u ? 1u : 0u;
+         hipLaunchKernelGGL(fx_translate, dim3((unsigned)tb), dim3(256), tl ? tl_bytes : 0, st, d_rows, n, (int32_t)(row_len >> 4), p->d_blob,
+                            d_flags, p->d_ws, tl, p->d_counter);
+         FX_HIP(hipGetLastError());
+         FX_HIP(launch_fast_any<true>(h, p->d_blob, p->d_ws, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
+         p->last_path = 1;
+         return FXAMD_OK;
+      }
+      // fix-up pass for rows holding bytes >= 0x80 (general kernel's decode path); a cheap read of the flags otherwise
       if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
          const unsigned fblocks = (unsigned)((n + 4095) / 4096);
          hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to);

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 4u
+#define FXP_VERSION 5u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -29,7 +29,8 @@ enum FxpFlags {
    FXP_F_HAS_SUFFIX = 1u << 2,      // suffix literal is not blank
    FXP_F_FAST_OK = 1u << 3,         // <=8-state byte tables present and brute-force semantics proven equivalent
    FXP_F_HAS_R = 1u << 4,           // reverse DFA present (else: bounded restart loop)
-   FXP_F_MATCH_LITERAL = 1u << 5,   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
+   FXP_F_MATCH_LITERAL = 1u << 5,
+   FXP_F_FAST_UTF8 = 1u << 6,       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
 };
 
 struct FxpHeader {
@@ -48,8 +49,8 @@ struct FxpHeader {
    uint32_t off_hitR;        // uint8  [nR]
    uint32_t off_finalM;      // uint8  [nA]   .match. verdict of a state reached after the last text byte
    uint32_t off_prefix, off_suffix, off_all;   // raw bytes
-   uint32_t off_fastA;       // uint8 [128][8]   next state of each of 8 states on an ASCII byte (fast path)
-   uint32_t off_fastR;       // uint8 [128][8]
+   uint32_t off_fastA;       // uint8 [256][8]   next state of each of 8 states per fast-path symbol id:
+   uint32_t off_fastR;       // uint8 [256][8]   0..127 ASCII byte, 128+c character of class c, 255 SKIP
    uint32_t total_bytes;
    uint32_t n_pages;         // distinct 64-code-point pages of the BMP class map
    uint32_t off_cls_page;    // uint16 [1024]          page id of code points [64p, 64p+63], p = cp >> 6 (cp < 0x10000)

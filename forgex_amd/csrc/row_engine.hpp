@@ -184,6 +184,76 @@ FX_HD int find_wrapped(const Row& r, int L, PatFn pat, int m, int lo) {
    return 0;
 }
 
+// ---- UTF-8 -> fast-path symbol ids (fx_translate kernel; also compiled by the test-only host harness) ---------------
+FX_HD uint32_t u8_is_cont(uint32_t b) { return (b & 0xC0u) == 0x80u; }
+FX_HD uint32_t u8_lead_len(uint32_t b) { return b >= 0xF8u ? 0u : (b >= 0xF0u ? 4u : (b >= 0xE0u ? 3u : (b >= 0xC0u ? 2u : 0u))); }
+
+// w[0] = last dword of the previous cell of the row (0 at the row start), w[1..4] = this cell, w[5] = first dword of the next cell
+struct ClassTables {   // plain pointers only
+   const uint16_t *page_p, *pages_p, *bound_cls_p;
+   const int32_t* bounds;
+   uint32_t n_bounds;
+   FX_HD uint32_t class_of_code(int32_t code) const {
+      if (code < 0x10000) return pages_p[(uint32_t)page_p[(uint32_t)code >> 6] * 64u + ((uint32_t)code & 63u)];
+      uint32_t lo = 0, hi = n_bounds;
+      while (hi - lo > 1) {
+         const uint32_t mid = (lo + hi) >> 1;
+         if (bounds[mid] <= code) lo = mid;
+         else hi = mid;
+      }
+      return bound_cls_p[lo];
+   }
+};
+
+struct Cell16 {
+   uint32_t x, y, z, w;
+};
+FX_HD Cell16 translate_cell16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, const ClassTables& pv,
+                              uint32_t sym_ffff) {
+   const uint32_t w[6] = {w0, w1, w2, w3, w4, w5};
+   if (((w[1] | w[2] | w[3] | w[4]) & 0x80808080u) == 0) return Cell16{w[1], w[2], w[3], w[4]};
+   // phase 1: per position, everything except the class of a valid multi-byte character
+   uint32_t sym[16], code[16];
+#pragma unroll
+   for (int q = 0; q < 16; ++q) {
+      auto B = [&](int i) -> uint32_t {   // byte at cell offset i, -4 <= i < 20
+         const int j = i + 4;
+         return (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+      };
+      const uint32_t b0 = B(q);
+      const uint32_t bm1 = B(q - 1), bm2 = B(q - 2), bm3 = B(q - 3), bp1 = B(q + 1), bp2 = B(q + 2), bp3 = B(q + 3);
+      const bool cp1 = u8_is_cont(bp1), cp2 = u8_is_cont(bp2), cp3 = u8_is_cont(bp3);
+      const bool cm1 = u8_is_cont(bm1), cm2 = u8_is_cont(bm2);
+      const uint32_t l1 = u8_lead_len(bm1), l2 = u8_lead_len(bm2), l3 = u8_lead_len(bm3);
+      const bool covered = (l1 >= 2 && (l1 < 3 || cp1) && (l1 < 4 || cp2)) || (cm1 && l2 >= 3 && (l2 < 4 || cp1)) || (cm1 && cm2 && l3 == 4);
+      const uint32_t n0 = u8_lead_len(b0);
+      const bool valid = n0 >= 2 && cp1 && (n0 < 3 || cp2) && (n0 < 4 || cp3);
+      uint32_t cd = n0 == 2 ? (b0 & 0x1Fu) : (n0 == 3 ? (b0 & 0x0Fu) : (b0 & 0x07u));
+      cd = (cd << 6) | (bp1 & 0x3Fu);
+      cd = n0 >= 3 ? (cd << 6) | (bp2 & 0x3Fu) : cd;
+      cd = n0 >= 4 ? (cd << 6) | (bp3 & 0x3Fu) : cd;
+      code[q] = valid ? cd : 0xFFFFFFFFu;   // 0xFFFFFFFF: no class lookup wanted
+      sym[q] = b0 < 0x80u ? b0 : ((u8_is_cont(b0) && covered) ? 255u : sym_ffff);
+   }
+   // phase 2: class lookups, all independent (two table reads each; BMP only here)
+   uint32_t pg[16];
+#pragma unroll
+   for (int q = 0; q < 16; ++q) pg[q] = pv.page_p[code[q] < 0x10000u ? (code[q] >> 6) : 0u];
+#pragma unroll
+   for (int q = 0; q < 16; ++q) {
+      const uint32_t c = pv.pages_p[pg[q] * 64u + (code[q] & 63u)];
+      sym[q] = code[q] < 0x10000u ? 128u + c : sym[q];
+   }
+   // phase 3 (rare): characters beyond the BMP -> binary search over the interval starts
+#pragma unroll
+   for (int q = 0; q < 16; ++q)
+      if (code[q] != 0xFFFFFFFFu && code[q] >= 0x10000u) sym[q] = 128u + pv.class_of_code((int32_t)code[q]);
+   uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+   for (int q = 0; q < 16; ++q) out[q >> 2] |= sym[q] << ((q & 3) * 8);
+   return Cell16{out[0], out[1], out[2], out[3]};
+}
+
 struct Result {
    uint32_t flag;   // verdict of `.in.` / `.match.`
    int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none

@@ -5,6 +5,7 @@
 // Speaks the I/M/R/V protocol of oracle/ref_driver.f90 (answers "U <status>" for patterns the GPU build
 // does not support, e.g. DFA state explosion).
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -65,6 +66,39 @@ int hw_batch(const char* pat, int64_t plen, int op, const uint8_t* rows, int64_t
    }
    return 0;
 }
+// symbol-id image of ONE row (length L, multiple of 16) as fx_translate produces it; `expect` gets the same image derived
+// from the strict forward parse (fwd_symbol).  Returns 0, or status / -1 when the program has no UTF-8 fast tables.
+int hw_translate(const char* pat, int64_t plen, const uint8_t* row, int64_t L, uint8_t* got, uint8_t* expect) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), fxc::OP_SEARCH);
+   if (p.status != 0) return p.status;
+   const FxpHeader& h = p.hdr();
+   if (!(h.flags & FXP_F_FAST_UTF8) || (L & 15)) return -1;
+   const uint8_t* b = p.blob.data();
+   fxrow::ClassTables ct{reinterpret_cast<const uint16_t*>(b + h.off_cls_page), reinterpret_cast<const uint16_t*>(b + h.off_cls_pages),
+                         reinterpret_cast<const uint16_t*>(b + h.off_bound_cls), reinterpret_cast<const int32_t*>(b + h.off_bounds), h.n_bounds};
+   const uint32_t sym_ffff = 128u + h.cls_ffff;
+   const int CH = static_cast<int>(L / 16);
+   for (int k = 0; k < CH; ++k) {
+      uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+      if (k > 0) std::memcpy(&w[0], row + 16 * k - 4, 4);
+      std::memcpy(&w[1], row + 16 * k, 16);
+      if (k + 1 < CH) std::memcpy(&w[5], row + 16 * k + 16, 4);
+      fxrow::Cell16 o = fxrow::translate_cell16(w[0], w[1], w[2], w[3], w[4], w[5], ct, sym_ffff);
+      std::memcpy(got + 16 * k, &o, 16);
+   }
+   fxrow::ProgView pv(b);
+   HostRow r{row};
+   int j = 0;
+   while (j < L) {
+      int next;
+      uint32_t cls = fxrow::fwd_symbol(pv, r, static_cast<int>(L), j, next);
+      expect[j] = row[j] < 0x80 ? row[j] : static_cast<uint8_t>(128u + cls);
+      for (int q = j + 1; q < next; ++q) expect[q] = 255;
+      j = next;
+   }
+   return 0;
+}
+
 // program facts for tests: fills info[0..7] = mode, flags, nA, nR, n_classes, status, total_bytes, n_bounds
 void hw_info(const char* pat, int64_t plen, int op, int32_t* info) {
    fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);

@@ -84,7 +84,7 @@ def test_config_rows_vs_oracle(fx, cfg, n):
     _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
     assert np.array_equal(f2, of)
     if cfg in ("cfg2", "cfg3", "cfg5"):
-        assert prog.last_path() == 3   # fast kernel (+ no-op fix-up)
+        assert prog.last_path() in (1, 3)   # fast kernel
 
 
 def test_fast_and_general_kernels_agree(fx):
@@ -95,7 +95,7 @@ def test_fast_and_general_kernels_agree(fx):
     pat = synth.PATTERNS["cfg3"]
     p = fx.Program(pat, fx.OP_SEARCH)
     f1, a1, b1 = p.match_device(rows)
-    assert p.last_path() == 3
+    assert p.last_path() in (1, 3)
     wide = torch.cat([rows, torch.full((rows.shape[0], 1), 33, dtype=torch.uint8, device=rows.device)], dim=1).contiguous()  # '!' appended
     f2, a2, b2 = p.match_device(wide)
     assert p.last_path() == 2
