@@ -130,11 +130,11 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
 //                 the offending rows are marked individually for the general kernel's fix-up.
-// FIXUP = true:  second pass over the symbol-id workspace written by fx_translate; only marked tiles are scanned.
+// FIXUP = true:  second pass: only marked tiles are loaded, decoded from UTF-8 to symbol ids in LDS, then scanned.
 template <int CH, bool SPANS, bool FIXUP>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
-                                                        int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred) {
+                                                        int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds) {
    constexpr int L = 16 * CH;
    if (FIXUP && *n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
    __shared__ uint2 tabR[256];
@@ -151,11 +151,26 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    __syncthreads();
    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
    const bool utf8 = (h->flags & FXP_F_FAST_UTF8) != 0;
+   // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
+   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
+   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
+   if (FIXUP && class_map_in_lds) {
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
+      const uint32_t n16 = 1024u + h->n_pages * 64u;
+      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      __syncthreads();
+      page_p = l16;
+      pages_p = l16 + 1024;
+   }
+   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
+                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
+   const uint32_t sym_ffff = 128u + h->cls_ffff;
    uint4* tile = tiles + wave * (64 * CH);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
 
+   bool any_deferred = false;   // wave-uniform: this wave deferred at least one tile to the second pass
    uint4 stage[CH];   // next tile's global loads stay in flight while the current tile is scanned
    if (!FIXUP && wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
@@ -166,9 +181,34 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;   // wave-uniform: nothing deferred in this tile
          load_tile<CH>(stage, rows, row0, n, lane);
       }
+      if (!FIXUP && utf8) {
+         // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
+         // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
+         const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+         if (__builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0) {
+            if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
+            any_deferred = true;
+            if (t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+            continue;
+         }
+      }
       store_tile<CH>(stage, tile, lane);
       // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
       if (!FIXUP && t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+      if (FIXUP) {
+         // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
+         // (fxrow::translate_cell16).  The 4 bytes before / after a cell are taken from the ORIGINAL neighbours: the
+         // previous cell's last dword is kept in a register, the next cell is read before anything overwrites it.
+         uint32_t prev = 0;
+         uint4 cur = tile[tile_cell(lane, 0)];
+         for (int k = 0; k < CH; ++k) {
+            const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+            const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+            tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+            prev = cur.w;
+            cur = nxt;
+         }
+      }
 
       // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
       // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
@@ -225,7 +265,12 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          state = __builtin_amdgcn_perm(fz.y, fz.x, state);
          s = state >= fp.hit_min ? 1u : s;
       }
-   const bool nonascii = !FIXUP && !utf8 && (na & 0x80808080u) != 0;   // such rows go to the general kernel's fix-up pass
+      // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
+      // TILE is deferred to the second pass (wave-uniform; the raw-byte scan above is discarded and the
+      // forward walk below is skipped).
+      const bool row_hi = !FIXUP && (na & 0x80808080u) != 0;
+      const bool defer_tile = !FIXUP && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
+      const bool nonascii = (row_hi && !utf8) || defer_tile;
       const int64_t row = row0 + lane;
 
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
@@ -310,14 +355,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
       }
       if (nonascii) flag = FX_NEEDS_GENERAL;
-      if (!FIXUP && utf8) {
-         // a tile holding any byte >= 0x80 is deferred as a whole to fx_translate + the second pass (wave-uniform decision;
-         // the scan above was done on raw bytes and is discarded for such tiles)
-         if (__builtin_amdgcn_ballot_w64((na & 0x80808080u) != 0) != 0) {
-            flag = FX_NEEDS_GENERAL;
-            if (lane == 0) atomicAdd(n_deferred, 1u);
-         }
-      }
+      any_deferred = any_deferred || defer_tile;
       if (row < n) {
          flags[row] = (uint8_t)flag;
          if (SPANS) {
@@ -326,59 +364,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          }
       }
    }
-}
-
-// =========================================================================================================
-// fx_translate: UTF-8 decode of the deferred tiles.  One thread = one 16-byte cell (row R, chunk k) of a marked tile: it
-// reads the cell and the 4 bytes on either side from the caller's rows and writes 16 symbol ids to the workspace (same
-// layout as the rows).  Embarrassingly parallel and HBM-bound; the class tables are read from the blob through L1/L2.
-// =========================================================================================================
-__global__ __launch_bounds__(256) void fx_translate(const uint8_t* __restrict__ rows, int64_t n, int32_t CH, const uint8_t* __restrict__ prog,
-                                                     const uint8_t* __restrict__ flags, uint8_t* __restrict__ ws, uint32_t tables_in_lds,
-                                                     const uint32_t* __restrict__ n_deferred) {
-   extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
-   if (*n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
-   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
-   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
-   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
-   if (tables_in_lds) {   // BMP class map (page index + pages) into LDS: two LDS reads per character instead of two L2 reads
-      uint16_t* l16 = reinterpret_cast<uint16_t*>(dyn_lds);
-      const uint32_t n16 = 1024u + h->n_pages * 64u;
-      for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
-      __syncthreads();
-      page_p = l16;
-      pages_p = l16 + 1024;
-   }
-   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
-                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
-   const uint32_t sym_ffff = 128u + h->cls_ffff;
-   const int64_t n_tiles = (n + 63) >> 6;
-   const uint32_t lane = threadIdx.x & 63u;
-   // work item = (tile, quarter of its chunk range): four waves share a tile's cells
-   const int64_t n_items = n_tiles * 4;
-   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), wave_stride = (int64_t)gridDim.x * 4;
-   const int q_per = (CH + 3) / 4;
-   for (int64_t it = wave_global; it < n_items; it += wave_stride) {
-      const int64_t t = it >> 2;
-      const int part = (int)(it & 3);
-      const int64_t row0 = t << 6;
-      const bool marked = row0 + lane < n && flags[row0 + lane] == FX_NEEDS_GENERAL;
-      if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;
-      const int64_t rows_left = n - row0;
-      const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (uint32_t)rows_left * CH;
-      const uint4* src = reinterpret_cast<const uint4*>(rows + row0 * (int64_t)(16 * CH));
-      uint4* dst = reinterpret_cast<uint4*>(ws + row0 * (int64_t)(16 * CH));
-      for (int q = part * q_per; q < (part + 1) * q_per && q < CH; ++q) {
-         const uint32_t p = q * 64 + lane;
-         if (p >= valid_pieces) continue;
-         const uint32_t k = p % (uint32_t)CH;
-         const uint4 c = src[p];
-         const uint32_t prev = k > 0 ? reinterpret_cast<const uint32_t*>(src + p)[-1] : 0u;
-         const uint32_t next = k + 1 < (uint32_t)CH ? reinterpret_cast<const uint32_t*>(src + p)[4] : 0u;
-         const fxrow::Cell16 o = fxrow::translate_cell16(prev, c.x, c.y, c.z, c.w, next, ct, sym_ffff);
-         dst[p] = make_uint4(o.x, o.y, o.z, o.w);
-      }
-   }
+   // one plain store per wave (not an atomic per tile: 16k same-address atomics cost ~0.2 ms); the value only gates the second pass
+   if (!FIXUP && any_deferred && lane == 0) *n_deferred = 1u;
 }
 
 // =========================================================================================================
@@ -506,8 +493,6 @@ struct fxamd_program {
    int device = -1;
    uint8_t* d_blob = nullptr;
    uint32_t* d_counter = nullptr;   // number of tiles the first fast pass deferred (non-ASCII), reset per call
-   uint8_t* d_ws = nullptr;     // symbol-id workspace of the UTF-8 second pass
-   size_t ws_bytes = 0;
    int last_path = 0;
 };
 
@@ -524,16 +509,18 @@ static int hip_fail(hipError_t e) {
 
 template <int CH, bool FIXUP>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
-                              int32_t* to, uint32_t* n_deferred, hipStream_t st) {
+                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
    if (blocks > cap) blocks = cap;
-   const size_t lds = (size_t)4 * 64 * CH * 16;
+   // second pass: the BMP class map rides behind the tiles when it fits
+   const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const size_t lds = (size_t)4 * 64 * CH * 16 + map_lds;
    if (from && to)
-      hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred);
+      hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
    else
-      hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred);
+      hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
    return hipGetLastError();
 }
 
@@ -547,6 +534,7 @@ static bool fast_applies(const FxpHeader& h, const uint8_t* d_rows, int64_t row_
 template <bool FIXUP>
 static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                   uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st) {
+   const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
                  make_uint2(0, 0)};
    {
@@ -556,14 +544,14 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.H = make_uint2((uint32_t)hb, (uint32_t)(hb >> 32));
    }
    switch (row_len >> 4) {
-      case 1: return launch_fast<1, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      case 2: return launch_fast<2, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      case 3: return launch_fast<3, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      case 4: return launch_fast<4, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      case 6: return launch_fast<6, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      case 8: return launch_fast<8, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      case 12: return launch_fast<12, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
-      default: return launch_fast<16, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, st);
+      case 1: return launch_fast<1, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 2: return launch_fast<2, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 3: return launch_fast<3, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 4: return launch_fast<4, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 6: return launch_fast<6, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 8: return launch_fast<8, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 12: return launch_fast<12, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      default: return launch_fast<16, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
    }
 }
 
@@ -629,7 +617,6 @@ int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64
 void fxamd_program_free(fxamd_program* p) {
    if (!p) return;
    if (p->d_blob) (void)hipFree(p->d_blob);
-   if (p->d_ws) (void)hipFree(p->d_ws);
    if (p->d_counter) (void)hipFree(p->d_counter);
    delete p;
 }
@@ -688,22 +675,6 @@ int fxamd_program_upload(fxamd_program* p) {
    return FXAMD_OK;
 }
 
-int fxamd_program_reserve(fxamd_program* p, int64_t n, int64_t row_len) {
-   if (!p || n < 0 || row_len < 0) return FXAMD_E_ARG;
-   if (p->prog.status != 0 || !(p->prog.hdr().flags & FXP_F_FAST_UTF8)) return FXAMD_OK;   // no workspace needed
-   const size_t need = (size_t)n * (size_t)row_len;
-   std::lock_guard<std::mutex> g(p->mu);
-   if (need <= p->ws_bytes) return FXAMD_OK;
-   if (p->d_ws) {
-      (void)hipFree(p->d_ws);
-      p->d_ws = nullptr;
-      p->ws_bytes = 0;
-   }
-   FX_HIP(hipMalloc((void**)&p->d_ws, need));
-   p->ws_bytes = need;
-   return FXAMD_OK;
-}
-
 int fxamd_last_path(const fxamd_program* p) { return p ? p->last_path : FXAMD_E_ARG; }
 
 int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
@@ -740,24 +711,11 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
    const bool fast = fast_applies(h, d_rows, row_len);
    if (fast) {
-      if (h.flags & FXP_F_FAST_UTF8) {
-         // workspace for the symbol-id image of deferred (non-ASCII) tiles; reserve it up front to keep this call allocation-free
-         rc = fxamd_program_reserve(p, n, row_len);
-         if (rc != FXAMD_OK) return rc;
-      }
       FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
       FX_HIP(launch_fast_any<false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
       if (h.flags & FXP_F_FAST_UTF8) {
-         // tiles holding bytes >= 0x80 were deferred: decode them to symbol ids (fx_translate), then scan only those tiles
-         const int64_t n_tiles = (n + 63) >> 6;
-         int64_t tb = n_tiles;   // 4 work items (tile quarters) per tile, 4 waves per block
-         if (tb > 256 * 8) tb = 256 * 8;
-         const uint32_t tl_bytes = (1024u + h.n_pages * 64u) * 2u;
-         const uint32_t tl = tl_bytes <= 48u * 1024u ? 1u : 0u;
-         hipLaunchKernelGGL(fx_translate, dim3((unsigned)tb), dim3(256), tl ? tl_bytes : 0, st, d_rows, n, (int32_t)(row_len >> 4), p->d_blob,
-                            d_flags, p->d_ws, tl, p->d_counter);
-         FX_HIP(hipGetLastError());
-         FX_HIP(launch_fast_any<true>(h, p->d_blob, p->d_ws, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
+         // tiles holding bytes >= 0x80 were deferred: the second pass decodes UTF-8 in LDS and scans only those tiles
+         FX_HIP(launch_fast_any<true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
          p->last_path = 1;
          return FXAMD_OK;
       }

@@ -208,49 +208,81 @@ struct ClassTables {   // plain pointers only
 struct Cell16 {
    uint32_t x, y, z, w;
 };
+// byte k of the 8-byte pair {hi,lo} shifted right by n bytes (n = 1..3): v_alignbyte_b32 on the device
+FX_HD uint32_t fx_alignbyte(uint32_t hi, uint32_t lo, uint32_t n) {
+#if defined(__HIPCC__)
+   return __builtin_amdgcn_alignbyte(hi, lo, n);
+#else
+   return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (8 * n));
+#endif
+}
+
+// SWAR formulation: the byte-type predicates (continuation, 2/3/4-byte lead) are computed for whole dwords as masks with
+// bit 7 of each byte set; "valid lead", "covered continuation" follow from byte-shifted ANDs across the 24-byte window.
+// Only the class of valid lead bytes needs per-position work (code point assembly + two table reads).
 FX_HD Cell16 translate_cell16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5, const ClassTables& pv,
                               uint32_t sym_ffff) {
    const uint32_t w[6] = {w0, w1, w2, w3, w4, w5};
    if (((w[1] | w[2] | w[3] | w[4]) & 0x80808080u) == 0) return Cell16{w[1], w[2], w[3], w[4]};
-   // phase 1: per position, everything except the class of a valid multi-byte character
-   uint32_t sym[16], code[16];
+   const uint32_t M = 0x80808080u;
+   uint32_t C[6], L2[6], L3[6], L4[6];
+#pragma unroll
+   for (int d = 0; d < 6; ++d) {
+      const uint32_t x = w[d], s1 = x << 1, s2 = x << 2, s3 = x << 3, s4 = x << 4;
+      C[d] = x & ~s1 & M;
+      L2[d] = x & s1 & ~s2 & M;
+      L3[d] = x & s1 & s2 & ~s3 & M;
+      L4[d] = x & s1 & s2 & s3 & ~s4 & M;
+   }
+   // V*[d]: a structurally valid 2/3/4-byte character starts at this byte (d = 0..4; the window's last dword only feeds C)
+   uint32_t V2[5], V3[5], V4[5];
+#pragma unroll
+   for (int d = 0; d < 5; ++d) {
+      const uint32_t c1 = fx_alignbyte(C[d + 1], C[d], 1), c2 = fx_alignbyte(C[d + 1], C[d], 2), c3 = fx_alignbyte(C[d + 1], C[d], 3);
+      V2[d] = L2[d] & c1;
+      V3[d] = L3[d] & c1 & c2;
+      V4[d] = L4[d] & c1 & c2 & c3;
+   }
+   uint32_t out[4];
+   const uint32_t ffff_rep = sym_ffff * 0x01010101u;
+#pragma unroll
+   for (int d = 1; d < 5; ++d) {
+      const uint32_t valid = V2[d] | V3[d] | V4[d];
+      const uint32_t va1 = V2[d - 1] | V3[d - 1] | V4[d - 1];
+      const uint32_t v34p = V3[d - 1] | V4[d - 1], v34 = V3[d] | V4[d];
+      // covered continuation byte: a valid lead 1 byte before, a valid 3/4-byte lead 2 before, or a valid 4-byte lead 3 before
+      const uint32_t cov = fx_alignbyte(valid, va1, 3) | fx_alignbyte(v34, v34p, 2) | fx_alignbyte(V4[d], V4[d - 1], 1);
+      const uint32_t hi = w[d] & M;
+      const uint32_t inval = hi & ~cov & ~valid;
+      const uint32_t ff_hi = (hi >> 7) * 0xFFu, ff_cov = (cov >> 7) * 0xFFu, ff_inv = (inval >> 7) * 0xFFu;
+      out[d - 1] = (w[d] & ~ff_hi) | ff_cov | (ff_inv & ffff_rep);   // valid lead bytes are patched below
+   }
+   // classes of the valid lead bytes: code point assembly + BMP page lookup, all 16 positions independent
+   uint32_t code[16];
 #pragma unroll
    for (int q = 0; q < 16; ++q) {
-      auto B = [&](int i) -> uint32_t {   // byte at cell offset i, -4 <= i < 20
+      auto B = [&](int i) -> uint32_t {   // byte at cell offset i, 0 <= i < 20
          const int j = i + 4;
          return (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
       };
-      const uint32_t b0 = B(q);
-      const uint32_t bm1 = B(q - 1), bm2 = B(q - 2), bm3 = B(q - 3), bp1 = B(q + 1), bp2 = B(q + 2), bp3 = B(q + 3);
-      const bool cp1 = u8_is_cont(bp1), cp2 = u8_is_cont(bp2), cp3 = u8_is_cont(bp3);
-      const bool cm1 = u8_is_cont(bm1), cm2 = u8_is_cont(bm2);
-      const uint32_t l1 = u8_lead_len(bm1), l2 = u8_lead_len(bm2), l3 = u8_lead_len(bm3);
-      const bool covered = (l1 >= 2 && (l1 < 3 || cp1) && (l1 < 4 || cp2)) || (cm1 && l2 >= 3 && (l2 < 4 || cp1)) || (cm1 && cm2 && l3 == 4);
-      const uint32_t n0 = u8_lead_len(b0);
-      const bool valid = n0 >= 2 && cp1 && (n0 < 3 || cp2) && (n0 < 4 || cp3);
-      uint32_t cd = n0 == 2 ? (b0 & 0x1Fu) : (n0 == 3 ? (b0 & 0x0Fu) : (b0 & 0x07u));
-      cd = (cd << 6) | (bp1 & 0x3Fu);
-      cd = n0 >= 3 ? (cd << 6) | (bp2 & 0x3Fu) : cd;
-      cd = n0 >= 4 ? (cd << 6) | (bp3 & 0x3Fu) : cd;
-      code[q] = valid ? cd : 0xFFFFFFFFu;   // 0xFFFFFFFF: no class lookup wanted
-      sym[q] = b0 < 0x80u ? b0 : ((u8_is_cont(b0) && covered) ? 255u : sym_ffff);
+      const int d = 1 + (q >> 2), sh = (q & 3) * 8 + 7;
+      const uint32_t is2 = (V2[d] >> sh) & 1u, is3 = (V3[d] >> sh) & 1u, is4 = (V4[d] >> sh) & 1u;
+      const uint32_t b0 = B(q), b1 = B(q + 1) & 0x3Fu, b2 = B(q + 2) & 0x3Fu, b3 = B(q + 3) & 0x3Fu;
+      const uint32_t c2 = ((b0 & 0x1Fu) << 6) | b1;
+      const uint32_t c3 = ((((b0 & 0x0Fu) << 6) | b1) << 6) | b2;
+      const uint32_t c4 = ((((((b0 & 0x07u) << 6) | b1) << 6) | b2) << 6) | b3;
+      code[q] = is2 ? c2 : (is3 ? c3 : (is4 ? c4 : 0xFFFFFFFFu));   // 0xFFFFFFFF: not a valid lead, no lookup wanted
    }
-   // phase 2: class lookups, all independent (two table reads each; BMP only here)
    uint32_t pg[16];
 #pragma unroll
    for (int q = 0; q < 16; ++q) pg[q] = pv.page_p[code[q] < 0x10000u ? (code[q] >> 6) : 0u];
 #pragma unroll
    for (int q = 0; q < 16; ++q) {
-      const uint32_t c = pv.pages_p[pg[q] * 64u + (code[q] & 63u)];
-      sym[q] = code[q] < 0x10000u ? 128u + c : sym[q];
+      uint32_t c = pv.pages_p[pg[q] * 64u + (code[q] & 63u)];
+      if (code[q] != 0xFFFFFFFFu && code[q] >= 0x10000u) c = pv.class_of_code((int32_t)code[q]);   // beyond the BMP (rare)
+      const uint32_t patch = code[q] != 0xFFFFFFFFu ? (128u + c) : 0u;
+      out[q >> 2] |= patch << ((q & 3) * 8);
    }
-   // phase 3 (rare): characters beyond the BMP -> binary search over the interval starts
-#pragma unroll
-   for (int q = 0; q < 16; ++q)
-      if (code[q] != 0xFFFFFFFFu && code[q] >= 0x10000u) sym[q] = 128u + pv.class_of_code((int32_t)code[q]);
-   uint32_t out[4] = {0, 0, 0, 0};
-#pragma unroll
-   for (int q = 0; q < 16; ++q) out[q >> 2] |= sym[q] << ((q & 3) * 8);
    return Cell16{out[0], out[1], out[2], out[3]};
 }
 

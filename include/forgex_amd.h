@@ -70,11 +70,6 @@ const char* fxamd_strerror(int32_t status);
 /* Upload the tables to the current HIP device (idempotent; done lazily by the match calls otherwise). */
 int fxamd_program_upload(fxamd_program* p);
 
-/* Reserve the device workspace a later fxamd_match_batch_device(p, ., n, row_len, ...) may need (programs that decode
- * UTF-8 in a second pass keep a symbol-id image of the non-ASCII tiles: up to n*row_len bytes).  Optional: the match call
- * reserves on demand, but only a call that finds enough workspace reserved is allocation-free (graph capturable). */
-int fxamd_program_reserve(fxamd_program* p, int64_t n, int64_t row_len);
-
 /* Device-resident batch: d_rows, d_flags (n bytes: 0/1), d_from, d_to (n int32 each, may both be NULL) are
  * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
  * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
@@ -91,8 +86,8 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
 int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                            int32_t* d_from, int32_t* d_to, void* hip_stream);
 
-/* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ on-device UTF-8
- * translate + second fast pass over non-ASCII tiles), 2 = general kernel, 3 = fast kernel + general fix-up of non-ASCII rows. */
+/* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ second fast pass with
+ * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up of non-ASCII rows. */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);
