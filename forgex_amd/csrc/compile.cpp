@@ -116,7 +116,7 @@ struct Blob {
       while (b.size() % 16) b.push_back(0);
       uint32_t off = static_cast<uint32_t>(b.size());
       const uint8_t* q = static_cast<const uint8_t*>(p);
-      b.insert(b.end(), q, q + n);
+      if (n) b.insert(b.end(), q, q + n);
       if (n == 0) b.push_back(0);
       return off;
    }
@@ -161,6 +161,136 @@ bool border_free(const std::string& p) {
    for (size_t k = 1; k < p.size(); ++k)
       if (p.compare(0, k, p, p.size() - k, k) == 0) return false;
    return true;
+}
+
+// interval starts, class of each interval, ASCII class table and the two-level BMP page map
+void emit_class_map(Blob& bl, FxpHeader& h, const std::vector<int32_t>& bounds, int nI, const std::vector<int>& cls_of) {
+   auto interval_of = [&](int32_t code) {
+      return static_cast<int>(std::upper_bound(bounds.begin(), bounds.end(), code) - bounds.begin()) - 1;
+   };
+   h.n_bounds = static_cast<uint32_t>(nI);
+   std::vector<int32_t> b32(bounds.begin(), bounds.begin() + nI);
+   h.off_bounds = bl.put(b32.data(), b32.size() * 4);
+   std::vector<uint16_t> bc(static_cast<size_t>(nI));
+   for (int k = 0; k < nI; ++k) bc[static_cast<size_t>(k)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(k)]);
+   h.off_bound_cls = bl.put(bc.data(), bc.size() * 2);
+   std::vector<uint16_t> ac(128);
+   for (int c = 0; c < 128; ++c) ac[static_cast<size_t>(c)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(interval_of(c))]);
+   h.off_ascii_cls = bl.put(ac.data(), ac.size() * 2);
+   h.cls_nul = static_cast<uint32_t>(cls_of[static_cast<size_t>(interval_of(0))]);
+   h.cls_ffff = static_cast<uint32_t>(cls_of[static_cast<size_t>(interval_of(65535))]);
+   // two-level class map of the BMP: the on-device decoder classifies a 2-/3-byte character with two table reads
+   // instead of a binary search over the interval starts
+   std::vector<uint16_t> page_of(1024);
+   std::vector<uint16_t> pages;
+   std::map<std::vector<uint16_t>, uint16_t> seen;
+   for (int pg = 0; pg < 1024; ++pg) {
+      std::vector<uint16_t> v(64);
+      int iv = interval_of(pg * 64);
+      for (int k = 0; k < 64; ++k) {
+         int32_t code = pg * 64 + k;
+         while (iv + 1 < nI && bounds[static_cast<size_t>(iv) + 1] <= code) ++iv;
+         v[static_cast<size_t>(k)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(iv)]);
+      }
+      auto it = seen.find(v);
+      if (it == seen.end()) {
+         it = seen.emplace(v, static_cast<uint16_t>(seen.size())).first;
+         pages.insert(pages.end(), v.begin(), v.end());
+      }
+      page_of[static_cast<size_t>(pg)] = it->second;
+   }
+   h.n_pages = static_cast<uint32_t>(seen.size());
+   h.off_cls_page = bl.put(page_of.data(), page_of.size() * 2);
+   h.off_cls_pages = bl.put(pages.data(), pages.size() * 2);
+}
+
+std::vector<uint32_t> to_words(const Bits& b, uint32_t words) {
+   std::vector<uint32_t> w(words, 0);
+   for (uint32_t i = 0; i < words; ++i) {
+      const uint64_t q = (i >> 1) < b.size() ? b[i >> 1] : 0;
+      w[i] = static_cast<uint32_t>(q >> ((i & 1) * 32));
+   }
+   return w;
+}
+
+// The DFA does not fit: emit the NFA itself for on-device simulation of state SETS (same algorithm as the DFA path --
+// reverse unanchored pass for the leftmost start, forward anchored pass for the longest end -- with bitsets as states).
+Program compile_nfa_sim(const Nfa& nfa, const Literals& lit, int op, const std::vector<int32_t>& bounds, int nI,
+                        const std::vector<FlatTra>& tras, const std::vector<Bits>& clos, const std::vector<Bits>& rclos) {
+   const int N = nfa.nfa_top;
+   const uint32_t words = static_cast<uint32_t>(N + 32) / 32;
+   // classes: intervals consumed by exactly the same transitions
+   std::vector<std::vector<int>> sig(static_cast<size_t>(nI));
+   for (size_t t = 0; t < tras.size(); ++t)
+      for (int k : tras[t].acc) sig[static_cast<size_t>(k)].push_back(static_cast<int>(t));
+   std::vector<int> cls_of(static_cast<size_t>(nI));
+   std::map<std::vector<int>, int> m;
+   for (int k = 0; k < nI; ++k) {
+      auto it = m.find(sig[static_cast<size_t>(k)]);
+      if (it == m.end()) it = m.emplace(sig[static_cast<size_t>(k)], static_cast<int>(m.size())).first;
+      cls_of[static_cast<size_t>(k)] = it->second;
+   }
+   const int ncls = static_cast<int>(m.size());
+   const size_t table_words = static_cast<size_t>(ncls) * (N + 1) * words;
+   if (table_words * 8 > (size_t(1) << 30)) return invalid_program(FX_ERR_NFA_LIMIT);   // 2 tables x 4 bytes per word: keep under 1 GiB
+
+   Blob bl;
+   bl.b.assign(sizeof(FxpHeader), 0);
+   FxpHeader h;
+   std::memset(&h, 0, sizeof(h));
+   h.mode = op == OP_SEARCH ? FXP_MODE_SEARCH_ENGINE : FXP_MODE_MATCH_ENGINE;
+   h.flags = FXP_F_NFA_SIM | FXP_F_HAS_R;
+   h.n_classes = static_cast<uint32_t>(ncls);
+   h.len_prefix = static_cast<uint32_t>(lit.prefix.size());
+   h.len_suffix = static_cast<uint32_t>(lit.suffix.size());
+   h.len_all = static_cast<uint32_t>(lit.all.size());
+   if (bt(clos[static_cast<size_t>(nfa.entry)], nfa.exit)) h.flags |= FXP_F_INIT_ACCEPTING;
+   if (!f_eq(lit.prefix, "")) h.flags |= FXP_F_PREFILTER;
+   if (!f_eq(lit.suffix, "")) h.flags |= FXP_F_HAS_SUFFIX;
+   if (op == OP_MATCH && !f_eq(lit.all, "")) h.flags |= FXP_F_MATCH_LITERAL;
+   emit_class_map(bl, h, bounds, nI, cls_of);
+   h.off_prefix = bl.put(lit.prefix.data(), lit.prefix.size());
+   h.off_suffix = bl.put(lit.suffix.data(), lit.suffix.size());
+   h.off_all = bl.put(lit.all.data(), lit.all.size());
+   h.nfa_N = static_cast<uint32_t>(N);
+   h.nfa_words = words;
+   h.nfa_entry = static_cast<uint32_t>(nfa.entry);
+   h.nfa_exit = static_cast<uint32_t>(nfa.exit);
+   // per-class transition bitsets
+   std::vector<uint32_t> fwdT(table_words, 0), revT(table_words, 0);
+   std::vector<std::vector<uint8_t>> acc_cls(tras.size(), std::vector<uint8_t>(static_cast<size_t>(ncls), 0));
+   for (size_t t = 0; t < tras.size(); ++t)
+      for (int k : tras[t].acc) acc_cls[t][static_cast<size_t>(cls_of[static_cast<size_t>(k)])] = 1;
+   for (size_t t = 0; t < tras.size(); ++t) {
+      const std::vector<uint32_t> cw = to_words(clos[static_cast<size_t>(tras[t].dst)], words);
+      const std::vector<uint32_t> rw = to_words(rclos[static_cast<size_t>(tras[t].src)], words);
+      for (int c = 0; c < ncls; ++c) {
+         if (!acc_cls[t][static_cast<size_t>(c)]) continue;
+         uint32_t* f = &fwdT[(static_cast<size_t>(c) * (N + 1) + tras[t].src) * words];
+         uint32_t* r = &revT[(static_cast<size_t>(c) * (N + 1) + tras[t].dst) * words];
+         for (uint32_t i = 0; i < words; ++i) {
+            f[i] |= cw[i];
+            r[i] |= rw[i];
+         }
+      }
+   }
+   const std::vector<uint32_t> init = to_words(clos[static_cast<size_t>(nfa.entry)], words);
+   const std::vector<uint32_t> f0 = to_words(rclos[static_cast<size_t>(nfa.exit)], words);
+   std::vector<uint32_t> rstart = f0;   // F0 + pre(NUL, F0), hit cleared: the trailing NUL is never a start
+   for (int z = 1; z <= N; ++z)
+      if ((f0[static_cast<size_t>(z) >> 5] >> (z & 31)) & 1u) {
+         const uint32_t* r = &revT[(static_cast<size_t>(h.cls_nul) * (N + 1) + z) * words];
+         for (uint32_t i = 0; i < words; ++i) rstart[i] |= r[i];
+      }
+   h.off_nfa_init = bl.put(init.data(), init.size() * 4);
+   h.off_nfa_f0 = bl.put(f0.data(), f0.size() * 4);
+   h.off_nfa_rstart = bl.put(rstart.data(), rstart.size() * 4);
+   h.off_nfa_fwd = bl.put(fwdT.data(), fwdT.size() * 4);
+   h.off_nfa_rev = bl.put(revT.data(), revT.size() * 4);
+   // empty placeholders so that every offset stays inside the blob
+   const uint32_t none = bl.put(nullptr, 0);
+   h.off_TA = h.off_TR = h.off_accA = h.off_hitR = h.off_finalM = h.off_fastA = h.off_fastR = none;
+   return finish(h, bl);
 }
 
 }   // namespace
@@ -248,7 +378,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
          for (int k = 0; k < nI; ++k) {
             auto it = ids.find(next[static_cast<size_t>(k)]);
             if (it == ids.end()) {
-               if (static_cast<int>(sets.size()) >= lim.max_dfa_states) return invalid_program(FX_ERR_DFA_LIMIT);
+               if (static_cast<int>(sets.size()) >= lim.max_dfa_states) return compile_nfa_sim(nfa, lit, op, bounds, nI, tras, clos, rclos);
                it = ids.emplace(next[static_cast<size_t>(k)], static_cast<int>(sets.size())).first;
                sets.push_back(next[static_cast<size_t>(k)]);
             }
@@ -419,14 +549,9 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    if (R.ok) h.flags |= FXP_F_HAS_R;
    if (op == OP_MATCH && !f_eq(lit.all, "")) h.flags |= FXP_F_MATCH_LITERAL;
 
-   std::vector<int32_t> b32(bounds.begin(), bounds.begin() + nI);
-   h.off_bounds = bl.put(b32.data(), b32.size() * 4);
-   std::vector<uint16_t> bc(static_cast<size_t>(nI));
-   for (int k = 0; k < nI; ++k) bc[static_cast<size_t>(k)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(k)]);
-   h.off_bound_cls = bl.put(bc.data(), bc.size() * 2);
+   emit_class_map(bl, h, bounds, nI, cls_of);
    std::vector<uint16_t> ac(128);
    for (int c = 0; c < 128; ++c) ac[static_cast<size_t>(c)] = static_cast<uint16_t>(class_of_code(c));
-   h.off_ascii_cls = bl.put(ac.data(), ac.size() * 2);
    std::vector<uint16_t> ta(static_cast<size_t>(A.n) * ncls);
    for (int s = 0; s < A.n; ++s)
       for (int c = 0; c < ncls; ++c) {
@@ -434,31 +559,6 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
          ta[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(t | (A.out[static_cast<size_t>(t)] ? FXP_FLAG_BIT : 0));
       }
    h.off_TA = bl.put(ta.data(), ta.size() * 2);
-   {
-      // two-level class map of the BMP: the on-device decoder classifies a 2-/3-byte character with two table reads
-      // instead of a binary search over the interval starts
-      std::vector<uint16_t> page_of(1024);
-      std::vector<uint16_t> pages;
-      std::map<std::vector<uint16_t>, uint16_t> seen;
-      for (int pg = 0; pg < 1024; ++pg) {
-         std::vector<uint16_t> v(64);
-         int iv = interval_of(pg * 64);
-         for (int k = 0; k < 64; ++k) {
-            int32_t code = pg * 64 + k;
-            while (iv + 1 < nI && bounds[static_cast<size_t>(iv) + 1] <= code) ++iv;
-            v[static_cast<size_t>(k)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(iv)]);
-         }
-         auto it = seen.find(v);
-         if (it == seen.end()) {
-            it = seen.emplace(v, static_cast<uint16_t>(seen.size())).first;
-            pages.insert(pages.end(), v.begin(), v.end());
-         }
-         page_of[static_cast<size_t>(pg)] = it->second;
-      }
-      h.n_pages = static_cast<uint32_t>(seen.size());
-      h.off_cls_page = bl.put(page_of.data(), page_of.size() * 2);
-      h.off_cls_pages = bl.put(pages.data(), pages.size() * 2);
-   }
    std::vector<uint16_t> tr;
    if (R.ok) {
       tr.resize(static_cast<size_t>(R.n) * ncls);

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ ro
    fxrow::ProgView pv(pbase);
    GlobalRow r{rows + row * (int64_t)L};
    fxrow::Result res;
-   fxrow::run_row(pv, r, L, res);
+   fxrow::DfaSim sim(pv);
+   fxrow::run_row(pv, sim, r, L, res);
    flags[row] = (uint8_t)res.flag;
    if (from) from[row] = res.from;
    if (to) to[row] = res.to;
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(256) void fx_fixup(const uint8_t* __restrict__ rows
       const int64_t row = base + k;
       GlobalRow r{rows + row * (int64_t)L};
       fxrow::Result res;
-      fxrow::run_row(pv, r, L, res);
+      fxrow::DfaSim sim(pv);
+      fxrow::run_row(pv, sim, r, L, res);
       flags[row] = (uint8_t)res.flag;
       if (from) from[row] = res.from;
       if (to) to[row] = res.to;
@@ -470,7 +472,26 @@ __global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict
    fxrow::ProgView pv(pbase);
    TileRow r{reinterpret_cast<const uint8_t*>(tiles), lane};
    fxrow::Result res;
-   fxrow::run_row(pv, r, L, res);
+   fxrow::DfaSim sim(pv);
+   fxrow::run_row(pv, sim, r, L, res);
+   flags[row] = (uint8_t)res.flag;
+   if (from) from[row] = res.from;
+   if (to) to[row] = res.to;
+}
+
+// FXP_F_NFA_SIM programs (DFA too large to build): one lane = one row, NFA state sets as bitsets in `scratch`
+// (2 * nfa_words words per row of this launch).  Slow by construction; exists so that every valid pattern runs.
+__global__ __launch_bounds__(64) void fx_nfa(const uint8_t* __restrict__ rows, int64_t row_begin, int64_t n, int32_t L,
+                                              const uint8_t* __restrict__ prog, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
+                                              int32_t* __restrict__ to, uint32_t* __restrict__ scratch) {
+   const int64_t local = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   const int64_t row = row_begin + local;
+   if (row >= n) return;
+   fxrow::ProgView pv(prog);
+   GlobalRow r{rows + row * (int64_t)L};
+   fxrow::NfaSim sim(pv, scratch + local * 2 * (int64_t)pv.h().nfa_words);
+   fxrow::Result res;
+   fxrow::run_row(pv, sim, r, L, res);
    flags[row] = (uint8_t)res.flag;
    if (from) from[row] = res.from;
    if (to) to[row] = res.to;
@@ -492,7 +513,9 @@ struct fxamd_program {
    std::mutex mu;
    int device = -1;
    uint8_t* d_blob = nullptr;
-   uint32_t* d_counter = nullptr;   // number of tiles the first fast pass deferred (non-ASCII), reset per call
+   uint32_t* d_counter = nullptr;   // set by the first fast pass when it deferred a (non-ASCII) tile, reset per call
+   uint32_t* d_nfa_scratch = nullptr;   // bitset scratch of the NFA-simulation kernel (FXP_F_NFA_SIM programs)
+   size_t nfa_scratch_rows = 0;
    int last_path = 0;
 };
 
@@ -618,6 +641,7 @@ void fxamd_program_free(fxamd_program* p) {
    if (!p) return;
    if (p->d_blob) (void)hipFree(p->d_blob);
    if (p->d_counter) (void)hipFree(p->d_counter);
+   if (p->d_nfa_scratch) (void)hipFree(p->d_nfa_scratch);
    delete p;
 }
 int32_t fxamd_program_status(const fxamd_program* p) { return p ? p->prog.status : FXAMD_E_ARG; }
@@ -708,6 +732,32 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
+   if (h.flags & FXP_F_NFA_SIM) {
+      // bounded scratch: rows are processed in chunks that share one scratch area (allocated on first use)
+      const size_t per_row = (size_t)2 * h.nfa_words * 4;
+      size_t chunk = (size_t(256) << 20) / per_row;
+      if (chunk > 65536) chunk = 65536;
+      if (chunk < 64) chunk = 64;
+      chunk &= ~size_t(63);
+      {
+         std::lock_guard<std::mutex> g(p->mu);
+         if (p->nfa_scratch_rows < chunk) {
+            if (p->d_nfa_scratch) (void)hipFree(p->d_nfa_scratch);
+            p->d_nfa_scratch = nullptr;
+            p->nfa_scratch_rows = 0;
+            FX_HIP(hipMalloc((void**)&p->d_nfa_scratch, chunk * per_row));
+            p->nfa_scratch_rows = chunk;
+         }
+      }
+      for (int64_t b0 = 0; b0 < n; b0 += (int64_t)chunk) {
+         const int64_t cnt = n - b0 < (int64_t)chunk ? n - b0 : (int64_t)chunk;
+         hipLaunchKernelGGL(fx_nfa, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, d_rows, b0, b0 + cnt, (int32_t)row_len, p->d_blob, d_flags,
+                            d_from, d_to, p->d_nfa_scratch);
+         FX_HIP(hipGetLastError());
+      }
+      p->last_path = 4;
+      return FXAMD_OK;
+   }
    const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
    const bool fast = fast_applies(h, d_rows, row_len);
    if (fast) {

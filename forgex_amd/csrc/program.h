@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 5u
+#define FXP_VERSION 6u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -30,7 +30,8 @@ enum FxpFlags {
    FXP_F_FAST_OK = 1u << 3,         // <=8-state byte tables present and brute-force semantics proven equivalent
    FXP_F_HAS_R = 1u << 4,           // reverse DFA present (else: bounded restart loop)
    FXP_F_MATCH_LITERAL = 1u << 5,
-   FXP_F_FAST_UTF8 = 1u << 6,       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
+   FXP_F_FAST_UTF8 = 1u << 6,
+   FXP_F_NFA_SIM = 1u << 7,         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
 };
 
 struct FxpHeader {
@@ -55,7 +56,14 @@ struct FxpHeader {
    uint32_t n_pages;         // distinct 64-code-point pages of the BMP class map
    uint32_t off_cls_page;    // uint16 [1024]          page id of code points [64p, 64p+63], p = cp >> 6 (cp < 0x10000)
    uint32_t off_cls_pages;   // uint16 [n_pages][64]   class of each code point of a page
-   uint32_t reserved[1];
+   // ---- NFA simulation (FXP_F_NFA_SIM): states 1..nfa_N are bit positions; sets are nfa_words 32-bit words ----
+   uint32_t nfa_N, nfa_words, nfa_entry, nfa_exit;
+   uint32_t off_nfa_init;     // uint32 [words]   epsilon closure of the entry state
+   uint32_t off_nfa_f0;       // uint32 [words]   states whose closure holds the exit state
+   uint32_t off_nfa_rstart;   // uint32 [words]   reverse scan start set (after the trailing NUL)
+   uint32_t off_nfa_fwd;      // uint32 [n_classes][N+1][words]   closed successors of a state on a class
+   uint32_t off_nfa_rev;      // uint32 [n_classes][N+1][words]   states that reach z' by (closure, one symbol of the class)
+   uint32_t reserved[3];
 };
 
 #define FXP_STATE_MASK 0x7FFFu

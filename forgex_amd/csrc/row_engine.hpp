@@ -75,6 +75,98 @@ struct ProgView {
    }
 };
 
+// ---- automaton back ends: the row procedures below only see "init / step / alive" ---------------------------------------
+struct DfaSim {   // dense tables T_A / T_R (the normal case)
+   const ProgView& pv;
+   uint32_t st;
+   FX_HD explicit DfaSim(const ProgView& p) : pv(p), st(0) {}
+   FX_HD void fwd_init() { st = pv.h().A_init; }
+   FX_HD bool fwd_step(uint32_t cls) {   // returns "destination accepts"
+      const uint32_t e = pv.TA(st, cls);
+      st = e & FXP_STATE_MASK;
+      return (e & FXP_FLAG_BIT) != 0;
+   }
+   FX_HD bool alive() const { return st != 0; }
+   FX_HD void rev_init() { st = pv.h().R_start; }
+   FX_HD bool rev_step(uint32_t cls) {   // returns "a non-empty match starts at this symbol"
+      const uint32_t e = pv.TR(st, cls);
+      st = e & FXP_STATE_MASK;
+      return (e & FXP_FLAG_BIT) != 0;
+   }
+   FX_HD void match_init() { st = pv.h().M_start; }
+   FX_HD bool match_final() { return st != 0 && pv.finalM(st) != 0; }
+};
+
+struct NfaSim {   // FXP_F_NFA_SIM: state SETS as bitsets in per-row scratch memory (DFA too large to build)
+   const ProgView& pv;
+   uint32_t *a, *b;   // current / next set, nfa_words words each
+   uint32_t words, N1, entry, exit_s;
+   const uint32_t *fwd, *rev, *init, *f0, *rstart;
+   FX_HD NfaSim(const ProgView& p, uint32_t* scratch) : pv(p) {
+      const FxpHeader hh = *p.hd;
+      words = hh.nfa_words;
+      N1 = hh.nfa_N + 1;
+      entry = hh.nfa_entry;
+      exit_s = hh.nfa_exit;
+      a = scratch;
+      b = scratch + words;
+      fwd = reinterpret_cast<const uint32_t*>(p.base + hh.off_nfa_fwd);
+      rev = reinterpret_cast<const uint32_t*>(p.base + hh.off_nfa_rev);
+      init = reinterpret_cast<const uint32_t*>(p.base + hh.off_nfa_init);
+      f0 = reinterpret_cast<const uint32_t*>(p.base + hh.off_nfa_f0);
+      rstart = reinterpret_cast<const uint32_t*>(p.base + hh.off_nfa_rstart);
+   }
+   FX_HD void load(const uint32_t* src) {
+      for (uint32_t i = 0; i < words; ++i) a[i] = src[i];
+   }
+   FX_HD bool test(uint32_t s) const { return (a[s >> 5] >> (s & 31u)) & 1u; }
+   FX_HD void step(const uint32_t* table, uint32_t cls) {   // b = union over members x of a of table[cls][x]; swap
+      for (uint32_t i = 0; i < words; ++i) b[i] = 0;
+      for (uint32_t wi = 0; wi < words; ++wi) {
+         uint32_t bits = a[wi];
+         while (bits) {
+            const uint32_t low = bits & (0u - bits);
+            uint32_t k = 0;
+            for (uint32_t t = low; t > 1u; t >>= 1) ++k;
+            bits ^= low;
+            const uint32_t* row = table + (static_cast<size_t>(cls) * N1 + (wi * 32u + k)) * words;
+            for (uint32_t i = 0; i < words; ++i) b[i] |= row[i];
+         }
+      }
+      uint32_t* t = a;
+      a = b;
+      b = t;
+   }
+   FX_HD void fwd_init() { load(init); }
+   FX_HD bool fwd_step(uint32_t cls) {
+      step(fwd, cls);
+      return test(exit_s);
+   }
+   FX_HD bool alive() const {
+      uint32_t any = 0;
+      for (uint32_t i = 0; i < words; ++i) any |= a[i];
+      return any != 0;
+   }
+   FX_HD void rev_init() { load(rstart); }
+   FX_HD bool rev_step(uint32_t cls) {
+      step(rev, cls);
+      const bool hit = test(entry);
+      for (uint32_t i = 0; i < words; ++i) a[i] |= f0[i];
+      return hit;
+   }
+   FX_HD void match_init() {   // api_internal_m.F90:280-289: consume the leading NUL if the initial state can, else skip it
+      load(init);
+      step(fwd, pv.cls_nul_v);
+      if (!alive()) load(init);
+   }
+   FX_HD bool match_final() {   // accept at ci = n+2, or after the trailing NUL at n+3
+      if (!alive()) return false;
+      if (test(exit_s)) return true;
+      step(fwd, pv.cls_nul_v);
+      return test(exit_s);
+   }
+};
+
 FX_HD bool is_cont(uint32_t b) { return (b >> 6) == 2u; }
 FX_HD int lead_len(uint32_t b) {
    if ((b >> 5) == 6u) return 2;
@@ -138,31 +230,26 @@ FX_HD uint32_t wrapped(const Row& r, int L, int i) {
 
 // Longest non-empty match of the anchored automaton started at wrapped index `st` (1 <= st <= L+1).
 // Returns max_match exactly as api_internal_m.F90:119-137 computes it (0 = none).
-template <class Row>
-FX_HD int anchored_max_match(const ProgView& pv, const Row& r, int L, int st) {
-   const FxpHeader& h = pv.h();
-   uint32_t cur = h.A_init;
+template <class Row, class Sim>
+FX_HD int anchored_max_match(const ProgView& pv, Sim& sim, const Row& r, int L, int st) {
+   sim.fwd_init();
    int mm = 0;
    int j;   // 0-based text index of the next symbol
    if (st == 1) {
-      uint32_t e = pv.TA(cur, pv.cls_nul_v);
-      cur = e & FXP_STATE_MASK;
-      if (e & FXP_FLAG_BIT) mm = 2;
+      if (sim.fwd_step(pv.cls_nul_v)) mm = 2;
       j = 0;
    } else {
       j = st - 2;
    }
-   while (cur != 0 && j < L) {
+   while (sim.alive() && j < L) {
       int next;
-      uint32_t cls = fwd_symbol(pv, r, L, j, next);
-      uint32_t e = pv.TA(cur, cls);
-      cur = e & FXP_STATE_MASK;
+      const uint32_t cls = fwd_symbol(pv, r, L, j, next);
+      const bool acc = sim.fwd_step(cls);
       j = next;
-      if (e & FXP_FLAG_BIT) mm = j + 2;
+      if (acc) mm = j + 2;
    }
-   if (cur != 0) {   // trailing NUL
-      uint32_t e = pv.TA(cur, pv.cls_nul_v);
-      if (e & FXP_FLAG_BIT) mm = L + 3;
+   if (sim.alive()) {   // trailing NUL
+      if (sim.fwd_step(pv.cls_nul_v)) mm = L + 3;
    }
    return mm;
 }
@@ -291,8 +378,8 @@ struct Result {
    int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none
 };
 
-template <class Row>
-FX_HD void search_engine(const ProgView& pv, const Row& r, int L, Result& out) {
+template <class Row, class Sim>
+FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out) {
    const FxpHeader& h = pv.h();
    out.flag = 0;
    out.from = 0;
@@ -329,26 +416,23 @@ FX_HD void search_engine(const ProgView& pv, const Row& r, int L, Result& out) {
    if (brute) {
       int s = 0;
       if (h.flags & FXP_F_HAS_R) {
-         uint32_t state = h.R_start;
+         sim.rev_init();
          int j = L - 1;
          while (j >= 0) {
             int start;
-            uint32_t cls = back_symbol(pv, r, j, start);
-            uint32_t e = pv.TR(state, cls);
-            state = e & FXP_STATE_MASK;
-            if (e & FXP_FLAG_BIT) s = start + 2;
+            const uint32_t cls = back_symbol(pv, r, j, start);
+            if (sim.rev_step(cls)) s = start + 2;
             j = start - 1;
          }
-         uint32_t e = pv.TR(state, pv.cls_nul_v);
-         if (e & FXP_FLAG_BIT) s = 1;
+         if (sim.rev_step(pv.cls_nul_v)) s = 1;
          if (s == 0) return;
-         int mm = anchored_max_match(pv, r, L, s);
+         int mm = anchored_max_match(pv, sim, r, L, s);
          span_from(s, mm, L, out.from, out.to);
       } else {
          // bounded restart loop, api_internal_m.F90:108-155
          int start = 1;
          while (start < L + 2) {
-            int mm = anchored_max_match(pv, r, L, start);
+            int mm = anchored_max_match(pv, sim, r, L, start);
             if (mm > 0) {
                span_from(start, mm, L, out.from, out.to);
                s = start;
@@ -386,7 +470,7 @@ FX_HD void search_engine(const ProgView& pv, const Row& r, int L, Result& out) {
       int found = 0, mm = 0;
       while (start < L + 2) {
          if (suf2 >= 0 && suf2 < start) break;
-         mm = anchored_max_match(pv, r, L, start);
+         mm = anchored_max_match(pv, sim, r, L, start);
          if (mm > 0) {
             found = start;
             break;
@@ -434,8 +518,8 @@ FX_HD void search_literal(const ProgView& pv, const Row& r, int L, Result& out) 
    }
 }
 
-template <class Row>
-FX_HD void match_engine(const ProgView& pv, const Row& r, int L, Result& out) {   // forgex.F90:207-226 + api_internal_m.F90:171-303
+template <class Row, class Sim>
+FX_HD void match_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out) {   // forgex.F90:207-226 + api_internal_m.F90:171-303
    const FxpHeader& h = pv.h();
    out.flag = 0;
    out.from = 0;
@@ -472,23 +556,23 @@ FX_HD void match_engine(const ProgView& pv, const Row& r, int L, Result& out) { 
       out.flag = (h.flags & FXP_F_INIT_ACCEPTING) ? 1u : 0u;
       return;
    }
-   uint32_t cur = h.M_start;
+   sim.match_init();
    int j = 0;
-   while (cur != 0 && j < L) {
+   while (sim.alive() && j < L) {
       int next;
-      uint32_t cls = fwd_symbol(pv, r, L, j, next);
-      cur = pv.TA(cur, cls) & FXP_STATE_MASK;
+      const uint32_t cls = fwd_symbol(pv, r, L, j, next);
+      (void)sim.fwd_step(cls);
       j = next;
    }
-   out.flag = (cur != 0 && pv.finalM(cur)) ? 1u : 0u;
+   out.flag = sim.match_final() ? 1u : 0u;
 }
 
-template <class Row>
-FX_HD void run_row(const ProgView& pv, const Row& r, int L, Result& out) {
+template <class Row, class Sim>
+FX_HD void run_row(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out) {
    switch (pv.h().mode) {
-      case FXP_MODE_SEARCH_ENGINE: search_engine(pv, r, L, out); break;
+      case FXP_MODE_SEARCH_ENGINE: search_engine(pv, sim, r, L, out); break;
       case FXP_MODE_SEARCH_LITERAL: search_literal(pv, r, L, out); break;
-      case FXP_MODE_MATCH_ENGINE: match_engine(pv, r, L, out); break;
+      case FXP_MODE_MATCH_ENGINE: match_engine(pv, sim, r, L, out); break;
       default:
          out.flag = 0;
          out.from = 0;

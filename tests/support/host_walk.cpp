@@ -18,6 +18,16 @@ struct HostRow {
    const uint8_t* p;
    uint32_t operator[](int j) const { return p[j]; }
 };
+void run_any(const fxrow::ProgView& pv, const fxc::Program& p, const HostRow& r, int L, fxrow::Result& res) {
+   if (p.hdr().flags & FXP_F_NFA_SIM) {   // bitset simulation of NFA state sets (DFA too large)
+      std::vector<uint32_t> scratch(2 * p.hdr().nfa_words);
+      fxrow::NfaSim sim(pv, scratch.data());
+      fxrow::run_row(pv, sim, r, L, res);
+   } else {
+      fxrow::DfaSim sim(pv);
+      fxrow::run_row(pv, sim, r, L, res);
+   }
+}
 std::string unhex(const std::string& h) {
    if (h == "-") return std::string();
    std::string s;
@@ -44,7 +54,7 @@ int hw_run(const char* pat, int64_t plen, int op, const uint8_t* row, int64_t L,
    fxrow::ProgView pv(p.blob.data());
    HostRow r{row};
    fxrow::Result res;
-   fxrow::run_row(pv, r, static_cast<int>(L), res);
+   run_any(pv, p, r, static_cast<int>(L), res);
    *flag = static_cast<int32_t>(res.flag);
    *from = res.from;
    *to = res.to;
@@ -59,7 +69,7 @@ int hw_batch(const char* pat, int64_t plen, int op, const uint8_t* rows, int64_t
    for (int64_t i = 0; i < n; ++i) {
       HostRow r{rows + i * L};
       fxrow::Result res;
-      fxrow::run_row(pv, r, static_cast<int>(L), res);
+      run_any(pv, p, r, static_cast<int>(L), res);
       flags[i] = static_cast<uint8_t>(res.flag);
       if (from) from[i] = res.from;
       if (to) to[i] = res.to;
