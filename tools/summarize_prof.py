@@ -39,10 +39,11 @@ def pmc(sub):
 
 
 fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
-dom = None
+dom = None   # dominant kernel = the fx_* kernel with the largest fetched volume
+best = -1.0
 for (name, ctr), vals in fetch.items():
-    if "fx_search_fast" in name or "fx_general_tiled" in name:
-        dom = name
+    if ("fx_search_fast" in name or "fx_general" in name or "fx_nfa" in name) and sum(vals) > best:
+        dom, best = name, sum(vals)
 if dom:
     f = fetch.get((dom, "FETCH_SIZE"), [])
     w = write.get((dom, "WRITE_SIZE"), [])
