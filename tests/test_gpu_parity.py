@@ -253,3 +253,44 @@ def test_nfa_simulation_fallback_vs_oracle(fx):
     prog, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows)
     om, _, _ = oracle_lib.batch(1, pat, rows, NT)
     assert np.array_equal(fm, om) and 0 < int(om.sum()) < 600
+
+
+def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
+    """The hot kernel under random PATTERNS: every generated pattern that qualifies for the fast path is run over batches
+    of random rows at each row length the fast kernel is instantiated for (ASCII-only, and mixed with valid and broken
+    UTF-8 so that the deferred-tile pass with on-device decode runs), flags and spans vs the oracle."""
+    import random
+    import fuzz_diff
+    rng = random.Random(99)
+    nrng = np.random.default_rng(99)
+    ascii_alpha = np.frombuffer(b"abcxyz019 .-\n\tAZ_@", dtype=np.uint8)
+    pieces = [b"a", b"b", b"c", b"x", b"0", b"9", b" ", b".", "あ".encode(), "ん".encode(), "α".encode(), "ω".encode(), "é".encode(),
+              b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
+    n_fast = 0
+    tried = 0
+    while n_fast < 60 and tried < 800:
+        tried += 1
+        pat = fuzz_diff.gen_pattern(rng).encode()
+        p = fx.Program(pat, fx.OP_SEARCH)
+        if p.status != 0 or not (p.info()["flags"] & 8):
+            continue
+        n_fast += 1
+        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256])
+        n = 192
+        rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
+        mixed = []
+        for _ in range(n):
+            buf = b""
+            while len(buf) < L:
+                buf += rng.choice(pieces)
+            mixed.append(np.frombuffer(buf[:L], dtype=np.uint8))
+        rows_m = np.stack(mixed)
+        for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]])):
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            assert prog.last_path() in (1, 3), (pat, L)
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            assert np.array_equal(f, of), (pat, L)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
+            _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+            assert np.array_equal(f2, of), (pat, L, "flags-only")
+    assert n_fast >= 40
