@@ -290,6 +290,7 @@ Program compile_nfa_sim(const Nfa& nfa, const Literals& lit, int op, const std::
    // empty placeholders so that every offset stays inside the blob
    const uint32_t none = bl.put(nullptr, 0);
    h.off_TA = h.off_TR = h.off_accA = h.off_hitR = h.off_finalM = h.off_fastA = h.off_fastR = none;
+   h.off_chain_cls = h.off_chain_TR = h.off_chain_TA = none;
    return finish(h, bl);
 }
 
@@ -489,9 +490,17 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             R = Ru;
             r_has_skip = true;
          } else {
-            // too many states once SKIP must be told apart: keep the ASCII-only fast path (SKIP column inert)
-            for (int st = 0; st < R.n; ++st) R.T[static_cast<size_t>(st) * nC + nI] = st;
-            minimise(R, -1);
+            // more than 8 states once SKIP must be told apart: if the SKIP-blind automaton still fits the v_perm tables keep
+            // that ASCII-only fast path, otherwise keep SKIP (class-indexed chain tables have no 8-state limit)
+            Dfa Rn = R;
+            for (int st = 0; st < Rn.n; ++st) Rn.T[static_cast<size_t>(st) * nC + nI] = st;
+            minimise(Rn, -1);
+            if (Rn.n <= 8) {
+               R = Rn;
+            } else {
+               R = Ru;
+               r_has_skip = true;
+            }
          }
       }
    }
@@ -580,10 +589,10 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    h.off_all = bl.put(lit.all.data(), lit.all.size());
 
    // ---- 7. fast path: <= 8 states per automaton, fused ASCII byte tables -----------------------------------------
-   bool fast = op == OP_SEARCH && R.ok && A.n <= 8 && R.n <= 8 && !(prefilter && has_suffix);   // the suffix is only consulted by the candidate-list driver
-   if (fast && prefilter) {
-      // Candidate-list search == brute-force search on pure-ASCII rows iff the prefix is a NECESSARY, non-self-overlapping
-      // beginning of every non-empty match.
+   // Candidate-list search == brute-force search on pure-ASCII rows iff the prefix is a NECESSARY, non-self-overlapping
+   // beginning of every non-empty match; the suffix is only consulted by the candidate-list driver.
+   bool brute_equiv = op == OP_SEARCH && R.ok && !(prefilter && has_suffix);
+   if (brute_equiv && prefilter) {
       bool ok = border_free(lit.prefix) && lit.prefix.find('\0') == std::string::npos;
       int q = A.init;
       std::vector<int32_t> codes = decode_chars(lit.prefix);
@@ -601,8 +610,10 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             if (q == 0) ok = false;
          }
       }
-      fast = ok;
+      brute_equiv = ok;
    }
+   // ---- 7. fast path: <= 8 states per automaton, fused byte tables (one v_perm_b32 per input byte) ---------------------
+   const bool fast = brute_equiv && A.n <= 8 && R.n <= 8;
    // Symbol ids of the fast tables: 0..127 = the ASCII byte itself; 128+c = a multi-byte (or invalid) character of class c
    // (fx_translate rewrites such bytes); 254 = KILL (all-dead row, feeds the end of a row); 255 = SKIP (continuation byte
    // inside a valid character).
@@ -637,6 +648,52 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    }
    h.off_fastA = bl.put(fa.data(), fa.size());
    h.off_fastR = bl.put(fr.data(), fr.size());
+
+   // ---- 8. chain tables: any automaton whose class-indexed tables fit 16-bit row offsets (LDS chain kernel) ---------------
+   {
+      const uint32_t ncols = static_cast<uint32_t>(ncls) + 2, row_bytes = ncols * 2;
+      const uint32_t col_skip = static_cast<uint32_t>(ncls), col_kill = static_cast<uint32_t>(ncls) + 1;
+      const bool chain = brute_equiv && !fast && ncls <= 126 && static_cast<uint64_t>(A.n) * row_bytes < 65536u &&
+                         static_cast<uint64_t>(R.n) * row_bytes < 65536u;
+      std::vector<uint16_t> cm(256), ctr, cta;
+      if (chain) {
+         for (uint32_t sym = 0; sym < 256; ++sym) {
+            uint32_t col = col_kill;
+            if (sym < 128) col = ac[sym];
+            else if (sym == 255) col = col_skip;
+            else if (sym - 128 < static_cast<uint32_t>(ncls)) col = sym - 128;
+            cm[sym] = static_cast<uint16_t>(2 * col);
+         }
+         ctr.assign(static_cast<size_t>(R.n) * ncols, 0);
+         cta.assign(static_cast<size_t>(A.n) * ncols, 0);
+         for (int st = 0; st < R.n; ++st) {
+            for (int c = 0; c < ncls; ++c) ctr[static_cast<size_t>(st) * ncols + c] = static_cast<uint16_t>(TR(st, c) * row_bytes);
+            const int sk = r_has_skip ? R.T[static_cast<size_t>(st) * R.ncol + nI] : st;
+            ctr[static_cast<size_t>(st) * ncols + col_skip] = static_cast<uint16_t>(sk * row_bytes);
+            ctr[static_cast<size_t>(st) * ncols + col_kill] = static_cast<uint16_t>(st * row_bytes);
+         }
+         for (int st = 0; st < A.n; ++st) {
+            for (int c = 0; c < ncls; ++c) cta[static_cast<size_t>(st) * ncols + c] = static_cast<uint16_t>(TA(st, c) * row_bytes);
+            cta[static_cast<size_t>(st) * ncols + col_skip] = static_cast<uint16_t>(st * row_bytes);
+            cta[static_cast<size_t>(st) * ncols + col_kill] = 0;
+         }
+         int accmin = A.n, hitmin = R.n;
+         for (int st = A.n - 1; st >= 0 && A.out[static_cast<size_t>(st)]; --st) accmin = st;
+         for (int st = R.n - 1; st >= 0 && R.out[static_cast<size_t>(st)]; --st) hitmin = st;
+         h.flags |= FXP_F_CHAIN_OK;
+         if (r_has_skip && !prefilter) h.flags |= FXP_F_CHAIN_UTF8;
+         h.chain_row_bytes = row_bytes;
+         h.chain_R_start = h.R_start * row_bytes;
+         h.chain_A_init = h.A_init * row_bytes;
+         h.chain_hit_min = static_cast<uint32_t>(hitmin) * row_bytes;
+         h.chain_acc_min = static_cast<uint32_t>(accmin) * row_bytes;
+         h.chain_TR_bytes = static_cast<uint32_t>(ctr.size() * 2);
+         h.chain_TA_bytes = static_cast<uint32_t>(cta.size() * 2);
+      }
+      h.off_chain_cls = bl.put(cm.data(), cm.size() * 2);
+      h.off_chain_TR = bl.put(ctr.data(), ctr.size() * 2);
+      h.off_chain_TA = bl.put(cta.data(), cta.size() * 2);
+   }
    return finish(h, bl);
 }
 

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <new>
 #include <string>
 #include <vector>
@@ -66,19 +67,38 @@ struct FastParams {
 };
 
 // 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
-__device__ __forceinline__ void lookup8(uint2* __restrict__ f, uint32_t lo, uint32_t hi, const uint2* __restrict__ tab) {
+// Two table schemes share the kernel (template parameter CHAIN):
+//   v_perm scheme  (<= 8 states): F = uint2 = the 8 next-state bytes of the symbol; step = ONE v_perm_b32.
+//   chain scheme   (larger automata): F = 2 * column of the symbol's class (uint16 map, state-independent, pipelined the same
+//                  way); the state is the byte offset of its row in a class-indexed uint16 table held in LDS and the step is a
+//                  dependent ds_read_u16 of T[state + F] (the destination's row offset).
+template <class F, class TabT>
+__device__ __forceinline__ void lookup8(F* __restrict__ f, uint32_t lo, uint32_t hi, const TabT* __restrict__ tab) {
 #pragma unroll
    for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
 }
+__device__ __forceinline__ uint32_t fxstep(uint2 f, uint32_t st, const uint8_t*) { return __builtin_amdgcn_perm(f.y, f.x, st); }
+__device__ __forceinline__ uint32_t fxstep(uint32_t f, uint32_t st, const uint8_t* T) {
+   return *reinterpret_cast<const uint16_t*>(T + st + f);
+}
+template <bool CHAIN>
+struct FxF {
+   using type = uint2;
+};
+template <>
+struct FxF<true> {
+   using type = uint32_t;
+};
 
 // Right-to-left state chain over 8 bytes.  All four bytes of `state` carry the same state id (v_perm_b32 advances four
 // identical copies), so whole registers compare like ids and no masking is needed.  Hit states have the LARGEST ids, so
 // the group's "any hit" is max(states) >= hit_min: one v_max3_u32 per two bytes instead of a compare+select per byte.
-__device__ __forceinline__ uint32_t chain8_back(const uint2 (&f)[8], uint32_t& state) {
+template <class F>
+__device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state, const uint8_t* T) {
    uint32_t st[8];
 #pragma unroll
    for (int i = 7; i >= 0; --i) {
-      state = __builtin_amdgcn_perm(f[i].y, f[i].x, state);
+      state = fxstep(f[i], state, T);
       st[i] = state;
    }
    uint32_t m0 = max(max(st[0], st[1]), st[2]);
@@ -131,31 +151,47 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
 //                 the offending rows are marked individually for the general kernel's fix-up.
 // FIXUP = true:  second pass: only marked tiles are loaded, decoded from UTF-8 to symbol ids in LDS, then scanned.
-template <int CH, bool SPANS, bool FIXUP>
+template <int CH, bool SPANS, bool FIXUP, bool CHAIN>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds) {
    constexpr int L = 16 * CH;
    if (FIXUP && *n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
-   __shared__ uint2 tabR[256];
-   __shared__ uint2 tabA[256];
-   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells
+   using F = typename FxF<CHAIN>::type;
+   __shared__ uint2 permR[CHAIN ? 1 : 256];
+   __shared__ uint2 permA[CHAIN ? 1 : 256];
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
-   {
+   // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
+   const uint32_t chain_bytes = CHAIN ? ((512u + h->chain_TR_bytes + h->chain_TA_bytes + 15u) & ~15u) : 0u;
+   const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cmap) + 512;
+   const uint8_t* TAp = TRp + (CHAIN ? h->chain_TR_bytes : 0u);
+   if (CHAIN) {
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_chain_cls);
+      const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TR);
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TA);
+      const uint32_t nr = h->chain_TR_bytes / 2, na = h->chain_TA_bytes / 2;
+      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+   } else {
       const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
       const uint2* gA = reinterpret_cast<const uint2*>(prog + h->off_fastA);
       uint32_t t = threadIdx.x;   // 256 threads = 256 symbol ids (ids >= 128 are all-dead rows unless FXP_F_FAST_UTF8)
-      tabR[t] = gR[t];
-      tabA[t] = gA[t];
+      permR[t] = gR[t];
+      permA[t] = gA[t];
    }
    __syncthreads();
+   // symbol -> F tables of the two directions (the chain scheme shares one class map)
+   using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
+   const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permR);
+   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-   const bool utf8 = (h->flags & FXP_F_FAST_UTF8) != 0;
+   const bool utf8 = (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
    // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
    if (FIXUP && class_map_in_lds) {
-      uint16_t* l16 = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * CH) + chain_bytes);
       const uint32_t n16 = 1024u + h->n_pages * 64u;
       for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
       __syncthreads();
@@ -217,7 +253,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       uint32_t state = fp.R_start;
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
       uint32_t na = 0;
-      uint2 fa[8], fb[8];
+      F fa[8], fb[8];
       uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
       if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
       lookup8(fa, wk.z, wk.w, tabR);
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          __builtin_amdgcn_sched_barrier(0);
          {
             const uint32_t entry = state;
-            const uint32_t mx = chain8_back(fa, state);
+            const uint32_t mx = chain8_back(fa, state, TRp);
             gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
             esel = mx >= fp.hit_min ? entry : esel;
          }
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          __builtin_amdgcn_sched_barrier(0);
          {
             const uint32_t entry = state;
-            const uint32_t mx = chain8_back(fb, state);
+            const uint32_t mx = chain8_back(fb, state, TRp);
             gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
             esel = mx >= fp.hit_min ? entry : esel;
          }
@@ -252,17 +288,17 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
          const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
          const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
-         uint2 f[8];
+         F f[8];
          lookup8(f, rw.x, rw.y, tabR);
          uint32_t st = esel, loc = 8;
 #pragma unroll
          for (int i = 7; i >= 0; --i) {
-            st = __builtin_amdgcn_perm(f[i].y, f[i].x, st);
+            st = fxstep(f[i], st, TRp);
             loc = st >= fp.hit_min ? (uint32_t)i : loc;
          }
          s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
-         uint2 fz = tabR[0];   // leading NUL
-         state = __builtin_amdgcn_perm(fz.y, fz.x, state);
+         const F fz = tabR[0];   // leading NUL
+         state = fxstep(fz, state, TRp);
          s = state >= fp.hit_min ? 1u : s;
       }
       // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
@@ -281,8 +317,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       uint32_t mm = 0;                      // max_match (wrapped index of the byte after the longest match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
-         uint2 f = tabA[0];
-         cur = __builtin_amdgcn_perm(f.y, f.x, cur);
+         const F f = tabA[0];
+         cur = fxstep(f, cur, TAp);
          mm = cur >= fp.acc_min ? 2u : 0u;
       }
       if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
@@ -291,7 +327,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          // are kept and the last accepting group is re-walked for the exact byte.
          uint32_t o[8];
          fetch32(o, tb, lane, j, (uint32_t)L);
-         uint2 f[32];
+         F f[32];
 #pragma unroll
          for (int g = 0; g < 4; ++g) lookup8(&f[8 * g], o[2 * g], o[2 * g + 1], tabA);
          uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
@@ -301,7 +337,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             uint32_t st[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-               cur = __builtin_amdgcn_perm(f[8 * g + q].y, f[8 * g + q].x, cur);
+               cur = fxstep(f[8 * g + q], cur, TAp);
                st[q] = cur;
             }
             const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
@@ -312,12 +348,12 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             bhi = hit ? o[2 * g + 1] : bhi;
          }
          {
-            uint2 fr8[8];
+            F fr8[8];
             lookup8(fr8, blo, bhi, tabA);
             uint32_t st = el, loc = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-               st = __builtin_amdgcn_perm(fr8[q].y, fr8[q].x, st);
+               st = fxstep(fr8[q], st, TAp);
                loc = st >= fp.acc_min ? (uint32_t)q : loc;
             }
             mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
@@ -328,12 +364,12 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             if (cur != 0) {
                uint32_t o8[2];
                fetch8(o8, tb, lane, j, (uint32_t)L);
-               uint2 f8[8];
+               F f8[8];
                lookup8(f8, o8[0], o8[1], tabA);
                uint32_t loc = 8;
 #pragma unroll
                for (int q = 0; q < 8; ++q) {
-                  cur = __builtin_amdgcn_perm(f8[q].y, f8[q].x, cur);
+                  cur = fxstep(f8[q], cur, TAp);
                   loc = cur >= fp.acc_min ? (uint32_t)q : loc;
                }
                mm = loc != 8u ? j + loc + 3u : mm;
@@ -530,51 +566,69 @@ static int hip_fail(hipError_t e) {
       if (_e != hipSuccess) return hip_fail(_e);      \
    } while (0)
 
-template <int CH, bool FIXUP>
+template <int CH, bool FIXUP, bool CHAIN>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
-                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, hipStream_t st) {
+                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
    if (blocks > cap) blocks = cap;
    // second pass: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
-   const size_t lds = (size_t)4 * 64 * CH * 16 + map_lds;
+   const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
+   if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
+      hipError_t e;
+      if (from && to)
+         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      else
+         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_search_fast<CH, false, FIXUP, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+   }
    if (from && to)
-      hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
+      hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
    else
-      hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
+      hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
    return hipGetLastError();
 }
 
-static bool fast_applies(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+static bool row_len_ok(const uint8_t* d_rows, int64_t row_len) {
    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
-   return (h.flags & FXP_F_FAST_OK) && h.mode == FXP_MODE_SEARCH_ENGINE && aligned16 &&
-          (row_len == 16 || row_len == 32 || row_len == 48 || row_len == 64 || row_len == 96 || row_len == 128 || row_len == 192 ||
-           row_len == 256);
+   return aligned16 && (row_len == 16 || row_len == 32 || row_len == 48 || row_len == 64 || row_len == 96 || row_len == 128 ||
+                        row_len == 192 || row_len == 256);
+}
+// 0 = tile kernel not applicable, 1 = v_perm scheme, 2 = chain scheme (tables must fit the CU's LDS next to the tiles)
+static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+   if (h.mode != FXP_MODE_SEARCH_ENGINE || !row_len_ok(d_rows, row_len)) return 0;
+   if (h.flags & FXP_F_FAST_OK) return 1;
+   if (h.flags & FXP_F_CHAIN_OK) {
+      const size_t need = (size_t)4 * 64 * row_len + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
+      if (need <= 150 * 1024) return 2;
+   }
+   return 0;
 }
 
-template <bool FIXUP>
+template <bool FIXUP, bool CHAIN>
 static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                   uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st) {
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
+   const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
                  make_uint2(0, 0)};
-   {
-      uint64_t hb = 0;
-      for (uint32_t q = 0; q < 8; ++q)
-         if (q >= h.fast_hitR_min && q < h.nR) hb |= (uint64_t)0xFF << (8 * q);
-      fp.H = make_uint2((uint32_t)hb, (uint32_t)(hb >> 32));
+   if (CHAIN) {   // states are row byte offsets, compared as plain integers
+      fp.R_start = h.chain_R_start;
+      fp.A_init = h.chain_A_init;
+      fp.hit_min = h.chain_hit_min;
+      fp.acc_min = h.chain_acc_min;
    }
    switch (row_len >> 4) {
-      case 1: return launch_fast<1, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      case 2: return launch_fast<2, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      case 3: return launch_fast<3, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      case 4: return launch_fast<4, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      case 6: return launch_fast<6, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      case 8: return launch_fast<8, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      case 12: return launch_fast<12, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
-      default: return launch_fast<16, FIXUP>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, st);
+      case 1: return launch_fast<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      case 2: return launch_fast<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      case 3: return launch_fast<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      case 4: return launch_fast<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      case 6: return launch_fast<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      case 8: return launch_fast<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      case 12: return launch_fast<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+      default: return launch_fast<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
    }
 }
 
@@ -706,11 +760,13 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (!p || n <= 0 || !d_rows || !d_flags || (d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
    if (p->prog.status != 0) return FXAMD_E_ARG;
    const FxpHeader& h = p->prog.hdr();
-   if (!fast_applies(h, d_rows, row_len)) return FXAMD_E_ARG;
+   const int scheme = fast_scheme(h, d_rows, row_len);
+   if (scheme == 0) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, (hipStream_t)hip_stream));
-   FX_HIP(launch_fast_any<false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, (hipStream_t)hip_stream));
+   if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, (hipStream_t)hip_stream)));
+   else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, (hipStream_t)hip_stream)));
    return FXAMD_OK;
 }
 
@@ -759,14 +815,16 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       return FXAMD_OK;
    }
    const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
-   const bool fast = fast_applies(h, d_rows, row_len);
-   if (fast) {
+   const int scheme = fast_scheme(h, d_rows, row_len);
+   if (scheme != 0) {
       FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
-      FX_HIP(launch_fast_any<false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
-      if (h.flags & FXP_F_FAST_UTF8) {
+      if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+      else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+      if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
          // tiles holding bytes >= 0x80 were deferred: the second pass decodes UTF-8 in LDS and scans only those tiles
-         FX_HIP(launch_fast_any<true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st));
-         p->last_path = 1;
+         if (scheme == 1) FX_HIP((launch_fast_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+         else FX_HIP((launch_fast_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+         p->last_path = scheme == 1 ? 1 : 5;
          return FXAMD_OK;
       }
       // fix-up pass for rows holding bytes >= 0x80 (general kernel's decode path); a cheap read of the flags otherwise
@@ -777,7 +835,7 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
          hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
       }
       FX_HIP(hipGetLastError());
-      p->last_path = 3;
+      p->last_path = scheme == 1 ? 3 : 6;
       return FXAMD_OK;
    }
    if (aligned16 && row_len <= 1024) {

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 6u
+#define FXP_VERSION 7u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -31,7 +31,9 @@ enum FxpFlags {
    FXP_F_HAS_R = 1u << 4,           // reverse DFA present (else: bounded restart loop)
    FXP_F_MATCH_LITERAL = 1u << 5,
    FXP_F_FAST_UTF8 = 1u << 6,
-   FXP_F_NFA_SIM = 1u << 7,         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
+   FXP_F_NFA_SIM = 1u << 7,
+   FXP_F_CHAIN_OK = 1u << 8,        // class-indexed LDS chain tables present (automata too large for the v_perm tables)
+   FXP_F_CHAIN_UTF8 = 1u << 9,      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
 };
 
 struct FxpHeader {
@@ -63,7 +65,13 @@ struct FxpHeader {
    uint32_t off_nfa_rstart;   // uint32 [words]   reverse scan start set (after the trailing NUL)
    uint32_t off_nfa_fwd;      // uint32 [n_classes][N+1][words]   closed successors of a state on a class
    uint32_t off_nfa_rev;      // uint32 [n_classes][N+1][words]   states that reach z' by (closure, one symbol of the class)
-   uint32_t reserved[3];
+   // ---- LDS chain tables (FXP_F_CHAIN_OK): state = byte offset of its row; row = (n_classes + 2) uint16 entries holding
+   //      the destination row offset per column: classes 0..n_classes-1, then SKIP, then KILL ----
+   uint32_t chain_row_bytes, chain_R_start, chain_A_init, chain_hit_min, chain_acc_min, chain_TR_bytes, chain_TA_bytes;
+   uint32_t off_chain_cls;    // uint16 [256]   2 * column of each fast-path symbol id
+   uint32_t off_chain_TR;     // uint16 [nR][n_classes + 2]
+   uint32_t off_chain_TA;     // uint16 [nA][n_classes + 2]   row 0 = dead
+   uint32_t reserved[1];
 };
 
 #define FXP_STATE_MASK 0x7FFFu

@@ -88,7 +88,8 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
 
 /* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ second fast pass with
  * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up of non-ASCII rows,
- * 4 = NFA state-set simulation (DFA too large to build). */
+ * 4 = NFA state-set simulation (DFA too large to build), 5 / 6 = like 1 / 3 with the class-indexed LDS chain tables
+ * (automata with more than 8 states). */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);

@@ -268,11 +268,11 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
               b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
     n_fast = 0
     tried = 0
-    while n_fast < 60 and tried < 800:
+    while n_fast < 90 and tried < 1200:
         tried += 1
         pat = fuzz_diff.gen_pattern(rng).encode()
         p = fx.Program(pat, fx.OP_SEARCH)
-        if p.status != 0 or not (p.info()["flags"] & 8):
+        if p.status != 0 or not (p.info()["flags"] & (8 | 256)):   # v_perm tables or class-indexed chain tables
             continue
         n_fast += 1
         L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256])
@@ -287,10 +287,37 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
         rows_m = np.stack(mixed)
         for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]])):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (1, 3), (pat, L)
+            assert prog.last_path() in (1, 3, 5, 6), (pat, L)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
             _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
             assert np.array_equal(f2, of), (pat, L, "flags-only")
-    assert n_fast >= 40
+    assert n_fast >= 60
+
+
+CHAIN_PATTERNS = [rb"\d{3}-\d{4}", rb"\w+@\w+\.(com|org|net)", rb"(19|20)\d\d-(0[1-9]|1[012])-(0[1-9]|[12][0-9]|3[01])",
+                  rb"[a-z]{3,5}\d{2,4}x", rb"(ab|cd|ef|gh|ij)+k", "[ぁ-ん]{3}[ァ-ヶ]{3}[0-9]{3}".encode()]
+
+
+def test_chain_scheme_patterns_vs_oracle(fx):
+    """Automata with more than 8 states run on the same tile kernel through class-indexed LDS chain tables."""
+    nrng = np.random.default_rng(17)
+    alpha = np.frombuffer(b"abcdefghijkx0123456789-@._ comrgnt", dtype=np.uint8)
+    for pat in CHAIN_PATTERNS:
+        p = fx.Program(pat, fx.OP_SEARCH)
+        assert p.status == 0 and (p.info()["flags"] & 256), pat
+        for L in (32, 64, 128, 256):
+            rows = alpha[nrng.integers(0, len(alpha), size=(4096, L))].copy()
+            # plant some matches
+            seeds = [b"555-1234", b"bob@mail.org", b"2024-02-29", b"abcd123x", b"abcdefk", "あいうアイウ123".encode()]
+            for i in range(0, 4096, 7):
+                sd = np.frombuffer(seeds[(i // 7) % len(seeds)], dtype=np.uint8)
+                off = int(nrng.integers(0, L - len(sd)))
+                rows[i, off:off + len(sd)] = sd
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            assert prog.last_path() in (5, 6), (pat, L, prog.last_path())
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            assert np.array_equal(f, of), (pat, L)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
+            assert int(of.sum()) > 0
