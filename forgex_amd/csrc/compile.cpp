@@ -613,7 +613,10 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       brute_equiv = ok;
    }
    // ---- 7. fast path: <= 8 states per automaton, fused byte tables (one v_perm_b32 per input byte) ---------------------
-   const bool fast = brute_equiv && A.n <= 8 && R.n <= 8;
+   // `.match.` runs one forward pass of A over the whole row (api_internal_m.F90:258-302): no R, no candidate list, so the
+   // tile kernel applies whenever the tables fit; its prefix/suffix gate is evaluated on the row bytes by the kernel.
+   const bool is_match = op == OP_MATCH;
+   const bool fast = is_match ? A.n <= 8 : (brute_equiv && A.n <= 8 && R.n <= 8);
    // Symbol ids of the fast tables: 0..127 = the ASCII byte itself; 128+c = a multi-byte (or invalid) character of class c
    // (fx_translate rewrites such bytes); 254 = KILL (all-dead row, feeds the end of a row); 255 = SKIP (continuation byte
    // inside a valid character).
@@ -622,39 +625,45 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       for (int b = 0; b < 128; ++b)
          for (int s = 0; s < 8; ++s) {
             fa[static_cast<size_t>(b) * 8 + s] = s < A.n ? static_cast<uint8_t>(TA(s, ac[static_cast<size_t>(b)])) : 0;
-            fr[static_cast<size_t>(b) * 8 + s] = s < R.n ? static_cast<uint8_t>(TR(s, ac[static_cast<size_t>(b)])) : static_cast<uint8_t>(0);
+            fr[static_cast<size_t>(b) * 8 + s] = (!is_match && s < R.n) ? static_cast<uint8_t>(TR(s, ac[static_cast<size_t>(b)])) : static_cast<uint8_t>(0);
          }
       h.flags |= FXP_F_FAST_OK;
-      const bool utf8 = r_has_skip && !prefilter && ncls <= 126;   // id 254 stays an all-dead row (end-of-row kill symbol)
+      const bool utf8 = (is_match || (r_has_skip && !prefilter)) && ncls <= 126;   // id 254 stays an all-dead row (end-of-row kill symbol)
       if (utf8) {
          h.flags |= FXP_F_FAST_UTF8;
          for (int c = 0; c < ncls; ++c)
             for (int s = 0; s < 8; ++s) {
                fa[static_cast<size_t>(128 + c) * 8 + s] = s < A.n ? static_cast<uint8_t>(TA(s, c)) : 0;
-               fr[static_cast<size_t>(128 + c) * 8 + s] = s < R.n ? static_cast<uint8_t>(TR(s, c)) : static_cast<uint8_t>(0);
+               fr[static_cast<size_t>(128 + c) * 8 + s] = (!is_match && s < R.n) ? static_cast<uint8_t>(TR(s, c)) : static_cast<uint8_t>(0);
             }
          for (int s = 0; s < 8; ++s) {
             fa[255u * 8 + s] = static_cast<uint8_t>(s < A.n ? s : 0);
-            fr[255u * 8 + s] = s < R.n ? static_cast<uint8_t>(R.T[static_cast<size_t>(s) * R.ncol + nI]) : static_cast<uint8_t>(0);
+            fr[255u * 8 + s] = (!is_match && s < R.n) ? static_cast<uint8_t>(R.T[static_cast<size_t>(s) * R.ncol + nI]) : static_cast<uint8_t>(0);
          }
       }
-      int accmin = A.n, hitmin = R.n;
+      int accmin = A.n, hitmin = is_match ? 0 : R.n;
       for (int s = A.n - 1; s >= 0 && A.out[static_cast<size_t>(s)]; --s) accmin = s;
-      for (int s = R.n - 1; s >= 0 && R.out[static_cast<size_t>(s)]; --s) hitmin = s;
+      if (!is_match)
+         for (int s = R.n - 1; s >= 0 && R.out[static_cast<size_t>(s)]; --s) hitmin = s;
       h.fast_accA_min = static_cast<uint32_t>(accmin);
       h.fast_hitR_min = static_cast<uint32_t>(hitmin);
       h.fast_R_start = h.R_start;
-      h.fast_A_init = h.A_init;
+      h.fast_A_init = is_match ? h.M_start : h.A_init;
+      uint64_t fm = 0;
+      for (int s = 0; s < A.n && s < 8; ++s)
+         if (fin[static_cast<size_t>(s)]) fm |= uint64_t(1) << (8 * s);
+      h.fast_finalM[0] = static_cast<uint32_t>(fm);
+      h.fast_finalM[1] = static_cast<uint32_t>(fm >> 32);
    }
    h.off_fastA = bl.put(fa.data(), fa.size());
    h.off_fastR = bl.put(fr.data(), fr.size());
 
    // ---- 8. chain tables: any automaton whose class-indexed tables fit 16-bit row offsets (LDS chain kernel) ---------------
    {
-      const uint32_t ncols = static_cast<uint32_t>(ncls) + 2, row_bytes = ncols * 2;
-      const uint32_t col_skip = static_cast<uint32_t>(ncls), col_kill = static_cast<uint32_t>(ncls) + 1;
-      const bool chain = brute_equiv && !fast && ncls <= 126 && static_cast<uint64_t>(A.n) * row_bytes < 65536u &&
-                         static_cast<uint64_t>(R.n) * row_bytes < 65536u;
+      const uint32_t ncols = static_cast<uint32_t>(ncls) + 3, row_bytes = ncols * 2;
+      const uint32_t col_skip = static_cast<uint32_t>(ncls), col_kill = static_cast<uint32_t>(ncls) + 1, col_final = static_cast<uint32_t>(ncls) + 2;
+      const bool chain = (is_match || brute_equiv) && !fast && ncls <= 126 && static_cast<uint64_t>(A.n) * row_bytes < 65536u &&
+                         (is_match || static_cast<uint64_t>(R.n) * row_bytes < 65536u);
       std::vector<uint16_t> cm(256), ctr, cta;
       if (chain) {
          for (uint32_t sym = 0; sym < 256; ++sym) {
@@ -664,9 +673,9 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             else if (sym - 128 < static_cast<uint32_t>(ncls)) col = sym - 128;
             cm[sym] = static_cast<uint16_t>(2 * col);
          }
-         ctr.assign(static_cast<size_t>(R.n) * ncols, 0);
+         ctr.assign(is_match ? 0 : static_cast<size_t>(R.n) * ncols, 0);
          cta.assign(static_cast<size_t>(A.n) * ncols, 0);
-         for (int st = 0; st < R.n; ++st) {
+         for (int st = 0; !is_match && st < R.n; ++st) {
             for (int c = 0; c < ncls; ++c) ctr[static_cast<size_t>(st) * ncols + c] = static_cast<uint16_t>(TR(st, c) * row_bytes);
             const int sk = r_has_skip ? R.T[static_cast<size_t>(st) * R.ncol + nI] : st;
             ctr[static_cast<size_t>(st) * ncols + col_skip] = static_cast<uint16_t>(sk * row_bytes);
@@ -676,15 +685,17 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             for (int c = 0; c < ncls; ++c) cta[static_cast<size_t>(st) * ncols + c] = static_cast<uint16_t>(TA(st, c) * row_bytes);
             cta[static_cast<size_t>(st) * ncols + col_skip] = static_cast<uint16_t>(st * row_bytes);
             cta[static_cast<size_t>(st) * ncols + col_kill] = 0;
+            cta[static_cast<size_t>(st) * ncols + col_final] = fin[static_cast<size_t>(st)];
          }
-         int accmin = A.n, hitmin = R.n;
+         int accmin = A.n, hitmin = is_match ? 0 : R.n;
          for (int st = A.n - 1; st >= 0 && A.out[static_cast<size_t>(st)]; --st) accmin = st;
-         for (int st = R.n - 1; st >= 0 && R.out[static_cast<size_t>(st)]; --st) hitmin = st;
+         if (!is_match)
+            for (int st = R.n - 1; st >= 0 && R.out[static_cast<size_t>(st)]; --st) hitmin = st;
          h.flags |= FXP_F_CHAIN_OK;
-         if (r_has_skip && !prefilter) h.flags |= FXP_F_CHAIN_UTF8;
+         if (is_match || (r_has_skip && !prefilter)) h.flags |= FXP_F_CHAIN_UTF8;
          h.chain_row_bytes = row_bytes;
          h.chain_R_start = h.R_start * row_bytes;
-         h.chain_A_init = h.A_init * row_bytes;
+         h.chain_A_init = (is_match ? h.M_start : h.A_init) * row_bytes;
          h.chain_hit_min = static_cast<uint32_t>(hitmin) * row_bytes;
          h.chain_acc_min = static_cast<uint32_t>(accmin) * row_bytes;
          h.chain_TR_bytes = static_cast<uint32_t>(ctr.size() * 2);

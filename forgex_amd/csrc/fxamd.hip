@@ -405,6 +405,156 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
 }
 
 // =========================================================================================================
+// fx_match_fast: `.match.` on the tile kernel.  One forward pass of the anchored automaton over every byte of the row from
+// M_start (the state after the optional leading NUL, api_internal_m.F90:280-289), verdict = the state's FINAL bit (accept at
+// ci = n+2 or after the trailing NUL, :296-302), behind the reference's literal / prefix / suffix gate (forgex.F90:207-213,
+// api_internal_m.F90:199-233) which is evaluated on the raw row bytes.  Same staging, schemes and UTF-8 second pass as the
+// search kernel.
+// =========================================================================================================
+template <class F>
+__device__ __forceinline__ void chain8_fwd(const F (&f)[8], uint32_t& state, const uint8_t* T) {
+#pragma unroll
+   for (int i = 0; i < 8; ++i) state = fxstep(f[i], state, T);
+}
+
+// 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides
+__device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t* __restrict__ prog, const uint8_t* tb, uint32_t lane, uint32_t L) {
+   const uint32_t lp = h->len_prefix, ls = h->len_suffix, la = h->len_all;
+   auto row = [&](uint32_t j) -> uint32_t { return tb[(tile_cell(lane, j >> 4) << 4) + (j & 15u)]; };
+   if ((h->flags & FXP_F_MATCH_LITERAL) && L == la) {
+      bool eq = true;
+      for (uint32_t k = 0; k < la; ++k) eq = eq && row(k) == prog[h->off_all + k];
+      return eq ? 2u : 0u;
+   }
+   if (lp > 0 && lp == L) {
+      bool eq = true;
+      for (uint32_t k = 0; k < lp; ++k) eq = eq && row(k) == prog[h->off_prefix + k];
+      if (eq) return 2u;
+   }
+   if (lp > L || ls > L) return 0u;
+   bool ok = true;
+   if (h->flags & FXP_F_PREFILTER)
+      for (uint32_t k = 0; k < lp; ++k) ok = ok && row(k) == prog[h->off_prefix + k];
+   if (h->flags & FXP_F_HAS_SUFFIX)
+      for (uint32_t k = 0; k < ls; ++k) ok = ok && row(L - ls + k) == prog[h->off_suffix + k];
+   return ok ? 1u : 0u;
+}
+
+template <int CH, bool FIXUP, bool CHAIN>
+__global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+                                                       FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
+                                                       uint32_t class_map_in_lds) {
+   constexpr int L = 16 * CH;
+   if (FIXUP && *n_deferred == 0) return;
+   using F = typename FxF<CHAIN>::type;
+   __shared__ uint2 permA[CHAIN ? 1 : 256];
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
+   const uint32_t chain_bytes = CHAIN ? ((512u + h->chain_TA_bytes + 15u) & ~15u) : 0u;
+   const uint8_t* TAp = reinterpret_cast<const uint8_t*>(cmap) + 512;
+   if (CHAIN) {
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_chain_cls);
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TA);
+      const uint32_t na = h->chain_TA_bytes / 2;
+      for (uint32_t i = threadIdx.x; i < 256u + na; i += 256u) cmap[i] = i < 256u ? g[i] : ga[i - 256u];
+   } else {
+      permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
+   }
+   __syncthreads();
+   using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
+   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
+   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const bool utf8 = (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
+   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
+   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
+   if (FIXUP && class_map_in_lds) {
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * CH) + chain_bytes);
+      const uint32_t n16 = 1024u + h->n_pages * 64u;
+      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      __syncthreads();
+      page_p = l16;
+      pages_p = l16 + 1024;
+   }
+   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
+                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
+   const uint32_t sym_ffff = 128u + h->cls_ffff;
+   uint4* tile = tiles + wave * (64 * CH);
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   bool any_deferred = false;
+   uint4 stage[CH];
+   if (!FIXUP && wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
+      const int64_t row0 = t << 6;
+      if (FIXUP) {
+         const int64_t rr = row0 + lane;
+         const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
+         if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;
+         load_tile<CH>(stage, rows, row0, n, lane);
+      }
+      if (!FIXUP && utf8) {
+         const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+         if (__builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0) {
+            if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
+            any_deferred = true;
+            if (t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+            continue;
+         }
+      }
+      store_tile<CH>(stage, tile, lane);
+      if (!FIXUP && t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+      const uint32_t gate = match_gate(h, prog, tb, lane, (uint32_t)L);   // on the raw bytes, before any decode
+      if (FIXUP) {
+         uint32_t prev = 0;
+         uint4 cur = tile[tile_cell(lane, 0)];
+         for (int k = 0; k < CH; ++k) {
+            const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+            const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+            tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+            prev = cur.w;
+            cur = nxt;
+         }
+      }
+      // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
+      uint32_t st = fp.A_init;   // = M_start
+      uint32_t na = 0;
+      F fa[8], fb[8];
+      uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
+      if (CH >= 2) wn = tile[tile_cell(lane, 1)];
+      lookup8(fa, wk.x, wk.y, tabA);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+         na |= wk.x | wk.y | wk.z | wk.w;
+         lookup8(fb, wk.z, wk.w, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fa, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         if (k + 1 < CH) {
+            wk = wn;
+            lookup8(fa, wk.x, wk.y, tabA);
+            if (k + 2 < CH) wn = tile[tile_cell(lane, k + 2)];
+         }
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fb, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+      uint32_t fin;
+      if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * (h->n_classes + 2u));   // FINAL column
+      else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
+      uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin != 0 ? 1u : 0u));
+      const bool row_hi = !FIXUP && (na & 0x80808080u) != 0;
+      const bool defer_tile = !FIXUP && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
+      if ((row_hi && !utf8) || defer_tile) flag = FX_NEEDS_GENERAL;
+      any_deferred = any_deferred || defer_tile;
+      const int64_t row = row0 + lane;
+      if (row < n) flags[row] = (uint8_t)flag;
+   }
+   if (!FIXUP && any_deferred && lane == 0) *n_deferred = 1u;
+}
+
+// =========================================================================================================
 // general kernel: one lane = one row, fxrow::run_row
 // =========================================================================================================
 struct GlobalRow {
@@ -591,6 +741,40 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
    return hipGetLastError();
 }
 
+template <int CH, bool FIXUP, bool CHAIN>
+static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
+                               uint32_t class_map_bytes, uint32_t chain_bytes, hipStream_t st) {
+   const int64_t n_tiles = (n + 63) >> 6;
+   int64_t blocks = (n_tiles + 3) / 4;
+   if (blocks > 256 * 8) blocks = 256 * 8;
+   const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
+   if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_match_fast<CH, FIXUP, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+   }
+   hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds);
+   return hipGetLastError();
+}
+
+template <bool FIXUP, bool CHAIN>
+static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                                   uint8_t* d_flags, uint32_t* n_deferred, hipStream_t st) {
+   const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
+   const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TA_bytes + 15u) & ~15u) : 0u;
+   FastParams fp{0, CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u, 0, 0, make_uint2(0, 0)};
+   switch (row_len >> 4) {
+      case 1: return launch_match<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      case 2: return launch_match<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      case 3: return launch_match<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      case 4: return launch_match<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      case 6: return launch_match<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      case 8: return launch_match<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      case 12: return launch_match<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+      default: return launch_match<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+   }
+}
+
 static bool row_len_ok(const uint8_t* d_rows, int64_t row_len) {
    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
    return aligned16 && (row_len == 16 || row_len == 32 || row_len == 48 || row_len == 64 || row_len == 96 || row_len == 128 ||
@@ -598,7 +782,7 @@ static bool row_len_ok(const uint8_t* d_rows, int64_t row_len) {
 }
 // 0 = tile kernel not applicable, 1 = v_perm scheme, 2 = chain scheme (tables must fit the CU's LDS next to the tiles)
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if (h.mode != FXP_MODE_SEARCH_ENGINE || !row_len_ok(d_rows, row_len)) return 0;
+   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE) || !row_len_ok(d_rows, row_len)) return 0;
    if (h.flags & FXP_F_FAST_OK) return 1;
    if (h.flags & FXP_F_CHAIN_OK) {
       const size_t need = (size_t)4 * 64 * row_len + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
@@ -761,7 +945,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (p->prog.status != 0) return FXAMD_E_ARG;
    const FxpHeader& h = p->prog.hdr();
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme == 0) return FXAMD_E_ARG;
+   if (scheme == 0 || h.mode != FXP_MODE_SEARCH_ENGINE) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, (hipStream_t)hip_stream));
@@ -815,7 +999,31 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       return FXAMD_OK;
    }
    const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
+   if (h.mode == FXP_MODE_MATCH_ENGINE) {   // `.match.` has no span: from/to stay untouched
+      d_from = nullptr;
+      d_to = nullptr;
+   }
    const int scheme = fast_scheme(h, d_rows, row_len);
+   if (scheme != 0 && h.mode == FXP_MODE_MATCH_ENGINE) {
+      FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
+      if (scheme == 1) FX_HIP((launch_match_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
+      else FX_HIP((launch_match_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
+      if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
+         if (scheme == 1) FX_HIP((launch_match_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
+         else FX_HIP((launch_match_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
+         p->last_path = scheme == 1 ? 1 : 5;
+         return FXAMD_OK;
+      }
+      if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
+         const unsigned fblocks = (unsigned)((n + 4095) / 4096);
+         hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to);
+      } else {
+         hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
+      }
+      FX_HIP(hipGetLastError());
+      p->last_path = scheme == 1 ? 3 : 6;
+      return FXAMD_OK;
+   }
    if (scheme != 0) {
       FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
       if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));

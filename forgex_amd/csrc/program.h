@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 7u
+#define FXP_VERSION 8u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -43,6 +43,7 @@ struct FxpHeader {
    uint32_t cls_nul, cls_ffff;
    uint32_t len_prefix, len_suffix, len_all;
    uint32_t fast_accA_min, fast_hitR_min, fast_R_start, fast_A_init;   // fast tables: state >= *_min <=> accepting / hit
+                                                                       // (`.match.` programs: fast_A_init = M_start)
    uint32_t off_bounds;      // int32  [n_bounds]   ascending first code point of each interval (bounds[0] == 0)
    uint32_t off_bound_cls;   // uint16 [n_bounds]   class of each interval
    uint32_t off_ascii_cls;   // uint16 [128]
@@ -65,13 +66,15 @@ struct FxpHeader {
    uint32_t off_nfa_rstart;   // uint32 [words]   reverse scan start set (after the trailing NUL)
    uint32_t off_nfa_fwd;      // uint32 [n_classes][N+1][words]   closed successors of a state on a class
    uint32_t off_nfa_rev;      // uint32 [n_classes][N+1][words]   states that reach z' by (closure, one symbol of the class)
-   // ---- LDS chain tables (FXP_F_CHAIN_OK): state = byte offset of its row; row = (n_classes + 2) uint16 entries holding
-   //      the destination row offset per column: classes 0..n_classes-1, then SKIP, then KILL ----
+   // ---- LDS chain tables (FXP_F_CHAIN_OK): state = byte offset of its row; row = (n_classes + 3) uint16 entries: the
+   //      destination row offset per column (classes 0..n_classes-1, then SKIP, then KILL) and a FINAL column that holds
+   //      the `.match.` verdict of the state (off_finalM) ----
    uint32_t chain_row_bytes, chain_R_start, chain_A_init, chain_hit_min, chain_acc_min, chain_TR_bytes, chain_TA_bytes;
    uint32_t off_chain_cls;    // uint16 [256]   2 * column of each fast-path symbol id
-   uint32_t off_chain_TR;     // uint16 [nR][n_classes + 2]
-   uint32_t off_chain_TA;     // uint16 [nA][n_classes + 2]   row 0 = dead
-   uint32_t reserved[1];
+   uint32_t off_chain_TR;     // uint16 [nR][n_classes + 3]
+   uint32_t off_chain_TA;     // uint16 [nA][n_classes + 3]   row 0 = dead
+   uint32_t fast_finalM[2];   // v_perm scheme, `.match.`: byte q = 1 when state q gives a true verdict after the last text byte
+   uint32_t reserved[3];
 };
 
 #define FXP_STATE_MASK 0x7FFFu

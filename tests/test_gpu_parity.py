@@ -293,6 +293,10 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
             _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
             assert np.array_equal(f2, of), (pat, L, "flags-only")
+            # `.match.` of the same pattern over the same rows (tile kernel when its tables fit, else the general kernel)
+            pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+            om, _, _ = oracle_lib.batch(1, pat, rows, NT)
+            assert np.array_equal(fm, om), (pat, L, "match", pm.last_path())
     assert n_fast >= 60
 
 
@@ -321,3 +325,34 @@ def test_chain_scheme_patterns_vs_oracle(fx):
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
             assert int(of.sum()) > 0
+
+
+def test_match_operator_on_tile_kernel(fx):
+    """`.match.` through fx_match_fast (v_perm and chain schemes), incl. the literal / prefix / suffix gate quirks."""
+    nrng = np.random.default_rng(23)
+    cases = [(rb"\d{3}-\d{4}", b"0123456789-", 16), (rb"[a-z]+\d+", b"abcxyz0189 ", 32), (rb"ab[cd]e*f", b"abcdef", 16),
+             (rb"foo(bar|baz)x*", b"fobarzx", 16), (rb"^abc.*xyz$", b"abcxyz.\n", 32), ("[ぁ-ん]+[0-9]*".encode(), None, 48)]
+    for pat, alpha, L in cases:
+        if alpha is None:
+            pieces = [s.encode() for s in "あいうえおかん"] + [b"0", b"1", b"9", b" ", b"\x80"]
+            rows = np.stack([np.frombuffer((b"".join(pieces[i] for i in nrng.integers(0, len(pieces), size=L)))[:L], dtype=np.uint8) for _ in range(3000)])
+        else:
+            a = np.frombuffer(alpha, dtype=np.uint8)
+            rows = a[nrng.integers(0, len(a), size=(3000, L))].copy()
+        # rows that actually match: fill some with canonical matches padded to L
+        full = {rb"\d{3}-\d{4}": b"555-1234", rb"ab[cd]e*f": b"abc" + b"e" * 12 + b"f", rb"foo(bar|baz)x*": b"foobar" + b"x" * 10}
+        if pat in full and len(full[pat]) == L:
+            rows[::5] = np.frombuffer(full[pat], dtype=np.uint8)
+        if pat == rb"[a-z]+\d+":
+            rows[::4] = np.frombuffer(b"a" * 20 + b"1" * 12, dtype=np.uint8)
+        prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+        assert prog.last_path() in (1, 3, 5, 6), (pat, prog.last_path())
+        of, _, _ = oracle_lib.batch(1, pat, rows, NT)
+        assert np.array_equal(f, of), pat
+    # 8-byte rows of BASELINE config 1 go through the general kernel (row length not a multiple of 16): still bit-exact
+    import torch
+    from forgex_amd import synth
+    rows = synth.batch("cfg1", 0, 1000, torch.device("cpu")).numpy()
+    prog, f, _, _ = _device_run(fx, synth.PATTERNS["cfg1"].encode(), fx.OP_MATCH, rows, spans=False)
+    of, _, _ = oracle_lib.batch(1, synth.PATTERNS["cfg1"].encode(), rows, NT)
+    assert np.array_equal(f, of) and prog.last_path() == 2
