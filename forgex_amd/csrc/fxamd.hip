@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
       uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
       if (CH >= 2) wn = tile[tile_cell(lane, 1)];
       lookup8(fa, wk.x, wk.y, tabA);
-#pragma unroll
+#pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
       for (int k = 0; k < CH; ++k) {
          na |= wk.x | wk.y | wk.z | wk.w;
          lookup8(fb, wk.z, wk.w, tabA);
