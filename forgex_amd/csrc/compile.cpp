@@ -716,6 +716,77 @@ Program make_search_literal(const std::string& all) {
    h.mode = FXP_MODE_SEARCH_LITERAL;
    h.len_all = static_cast<uint32_t>(all.size());
    h.off_all = bl.put(all.data(), all.size());
+   // Tile-kernel tables for INDEX(str, all): the right-to-left pass runs the KMP automaton of the REVERSED literal over raw
+   // bytes; it is in its last state exactly at the first byte of an occurrence, and the last such hit seen is the leftmost
+   // occurrence.  No forward pass: to = from + len - 1.  (A literal holding a NUL byte would also match the kernel's NUL
+   // sentinels: those stay on the general kernel.)
+   const int m = static_cast<int>(all.size());
+   std::vector<uint8_t> fa(256 * 8, 0), fr(256 * 8, 0);
+   std::vector<uint16_t> cm(256, 0), ctr, cta;
+   if (m >= 1 && all.find('\0') == std::string::npos) {
+      const std::string rev(all.rbegin(), all.rend());
+      std::vector<int> delta(static_cast<size_t>(m + 1) * 256, 0);   // KMP automaton of rev: delta[q][b], state m = full match
+      {
+         auto P = [&](int j) { return static_cast<int>(static_cast<unsigned char>(rev[static_cast<size_t>(j)])); };
+         delta[static_cast<size_t>(P(0))] = 1;
+         int x = 0;   // state reached on the longest proper border of rev[0..j)
+         for (int j = 1; j < m; ++j) {
+            for (int b2 = 0; b2 < 256; ++b2) delta[static_cast<size_t>(j) * 256 + b2] = delta[static_cast<size_t>(x) * 256 + b2];
+            delta[static_cast<size_t>(j) * 256 + P(j)] = j + 1;
+            x = delta[static_cast<size_t>(x) * 256 + P(j)];
+         }
+         for (int b2 = 0; b2 < 256; ++b2) delta[static_cast<size_t>(m) * 256 + b2] = delta[static_cast<size_t>(x) * 256 + b2];   // overlapping occurrences
+      }
+      // byte classes: each distinct literal byte, plus "any other byte"
+      std::vector<int> cls(256, -1);
+      int ncls = 0;
+      for (unsigned char ch : all)
+         if (cls[ch] < 0) cls[ch] = ncls++;
+      const int other = ncls++;
+      int other_byte = -1;
+      for (int b = 0; b < 256; ++b)
+         if (cls[static_cast<size_t>(b)] < 0) {
+            cls[static_cast<size_t>(b)] = other;
+            if (other_byte < 0) other_byte = b;
+         }
+      h.flags |= FXP_F_RAW_BYTES;
+      h.nR = static_cast<uint32_t>(m + 1);
+      if (m + 1 <= 8) {
+         for (int b = 0; b < 256; ++b)
+            for (int q = 0; q <= m; ++q) fr[static_cast<size_t>(b) * 8 + q] = static_cast<uint8_t>(delta[static_cast<size_t>(q) * 256 + b]);
+         h.flags |= FXP_F_FAST_OK;
+         h.fast_R_start = 0;
+         h.fast_hitR_min = static_cast<uint32_t>(m);
+         h.fast_accA_min = 8;
+      } else if (ncls <= 126 && static_cast<uint64_t>(m + 1) * (ncls + 3) * 2 < 65536u && other_byte >= 0) {
+         const uint32_t ncols = static_cast<uint32_t>(ncls) + 3, row_bytes = ncols * 2;
+         for (int b = 0; b < 256; ++b) cm[static_cast<size_t>(b)] = static_cast<uint16_t>(2 * cls[static_cast<size_t>(b)]);
+         ctr.assign(static_cast<size_t>(m + 1) * ncols, 0);
+         std::vector<int> rep(static_cast<size_t>(ncls), other_byte);
+         for (unsigned char ch : all) rep[static_cast<size_t>(cls[ch])] = ch;
+         for (int q = 0; q <= m; ++q)
+            for (int c = 0; c < ncls; ++c)
+               ctr[static_cast<size_t>(q) * ncols + c] = static_cast<uint16_t>(delta[static_cast<size_t>(q) * 256 + rep[static_cast<size_t>(c)]] * row_bytes);
+         cta.assign(ncols, 0);   // a single dead row: the forward pass is not used
+         h.flags |= FXP_F_CHAIN_OK;
+         h.n_classes = static_cast<uint32_t>(ncls);
+         h.chain_row_bytes = row_bytes;
+         h.chain_R_start = 0;
+         h.chain_A_init = 0;
+         h.chain_hit_min = static_cast<uint32_t>(m) * row_bytes;
+         h.chain_acc_min = 0xFFFFFFFFu;
+         h.chain_TR_bytes = static_cast<uint32_t>(ctr.size() * 2);
+         h.chain_TA_bytes = static_cast<uint32_t>(cta.size() * 2);
+      }
+   }
+   h.off_fastA = bl.put(fa.data(), fa.size());
+   h.off_fastR = bl.put(fr.data(), fr.size());
+   h.off_chain_cls = bl.put(cm.data(), cm.size() * 2);
+   h.off_chain_TR = bl.put(ctr.data(), ctr.size() * 2);
+   h.off_chain_TA = bl.put(cta.data(), cta.size() * 2);
+   const uint32_t none = bl.put(nullptr, 0);
+   h.off_bounds = h.off_bound_cls = h.off_ascii_cls = h.off_TA = h.off_TR = h.off_accA = h.off_hitR = h.off_finalM = none;
+   h.off_prefix = h.off_suffix = h.off_cls_page = h.off_cls_pages = none;
    return finish(h, bl);
 }
 

@@ -63,7 +63,8 @@ __device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, ui
 // copies of the automaton and `state >= hit_min` can compare whole registers without masking
 struct FastParams {
    uint32_t R_start, A_init, hit_min, acc_min;
-   uint2 H;   // hit table of R: byte q = 0xFF when state q is a hit state
+   uint2 H;   // (unused)
+   uint32_t lit_len;   // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
 };
 
 // 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permR);
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-   const bool utf8 = (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
+   const bool raw = (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search: bytes are symbols, nothing is decoded or deferred
+   const bool utf8 = !raw && (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
    // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
       // TILE is deferred to the second pass (wave-uniform; the raw-byte scan above is discarded and the
       // forward walk below is skipped).
-      const bool row_hi = !FIXUP && (na & 0x80808080u) != 0;
+      const bool row_hi = !FIXUP && !raw && (na & 0x80808080u) != 0;
       const bool defer_tile = !FIXUP && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
       const bool nonascii = (row_hi && !utf8) || defer_tile;
       const int64_t row = row0 + lane;
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk.
       // The row is extended virtually: position L holds the trailing NUL (byte 0 -> F[0]), later positions kill the state;
       // an accept after consuming position `pos` gives max_match = pos + 3 for text bytes and for the trailing NUL alike.
-      uint32_t cur = (s != 0 && !nonascii && (SPANS || s == 1)) ? fp.A_init : 0u;
-      uint32_t mm = 0;                      // max_match (wrapped index of the byte after the longest match)
+      uint32_t cur = (s != 0 && !nonascii && (SPANS || s == 1) && fp.lit_len == 0) ? fp.A_init : 0u;
+      uint32_t mm = (fp.lit_len != 0 && s != 0) ? s + fp.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
          const F f = tabA[0];
@@ -762,7 +764,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
                                    uint8_t* d_flags, uint32_t* n_deferred, hipStream_t st) {
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TA_bytes + 15u) & ~15u) : 0u;
-   FastParams fp{0, CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u, 0, 0, make_uint2(0, 0)};
+   FastParams fp{0, CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u, 0, 0, make_uint2(0, 0), 0};
    switch (row_len >> 4) {
       case 1: return launch_match<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
       case 2: return launch_match<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
@@ -782,7 +784,7 @@ static bool row_len_ok(const uint8_t* d_rows, int64_t row_len) {
 }
 // 0 = tile kernel not applicable, 1 = v_perm scheme, 2 = chain scheme (tables must fit the CU's LDS next to the tiles)
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE) || !row_len_ok(d_rows, row_len)) return 0;
+   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(d_rows, row_len)) return 0;
    if (h.flags & FXP_F_FAST_OK) return 1;
    if (h.flags & FXP_F_CHAIN_OK) {
       const size_t need = (size_t)4 * 64 * row_len + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
@@ -797,7 +799,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 make_uint2(0, 0)};
+                 make_uint2(0, 0), h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
    if (CHAIN) {   // states are row byte offsets, compared as plain integers
       fp.R_start = h.chain_R_start;
       fp.A_init = h.chain_A_init;
@@ -945,7 +947,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (p->prog.status != 0) return FXAMD_E_ARG;
    const FxpHeader& h = p->prog.hdr();
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme == 0 || h.mode != FXP_MODE_SEARCH_ENGINE) return FXAMD_E_ARG;
+   if (scheme == 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, (hipStream_t)hip_stream));
@@ -1028,6 +1030,10 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
       if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
       else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+      if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing was deferred
+         p->last_path = scheme == 1 ? 1 : 5;
+         return FXAMD_OK;
+      }
       if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
          // tiles holding bytes >= 0x80 were deferred: the second pass decodes UTF-8 in LDS and scans only those tiles
          if (scheme == 1) FX_HIP((launch_fast_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));

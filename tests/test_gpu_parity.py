@@ -356,3 +356,26 @@ def test_match_operator_on_tile_kernel(fx):
     prog, f, _, _ = _device_run(fx, synth.PATTERNS["cfg1"].encode(), fx.OP_MATCH, rows, spans=False)
     of, _, _ = oracle_lib.batch(1, synth.PATTERNS["cfg1"].encode(), rows, NT)
     assert np.array_equal(f, of) and prog.last_path() == 2
+
+
+def test_literal_index_search_on_tile_kernel(fx):
+    """Whole-pattern literals (`.in.` = raw-byte INDEX, forgex.F90:111-130): reverse-KMP tables on the tile kernel, raw bytes
+    (no UTF-8 decode), short (v_perm) and long (chain) literals, overlapping occurrences, occurrences at both row ends."""
+    nrng = np.random.default_rng(31)
+    for lit, L in ((b"ab", 16), (b"aa", 32), (b"abcab", 64), (b"fooba", 64), (b"abcabcabx", 128), ("あいう".encode(), 96), (b"needle in a hay", 256),
+                   (b"a", 16), (b"zzzzzzz", 48)):
+        p = fx.Program(lit, fx.OP_SEARCH)
+        assert p.status == 0 and p.info()["mode"] == 2 and (p.info()["flags"] & (8 | 256)), lit
+        alpha = np.frombuffer(bytes(set(lit)) + b"xy", dtype=np.uint8)
+        rows = alpha[nrng.integers(0, len(alpha), size=(3000, L))].copy()
+        la = np.frombuffer(lit, dtype=np.uint8)
+        rows[::9, :len(la)] = la
+        rows[4::9, L - len(la):] = la
+        rows[2::11] = np.frombuffer(b"q" * L, dtype=np.uint8)
+        prog, f, a, b = _device_run(fx, lit, fx.OP_SEARCH, rows)
+        assert prog.last_path() in (1, 5), (lit, prog.last_path())
+        of, oa, ob = oracle_lib.batch(2, lit, rows, NT)
+        assert np.array_equal(f, of), lit
+        assert np.array_equal(a, oa) and np.array_equal(b, ob), lit
+        _, f2, _, _ = _device_run(fx, lit, fx.OP_SEARCH, rows, spans=False)
+        assert np.array_equal(f2, of)
