@@ -636,11 +636,15 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                fa[static_cast<size_t>(128 + c) * 8 + s] = s < A.n ? static_cast<uint8_t>(TA(s, c)) : 0;
                fr[static_cast<size_t>(128 + c) * 8 + s] = (!is_match && s < R.n) ? static_cast<uint8_t>(TR(s, c)) : static_cast<uint8_t>(0);
             }
-         for (int s = 0; s < 8; ++s) {
-            fa[255u * 8 + s] = static_cast<uint8_t>(s < A.n ? s : 0);
-            fr[255u * 8 + s] = (!is_match && s < R.n) ? static_cast<uint8_t>(R.T[static_cast<size_t>(s) * R.ncol + nI]) : static_cast<uint8_t>(0);
-         }
       }
+      // symbol 255 (SKIP: continuation byte inside a character, also the pad behind rows shorter than their 16-byte chunks):
+      // identity for A; for R "same W, hit cleared" (a plain identity when R was built SKIP-blind).  254 (KILL) stays all-dead.
+      for (int s = 0; s < 8; ++s) {
+         fa[255u * 8 + s] = static_cast<uint8_t>(s < A.n ? s : 0);
+         const int sk = (is_match || s >= R.n) ? 0 : (r_has_skip ? R.T[static_cast<size_t>(s) * R.ncol + nI] : s);
+         fr[255u * 8 + s] = static_cast<uint8_t>(sk);
+      }
+      h.flags |= FXP_F_RAGGED_OK;
       int accmin = A.n, hitmin = is_match ? 0 : R.n;
       for (int s = A.n - 1; s >= 0 && A.out[static_cast<size_t>(s)]; --s) accmin = s;
       if (!is_match)
@@ -691,7 +695,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
          for (int st = A.n - 1; st >= 0 && A.out[static_cast<size_t>(st)]; --st) accmin = st;
          if (!is_match)
             for (int st = R.n - 1; st >= 0 && R.out[static_cast<size_t>(st)]; --st) hitmin = st;
-         h.flags |= FXP_F_CHAIN_OK;
+         h.flags |= FXP_F_CHAIN_OK | FXP_F_RAGGED_OK;
          if (is_match || (r_has_skip && !prefilter)) h.flags |= FXP_F_CHAIN_UTF8;
          h.chain_row_bytes = row_bytes;
          h.chain_R_start = h.R_start * row_bytes;
@@ -750,6 +754,7 @@ Program make_search_literal(const std::string& all) {
             if (other_byte < 0) other_byte = b;
          }
       h.flags |= FXP_F_RAW_BYTES;
+      if (all.find('\xFF') == std::string::npos) h.flags |= FXP_F_RAGGED_OK;   // pad byte 0xFF cannot advance the literal's automaton
       h.nR = static_cast<uint32_t>(m + 1);
       if (m + 1 <= 8) {
          for (int b = 0; b < 256; ++b)

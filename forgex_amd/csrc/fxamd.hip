@@ -47,6 +47,55 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
    }
 }
 
+// Rows whose length Lr is not 16*CH (Lr % 4 == 0, 16 <= Lr <= 16*CH): the same 64-row tile, but piece (R, k) comes from byte
+// R*Lr + 16k of the tile (dword aligned, not 16-byte aligned) and the bytes behind the row end are delivered as ZERO.  The
+// last partial chunk is read as the row's LAST 16 bytes and shifted down, so nothing beyond the caller's buffer is touched.
+struct __attribute__((aligned(4))) U4a {
+   uint32_t x, y, z, w;
+};
+template <int CH>
+__device__ __forceinline__ void load_tile_ragged(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane,
+                                                 uint32_t Lr) {
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      const uint32_t p = q * 64 + lane, R = p / CH, k = p % CH;
+      const int64_t row = row0 + R;
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (row < n && 16u * k < Lr) {
+         const uint8_t* rp = rows + row * (int64_t)Lr;
+         if (16u * k + 16u <= Lr) {
+            const U4a t = *reinterpret_cast<const U4a*>(rp + 16u * k);
+            o = make_uint4(t.x, t.y, t.z, t.w);
+         } else {
+            const U4a t = *reinterpret_cast<const U4a*>(rp + Lr - 16u);   // bytes [Lr-16, Lr)
+            const uint32_t rem = Lr - 16u * k;                            // 4, 8 or 12 valid bytes
+            o = rem == 12u ? make_uint4(t.y, t.z, t.w, 0) : (rem == 8u ? make_uint4(t.z, t.w, 0, 0) : make_uint4(t.w, 0, 0, 0));
+         }
+      }
+      v[q] = o;
+   }
+}
+
+// symbol 255 (inert at the end of a row in every scheme) behind the row end, for lane r's own row.  Returns the OR of the row's
+// own bytes (the loader delivered zeros behind the row end), which the ragged kernels use for their ">= 0x80 anywhere" test.
+template <int CH>
+__device__ __forceinline__ uint32_t pad_rows(uint4* tile, uint32_t lane, uint32_t Lr) {
+   uint32_t na = 0;
+#pragma unroll 1
+   for (uint32_t k = 0; k < (uint32_t)CH; ++k) {
+      uint4 c = tile[tile_cell(lane, k)];
+      na |= c.x | c.y | c.z | c.w;
+      const uint32_t b = 16u * k;
+      if (b + 16u <= Lr) continue;   // wave-uniform
+      c.x = b + 0u < Lr ? c.x : 0xFFFFFFFFu;
+      c.y = b + 4u < Lr ? c.y : 0xFFFFFFFFu;
+      c.z = b + 8u < Lr ? c.z : 0xFFFFFFFFu;
+      c.w = b + 12u < Lr ? c.w : 0xFFFFFFFFu;
+      tile[tile_cell(lane, k)] = c;
+   }
+   return na;
+}
+
 template <int CH>
 __device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, uint32_t lane) {
 #pragma unroll
@@ -118,10 +167,11 @@ __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
 // at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
 __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
-   const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8
+   const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8, L a multiple of 4
    const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
-   lo = p < L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);   // 0xFE: the symbol id whose table row is all-dead
-   hi = p < L ? r.y : 0xFEFEFEFEu;
+   // 0x00 at index L (the trailing NUL), 0xFE (the symbol id whose table row is all-dead) behind it
+   lo = p + 4u <= L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
+   hi = p + 8u <= L ? r.y : (p + 4u == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
 }
 __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;
@@ -148,15 +198,26 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
    o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
 }
 
+// aligned rows: fully coalesced 16-byte pieces; ragged rows (Lr != 16*CH): dword-aligned pieces, zero behind the row end
+#define LOAD_TILE(st, r0)                                              \
+   do {                                                                \
+      if (RAGGED) load_tile_ragged<CH>(st, rows, (r0), n, lane, Lr);   \
+      else load_tile<CH>(st, rows, (r0), n, lane);                     \
+   } while (0)
+
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
 //                 the offending rows are marked individually for the general kernel's fix-up.
 // FIXUP = true:  second pass: only marked tiles are loaded, decoded from UTF-8 to symbol ids in LDS, then scanned.
-template <int CH, bool SPANS, bool FIXUP, bool CHAIN>
+template <int CH, bool SPANS, bool FIXUP, bool CHAIN, bool RAGGED>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
-                                                        int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds) {
-   constexpr int L = 16 * CH;
+                                                        int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
+                                                        uint32_t Lr) {
+   // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
+   // instantiation keeps the row length a compile-time constant (the hot path).
+   const uint32_t L = RAGGED ? Lr : 16u * CH;
+   constexpr bool ragged = RAGGED;
    if (FIXUP && *n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
    using F = typename FxF<CHAIN>::type;
    __shared__ uint2 permR[CHAIN ? 1 : 256];
@@ -210,14 +271,14 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
 
    bool any_deferred = false;   // wave-uniform: this wave deferred at least one tile to the second pass
    uint4 stage[CH];   // next tile's global loads stay in flight while the current tile is scanned
-   if (!FIXUP && wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   if (!FIXUP && wave_global < n_tiles) LOAD_TILE(stage, wave_global << 6);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
       if (FIXUP) {
          const int64_t rr = row0 + lane;
          const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
          if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;   // wave-uniform: nothing deferred in this tile
-         load_tile<CH>(stage, rows, row0, n, lane);
+         LOAD_TILE(stage, row0);
       }
       if (!FIXUP && utf8) {
          // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
@@ -226,13 +287,13 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          if (__builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0) {
             if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
             any_deferred = true;
-            if (t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+            if (t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
             continue;
          }
       }
       store_tile<CH>(stage, tile, lane);
       // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
-      if (!FIXUP && t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+      if (!FIXUP && t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
       if (FIXUP) {
          // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
          // (fxrow::translate_cell16).  The 4 bytes before / after a cell are taken from the ORIGINAL neighbours: the
@@ -247,6 +308,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             cur = nxt;
          }
       }
+      const uint32_t na_ragged = ragged ? pad_rows<CH>(tile, lane, Lr) : 0u;
 
       // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
       // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
@@ -254,14 +316,14 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // group's entry state are kept; the exact byte is recovered afterwards by re-walking ONE group per row.
       uint32_t state = fp.R_start;
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
-      uint32_t na = 0;
+      uint32_t na = na_ragged;
       F fa[8], fb[8];
       uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
       if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
       lookup8(fa, wk.z, wk.w, tabR);
 #pragma unroll
       for (int k = CH - 1; k >= 0; --k) {
-         na |= wk.x | wk.y | wk.z | wk.w;
+         if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
          lookup8(fb, wk.x, wk.y, tabR);
          __builtin_amdgcn_sched_barrier(0);
          {
@@ -385,7 +447,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          if (s != 0 && mm != 0) {   // api_internal_m.F90:140-148
             fr = (int32_t)(s - 1);
             if (fr == 0) fr = 1;
-            tt = mm >= (uint32_t)L + 2 ? L : (int32_t)mm - 2;
+            tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
             if (fr > 0 && tt > 0) flag = 1;
             else { fr = 0; tt = 0; }
          }
@@ -442,11 +504,12 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
    return ok ? 1u : 0u;
 }
 
-template <int CH, bool FIXUP, bool CHAIN>
+template <int CH, bool FIXUP, bool CHAIN, bool RAGGED>
 __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
-                                                       uint32_t class_map_in_lds) {
-   constexpr int L = 16 * CH;
+                                                       uint32_t class_map_in_lds, uint32_t Lr) {
+   const uint32_t L = RAGGED ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
+   constexpr bool ragged = RAGGED;
    if (FIXUP && *n_deferred == 0) return;
    using F = typename FxF<CHAIN>::type;
    __shared__ uint2 permA[CHAIN ? 1 : 256];
@@ -487,27 +550,27 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    bool any_deferred = false;
    uint4 stage[CH];
-   if (!FIXUP && wave_global < n_tiles) load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   if (!FIXUP && wave_global < n_tiles) LOAD_TILE(stage, wave_global << 6);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
       if (FIXUP) {
          const int64_t rr = row0 + lane;
          const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
          if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;
-         load_tile<CH>(stage, rows, row0, n, lane);
+         LOAD_TILE(stage, row0);
       }
       if (!FIXUP && utf8) {
          const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
          if (__builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0) {
             if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
             any_deferred = true;
-            if (t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
+            if (t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
             continue;
          }
       }
       store_tile<CH>(stage, tile, lane);
-      if (!FIXUP && t + wave_stride < n_tiles) load_tile<CH>(stage, rows, (t + wave_stride) << 6, n, lane);
-      const uint32_t gate = match_gate(h, prog, tb, lane, (uint32_t)L);   // on the raw bytes, before any decode
+      if (!FIXUP && t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
+      const uint32_t gate = match_gate(h, prog, tb, lane, L);   // on the raw bytes, before any decode
       if (FIXUP) {
          uint32_t prev = 0;
          uint4 cur = tile[tile_cell(lane, 0)];
@@ -519,16 +582,17 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
             cur = nxt;
          }
       }
+      const uint32_t na_ragged = ragged ? pad_rows<CH>(tile, lane, Lr) : 0u;
       // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
       uint32_t st = fp.A_init;   // = M_start
-      uint32_t na = 0;
+      uint32_t na = na_ragged;
       F fa[8], fb[8];
       uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
       if (CH >= 2) wn = tile[tile_cell(lane, 1)];
       lookup8(fa, wk.x, wk.y, tabA);
 #pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
       for (int k = 0; k < CH; ++k) {
-         na |= wk.x | wk.y | wk.z | wk.w;
+         if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
          lookup8(fb, wk.z, wk.w, tabA);
          __builtin_amdgcn_sched_barrier(0);
          chain8_fwd(fa, st, TAp);
@@ -718,9 +782,16 @@ static int hip_fail(hipError_t e) {
       if (_e != hipSuccess) return hip_fail(_e);      \
    } while (0)
 
+// chunk count the tile kernels are instantiated for that covers row_len (0 = none)
+static int tile_chunks(int64_t row_len) {
+   static const int inst[] = {1, 2, 3, 4, 6, 8, 12, 16};
+   for (int c : inst)
+      if (row_len <= 16 * c) return c;
+   return 0;
+}
 template <int CH, bool FIXUP, bool CHAIN>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
-                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, hipStream_t st) {
+                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
@@ -728,34 +799,43 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
    // second pass: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
+   const bool ragged = Lr != 16u * CH;
+   const bool spans = from && to;
+   const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN, true>)
+                                    : reinterpret_cast<const void*>(&fx_search_fast<CH, false, FIXUP, CHAIN, true>))
+                           : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN, false>)
+                                    : reinterpret_cast<const void*>(&fx_search_fast<CH, false, FIXUP, CHAIN, false>));
    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
-      hipError_t e;
-      if (from && to)
-         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      else
-         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_search_fast<CH, false, FIXUP, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
-   if (from && to)
-      hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
-   else
-      hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds);
+   if (ragged) {
+      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
+      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
+   } else {
+      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
+      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
+   }
    return hipGetLastError();
 }
 
 template <int CH, bool FIXUP, bool CHAIN>
 static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
-                               uint32_t class_map_bytes, uint32_t chain_bytes, hipStream_t st) {
+                               uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    if (blocks > 256 * 8) blocks = 256 * 8;
    const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
+   const bool ragged = Lr != 16u * CH;
    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_match_fast<CH, FIXUP, CHAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, FIXUP, CHAIN, true>)
+                                                : reinterpret_cast<const void*>(&fx_match_fast<CH, FIXUP, CHAIN, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
-   hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds);
+   if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr);
+   else hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr);
    return hipGetLastError();
 }
 
@@ -765,29 +845,30 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TA_bytes + 15u) & ~15u) : 0u;
    FastParams fp{0, CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u, 0, 0, make_uint2(0, 0), 0};
-   switch (row_len >> 4) {
-      case 1: return launch_match<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      case 2: return launch_match<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      case 3: return launch_match<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      case 4: return launch_match<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      case 6: return launch_match<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      case 8: return launch_match<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      case 12: return launch_match<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
-      default: return launch_match<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, st);
+   switch (tile_chunks(row_len)) {
+      case 1: return launch_match<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 2: return launch_match<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 3: return launch_match<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 4: return launch_match<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 6: return launch_match<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 8: return launch_match<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 12: return launch_match<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      default: return launch_match<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
    }
 }
 
-static bool row_len_ok(const uint8_t* d_rows, int64_t row_len) {
-   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
-   return aligned16 && (row_len == 16 || row_len == 32 || row_len == 48 || row_len == 64 || row_len == 96 || row_len == 128 ||
-                        row_len == 192 || row_len == 256);
+static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+   if (row_len < 16 || row_len > 256 || (row_len & 3) != 0) return false;
+   if ((reinterpret_cast<uintptr_t>(d_rows) & 15u) != 0) return false;
+   if (row_len == 16 * tile_chunks(row_len)) return true;       // whole chunks: fully coalesced tile loads
+   return (h.flags & FXP_F_RAGGED_OK) != 0;                        // padded in LDS with the inert symbol 255
 }
 // 0 = tile kernel not applicable, 1 = v_perm scheme, 2 = chain scheme (tables must fit the CU's LDS next to the tiles)
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(d_rows, row_len)) return 0;
+   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return 0;
    if (h.flags & FXP_F_FAST_OK) return 1;
    if (h.flags & FXP_F_CHAIN_OK) {
-      const size_t need = (size_t)4 * 64 * row_len + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
+      const size_t need = (size_t)4 * 64 * 16 * tile_chunks(row_len) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
       if (need <= 150 * 1024) return 2;
    }
    return 0;
@@ -806,15 +887,15 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.hit_min = h.chain_hit_min;
       fp.acc_min = h.chain_acc_min;
    }
-   switch (row_len >> 4) {
-      case 1: return launch_fast<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      case 2: return launch_fast<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      case 3: return launch_fast<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      case 4: return launch_fast<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      case 6: return launch_fast<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      case 8: return launch_fast<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      case 12: return launch_fast<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
-      default: return launch_fast<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, st);
+   switch (tile_chunks(row_len)) {
+      case 1: return launch_fast<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 2: return launch_fast<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 3: return launch_fast<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 4: return launch_fast<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 6: return launch_fast<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 8: return launch_fast<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 12: return launch_fast<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      default: return launch_fast<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
    }
 }
 

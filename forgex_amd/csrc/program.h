@@ -34,6 +34,7 @@ enum FxpFlags {
    FXP_F_NFA_SIM = 1u << 7,
    FXP_F_CHAIN_OK = 1u << 8,        // class-indexed LDS chain tables present (automata too large for the v_perm tables)
    FXP_F_CHAIN_UTF8 = 1u << 9,
+   FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it
    FXP_F_RAW_BYTES = 1u << 10,      // literal INDEX search: symbols are raw bytes (no UTF-8 decode, no deferral), hit = occurrence start      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
 };
 

@@ -275,7 +275,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
         if p.status != 0 or not (p.info()["flags"] & (8 | 256)):   # v_perm tables or class-indexed chain tables
             continue
         n_fast += 1
-        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256])
+        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252])   # incl. ragged (not a multiple of 16)
         n = 192
         rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
         mixed = []
@@ -311,7 +311,7 @@ def test_chain_scheme_patterns_vs_oracle(fx):
     for pat in CHAIN_PATTERNS:
         p = fx.Program(pat, fx.OP_SEARCH)
         assert p.status == 0 and (p.info()["flags"] & 256), pat
-        for L in (32, 64, 128, 256):
+        for L in (32, 64, 128, 256, 80, 100):
             rows = alpha[nrng.integers(0, len(alpha), size=(4096, L))].copy()
             # plant some matches
             seeds = [b"555-1234", b"bob@mail.org", b"2024-02-29", b"abcd123x", b"abcdefk", "あいうアイウ123".encode()]
@@ -331,7 +331,10 @@ def test_match_operator_on_tile_kernel(fx):
     """`.match.` through fx_match_fast (v_perm and chain schemes), incl. the literal / prefix / suffix gate quirks."""
     nrng = np.random.default_rng(23)
     cases = [(rb"\d{3}-\d{4}", b"0123456789-", 16), (rb"[a-z]+\d+", b"abcxyz0189 ", 32), (rb"ab[cd]e*f", b"abcdef", 16),
-             (rb"foo(bar|baz)x*", b"fobarzx", 16), (rb"^abc.*xyz$", b"abcxyz.\n", 32), ("[ぁ-ん]+[0-9]*".encode(), None, 48)]
+             (rb"foo(bar|baz)x*", b"fobarzx", 16), (rb"^abc.*xyz$", b"abcxyz.\n", 32), ("[ぁ-ん]+[0-9]*".encode(), None, 48),
+             # ragged row lengths (L % 4 == 0, not a multiple of 16): padded with the inert symbol in LDS
+             (rb"[a-z]+\d+", b"abcxyz0189 ", 20), (rb"ab[cd]e*f", b"abcdef", 36), (rb"^abc.*xyz$", b"abcxyz.\n", 100),
+             (rb"(ab|cd|ef|gh|ij|kl)+\d{2}", b"abcdefghijkl01", 52), ("[ぁ-ん]+[0-9]*".encode(), None, 60)]
     for pat, alpha, L in cases:
         if alpha is None:
             pieces = [s.encode() for s in "あいうえおかん"] + [b"0", b"1", b"9", b" ", b"\x80"]
@@ -344,7 +347,11 @@ def test_match_operator_on_tile_kernel(fx):
         if pat in full and len(full[pat]) == L:
             rows[::5] = np.frombuffer(full[pat], dtype=np.uint8)
         if pat == rb"[a-z]+\d+":
-            rows[::4] = np.frombuffer(b"a" * 20 + b"1" * 12, dtype=np.uint8)
+            rows[::4] = np.frombuffer((b"a" * 20 + b"1" * 12)[32 - L:], dtype=np.uint8)
+        if pat == rb"ab[cd]e*f" and L == 36:
+            rows[::5] = np.frombuffer(b"abc" + b"e" * 32 + b"f", dtype=np.uint8)
+        if L == 52:
+            rows[::3] = np.frombuffer(b"abcdefghijkl" * 4 + b"ab42"[:4], dtype=np.uint8)
         prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
         assert prog.last_path() in (1, 3, 5, 6), (pat, prog.last_path())
         of, _, _ = oracle_lib.batch(1, pat, rows, NT)
@@ -362,7 +369,7 @@ def test_literal_index_search_on_tile_kernel(fx):
     """Whole-pattern literals (`.in.` = raw-byte INDEX, forgex.F90:111-130): reverse-KMP tables on the tile kernel, raw bytes
     (no UTF-8 decode), short (v_perm) and long (chain) literals, overlapping occurrences, occurrences at both row ends."""
     nrng = np.random.default_rng(31)
-    for lit, L in ((b"ab", 16), (b"aa", 32), (b"abcab", 64), (b"fooba", 64), (b"abcabcabx", 128), ("あいう".encode(), 96), (b"needle in a hay", 256),
+    for lit, L in ((b"ab", 20), (b"abcab", 100), (b"needle in a hay", 252), ("あいう".encode(), 84), (b"ab", 16), (b"aa", 32), (b"abcab", 64), (b"fooba", 64), (b"abcabcabx", 128), ("あいう".encode(), 96), (b"needle in a hay", 256),
                    (b"a", 16), (b"zzzzzzz", 48)):
         p = fx.Program(lit, fx.OP_SEARCH)
         assert p.status == 0 and p.info()["mode"] == 2 and (p.info()["flags"] & (8 | 256)), lit
