@@ -30,20 +30,35 @@
 
 // =========================================================================================================
 // tile staging: 64 rows x (16*CH) bytes, HBM -> LDS, transposed so each lane reads its own row conflict-free
-// cell(R, k) = k*64 + (R ^ (k & 63))   [16-byte cells]; chunk k of row R.
+// cell(R, k) = k*64 + (R ^ (k & 7))   [16-byte cells]; chunk k of row R.  Only the low three bits are swizzled: that is all the
+// banking needs (a 16-byte cell spans 4 of the 32/64 banks, so 8 resp. 16 consecutive cells are conflict-free), and it leaves the
+// row's upper bits additive, so the staging stores of one tile differ only in their immediate offsets (store_tile).
 // =========================================================================================================
-__device__ __forceinline__ uint32_t tile_cell(uint32_t R, uint32_t k) { return (k << 6) + (R ^ (k & 63u)); }
+__device__ __forceinline__ uint32_t tile_cell(uint32_t R, uint32_t k) { return (k << 6) + (R ^ (k & 7u)); }
 
+typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FX_PREFETCH_DEPTH
+#define FX_PREFETCH_DEPTH 1   // tiles of global loads in flight per wave in the first pass
+#endif
+#ifndef FX_LOAD_AUX
+#define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
+#endif
 template <int CH>
 __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane) {
-   // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH
-   const uint4* src = reinterpret_cast<const uint4*>(rows + row0 * (int64_t)(16 * CH));
+   // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH.  row0 is wave-uniform:
+   // the tile is addressed through a buffer resource whose base is the tile and whose extent is the tile's valid bytes, so
+   // each piece is ONE buffer_load_dwordx4 (scalar base, lane offset, immediate piece offset) and the pieces of rows >= n
+   // come back as zero from the hardware range check instead of per-piece predication.
    const int64_t rows_left = n - row0;
-   const uint32_t valid_pieces = rows_left >= 64 ? 64u * CH : (rows_left > 0 ? (uint32_t)rows_left * CH : 0u);
+   const uint32_t valid = rows_left >= 64 ? 64u * 16u * CH : (rows_left > 0 ? (uint32_t)rows_left * 16u * CH : 0u);
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)(16 * CH);
+   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(valid), 0x00020000);
 #pragma unroll
    for (int q = 0; q < CH; ++q) {
-      uint32_t p = q * 64 + lane;
-      v[q] = p < valid_pieces ? src[p] : make_uint4(0, 0, 0, 0);
+      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + (uint32_t)q * 1024u, 0, FX_LOAD_AUX);
+      v[q] = make_uint4(t.x, t.y, t.z, t.w);
    }
 }
 
@@ -98,10 +113,22 @@ __device__ __forceinline__ uint32_t pad_rows(uint4* tile, uint32_t lane, uint32_
 
 template <int CH>
 __device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, uint32_t lane) {
+   if constexpr ((CH & (CH - 1)) == 0) {
+      // piece q*64+lane = row q*RPI + r, chunk k (r = lane / CH, k = lane % CH).  With B = max(RPI, 8) the row splits into a
+      // multiple of B, which the swizzle leaves alone (an immediate offset), and a rest < B: B/RPI base addresses in all.
+      constexpr uint32_t RPI = 64 / CH, B = RPI > 8 ? RPI : 8;
+      const uint32_t r = lane / CH, k = lane % CH;
 #pragma unroll
-   for (int q = 0; q < CH; ++q) {
-      uint32_t p = q * 64 + lane;
-      tile[tile_cell(p / CH, p % CH)] = v[q];
+      for (int q = 0; q < CH; ++q) {
+         const uint32_t hi = ((uint32_t)q * RPI) & ~(B - 1u), lo = ((uint32_t)q * RPI) & (B - 1u);
+         tile[(k << 6) + hi + ((lo + r) ^ (k & 7u))] = v[q];
+      }
+   } else {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+         uint32_t p = q * 64 + lane;
+         tile[tile_cell(p / CH, p % CH)] = v[q];
+      }
    }
 }
 
@@ -166,18 +193,28 @@ __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state
 // non-continuation byte within 3 to its left is a lead whose whole sequence is continuation bytes).
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
 // at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
+template <bool RAGGED>
 __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
+   if (!RAGGED) {
+      // whole chunks: index L.. lives in the row's extra chunk column (NUL, then KILL symbols); anything further reads its KILL half
+      const uint32_t pc = p < L + 8u ? p : L + 8u;   // p and L are multiples of 8
+      const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 8u));
+      lo = r.x;
+      hi = r.y;
+      return;
+   }
    const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8, L a multiple of 4
    const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
    // 0x00 at index L (the trailing NUL), 0xFE (the symbol id whose table row is all-dead) behind it
    lo = p + 4u <= L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
    hi = p + 8u <= L ? r.y : (p + 4u == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
 }
+template <bool RAGGED>
 __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;
    uint32_t d[10];
 #pragma unroll
-   for (int g = 0; g < 5; ++g) group_words(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
+   for (int g = 0; g < 5; ++g) group_words<RAGGED>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
    const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
    uint32_t e[9];
 #pragma unroll
@@ -185,11 +222,12 @@ __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uin
 #pragma unroll
    for (int k = 0; k < 8; ++k) o[k] = __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u);
 }
+template <bool RAGGED>
 __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;
    uint32_t d[4];
-   group_words(d[0], d[1], tb, lane, base, L);
-   group_words(d[2], d[3], tb, lane, base + 8u, L);
+   group_words<RAGGED>(d[0], d[1], tb, lane, base, L);
+   group_words<RAGGED>(d[2], d[3], tb, lane, base + 8u, L);
    const uint32_t up = 0u - ((sh >> 2) & 1u);
    uint32_t e[3];
 #pragma unroll
@@ -198,11 +236,40 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
    o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
 }
 
+// ---- optional phase stamps (debug builds only: make stamp) --------------------------------------------------------------
+// -DFX_STAMP: lane 0 of every wave accumulates s_memtime deltas per phase of fx_search_fast and adds them to fx_stamp_acc[].
+#ifdef FX_STAMP
+__device__ unsigned long long fx_stamp_acc[16];
+#define STAMP_DECL unsigned long long _st_t = __builtin_amdgcn_s_memtime(), _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i)                                                     \
+   do {                                                              \
+      const unsigned long long _n = __builtin_amdgcn_s_memtime();    \
+      _st_acc[i] += _n - _st_t;                                      \
+      _st_t = _n;                                                    \
+   } while (0)
+#define STAMP_FLUSH                                                                      \
+   do {                                                                                  \
+      if (lane == 0)                                                                     \
+         for (int _i = 0; _i < 8; ++_i) atomicAdd(&fx_stamp_acc[_i], _st_acc[_i]);       \
+   } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 // aligned rows: fully coalesced 16-byte pieces; ragged rows (Lr != 16*CH): dword-aligned pieces, zero behind the row end
 #define LOAD_TILE(st, r0)                                              \
    do {                                                                \
       if (RAGGED) load_tile_ragged<CH>(st, rows, (r0), n, lane, Lr);   \
       else load_tile<CH>(st, rows, (r0), n, lane);                     \
+   } while (0)
+// prefetch of a tile that may lie behind the last one: the aligned loader needs no guard (zero valid bytes -> every piece is
+// range-checked away), and an unguarded load keeps the staging registers free of control-flow merges
+#define PREFETCH_TILE(st, tn)                                          \
+   do {                                                                \
+      if (!RAGGED) load_tile<CH>(st, rows, (tn) << 6, n, lane);        \
+      else if ((tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
    } while (0)
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
@@ -225,7 +292,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
-   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * (CH + 1));
    const uint32_t chain_bytes = CHAIN ? ((512u + h->chain_TR_bytes + h->chain_TA_bytes + 15u) & ~15u) : 0u;
    const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cmap) + 512;
    const uint8_t* TAp = TRp + (CHAIN ? h->chain_TR_bytes : 0u);
@@ -247,14 +314,14 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
    const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permR);
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
-   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
    const bool raw = (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search: bytes are symbols, nothing is decoded or deferred
    const bool utf8 = !raw && (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
    // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
    if (FIXUP && class_map_in_lds) {
-      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * CH) + chain_bytes);
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * (CH + 1)) + chain_bytes);
       const uint32_t n16 = 1024u + h->n_pages * 64u;
       for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
       __syncthreads();
@@ -264,36 +331,45 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
                                reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
    const uint32_t sym_ffff = 128u + h->cls_ffff;
-   uint4* tile = tiles + wave * (64 * CH);
+   // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (0xFE, whose table
+   // row is all-dead), so the forward pass reads "past the end" like any other position.  Written once, never overwritten.
+   uint4* tile = tiles + wave * (64 * (CH + 1));
+   tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
 
    bool any_deferred = false;   // wave-uniform: this wave deferred at least one tile to the second pass
-   uint4 stage[CH];   // next tile's global loads stay in flight while the current tile is scanned
-   if (!FIXUP && wave_global < n_tiles) LOAD_TILE(stage, wave_global << 6);
-   for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
+   STAMP_DECL;
+   // One tile: `stage` holds its global loads (issued DEPTH tiles ago); once they are stored to LDS the same registers take the
+   // loads of tile t_next, which stay in flight while this and the following DEPTH-1 tiles are scanned.
+   auto do_tile = [&](uint4 (&stage)[CH], const int64_t t, const int64_t t_next) {
       const int64_t row0 = t << 6;
+      STAMP(7);
       if (FIXUP) {
          const int64_t rr = row0 + lane;
          const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
-         if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;   // wave-uniform: nothing deferred in this tile
+         if (__builtin_amdgcn_ballot_w64(marked) == 0) return;   // wave-uniform: nothing deferred in this tile
          LOAD_TILE(stage, row0);
       }
+      // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
+      // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
+      bool defer_early = false;
       if (!FIXUP && utf8) {
-         // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
-         // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
          const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
-         if (__builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0) {
-            if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
-            any_deferred = true;
-            if (t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
-            continue;
-         }
+         defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
       }
       store_tile<CH>(stage, tile, lane);
+      STAMP(0);
       // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
-      if (!FIXUP && t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
+      // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
+      // loop's back edge: copies behind a vmcnt(0))
+      if (!FIXUP) PREFETCH_TILE(stage, t_next);
+      if (defer_early) {
+         if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
+         any_deferred = true;
+         return;
+      }
       if (FIXUP) {
          // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
          // (fxrow::translate_cell16).  The 4 bytes before / after a cell are taken from the ORIGINAL neighbours: the
@@ -314,6 +390,25 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
       // expressible) while the state chain of the current group runs.  Per group only "did any state hit" and the
       // group's entry state are kept; the exact byte is recovered afterwards by re-walking ONE group per row.
+      STAMP(1);
+#ifdef FX_EXP_NOCOMPUTE
+      {   // experiment: memory path only (loads, LDS staging, outputs), no automaton work
+         uint32_t acc = na_ragged;
+#pragma unroll
+         for (int k = 0; k < CH; ++k) {
+            const uint4 c = tile[tile_cell(lane, k)];
+            acc |= c.x | c.y | c.z | c.w;
+         }
+         if (row0 + lane < n) {
+            flags[row0 + lane] = (uint8_t)(acc & 1u);
+            if (SPANS) {
+               from[row0 + lane] = (int32_t)acc;
+               to[row0 + lane] = (int32_t)(acc >> 1);
+            }
+         }
+         return;
+      }
+#endif
       uint32_t state = fp.R_start;
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
       uint32_t na = na_ragged;
@@ -331,6 +426,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             const uint32_t mx = chain8_back(fa, state, TRp);
             gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
             esel = mx >= fp.hit_min ? entry : esel;
+            asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
          }
          __builtin_amdgcn_sched_barrier(0);
          if (k >= 1) {
@@ -344,9 +440,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             const uint32_t mx = chain8_back(fb, state, TRp);
             gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
             esel = mx >= fp.hit_min ? entry : esel;
+            asm volatile("" : "+v"(esel));
          }
          __builtin_amdgcn_sched_barrier(0);
       }
+      STAMP(2);
       uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
       {
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
@@ -385,12 +483,13 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          cur = fxstep(f, cur, TAp);
          mm = cur >= fp.acc_min ? 2u : 0u;
       }
+      STAMP(3);
       if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
          // First 32 symbols from j, straight-line: five aligned 8-byte row reads, a byte shift to start exactly at j,
          // all 32 table lookups issued before the chain; per 8-byte group only "any accept" (v_max3) + entry state
          // are kept and the last accepting group is re-walked for the exact byte.
          uint32_t o[8];
-         fetch32(o, tb, lane, j, (uint32_t)L);
+         fetch32<RAGGED>(o, tb, lane, j, (uint32_t)L);
          F f[32];
 #pragma unroll
          for (int g = 0; g < 4; ++g) lookup8(&f[8 * g], o[2 * g], o[2 * g + 1], tabA);
@@ -423,11 +522,12 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
          }
          j += 32u;
+         STAMP(4);
          // matches longer than the window: 8 symbols per round trip
          while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             if (cur != 0) {
                uint32_t o8[2];
-               fetch8(o8, tb, lane, j, (uint32_t)L);
+               fetch8<RAGGED>(o8, tb, lane, j, (uint32_t)L);
                F f8[8];
                lookup8(f8, o8[0], o8[1], tabA);
                uint32_t loc = 8;
@@ -441,6 +541,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             }
          }
       }
+      STAMP(5);
       uint32_t flag = 0;
       int32_t fr = 0, tt = 0;
       if (SPANS) {
@@ -463,7 +564,33 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             to[row] = tt;
          }
       }
+   };
+   if (FIXUP) {
+      uint4 stage[CH];
+      for (int64_t t = wave_global; t < n_tiles; t += wave_stride) do_tile(stage, t, n_tiles);
+   } else {
+      // first pass: DEPTH tiles of global loads in flight per wave (HBM latency under load is several microseconds: one tile
+      // ahead leaves the wave waiting for its data for a quarter of its time)
+      constexpr int DEPTH = FX_PREFETCH_DEPTH;
+      uint4 stage[DEPTH][CH];
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) PREFETCH_TILE(stage[d], wave_global + d * wave_stride);
+      for (int64_t t = wave_global;;) {   // (leaving the loop from the middle keeps the staging registers free of merges)
+         bool done = false;
+#pragma unroll
+         for (int d = 0; d < DEPTH; ++d) {
+            if (done || t >= n_tiles) {
+               done = true;
+               continue;
+            }
+            do_tile(stage[d], t, t + DEPTH * wave_stride);
+            t += wave_stride;
+         }
+         if (done) break;
+      }
    }
+   STAMP(6);
+   STAMP_FLUSH;
    // one plain store per wave (not an atomic per tile: 16k same-address atomics cost ~0.2 ms); the value only gates the second pass
    if (!FIXUP && any_deferred && lane == 0) *n_deferred = 1u;
 }
@@ -529,7 +656,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    __syncthreads();
    using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
-   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const bool utf8 = (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
@@ -550,7 +677,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    bool any_deferred = false;
    uint4 stage[CH];
-   if (!FIXUP && wave_global < n_tiles) LOAD_TILE(stage, wave_global << 6);
+   if (!FIXUP) PREFETCH_TILE(stage, wave_global);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
       if (FIXUP) {
@@ -559,17 +686,18 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;
          LOAD_TILE(stage, row0);
       }
+      bool defer_early = false;
       if (!FIXUP && utf8) {
          const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
-         if (__builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0) {
-            if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
-            any_deferred = true;
-            if (t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
-            continue;
-         }
+         defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
       }
       store_tile<CH>(stage, tile, lane);
-      if (!FIXUP && t + wave_stride < n_tiles) LOAD_TILE(stage, (t + wave_stride) << 6);
+      if (!FIXUP) PREFETCH_TILE(stage, t + wave_stride);   // the one reload site of the staging registers
+      if (defer_early) {
+         if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
+         any_deferred = true;
+         continue;
+      }
       const uint32_t gate = match_gate(h, prog, tb, lane, L);   // on the raw bytes, before any decode
       if (FIXUP) {
          uint32_t prev = 0;
@@ -798,7 +926,7 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
    if (blocks > cap) blocks = cap;
    // second pass: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
-   const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
+   const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
    const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN, true>)
@@ -868,7 +996,7 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return 0;
    if (h.flags & FXP_F_FAST_OK) return 1;
    if (h.flags & FXP_F_CHAIN_OK) {
-      const size_t need = (size_t)4 * 64 * 16 * tile_chunks(row_len) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
+      const size_t need = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
       if (need <= 150 * 1024) return 2;
    }
    return 0;
@@ -1190,4 +1318,13 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
    return FXAMD_OK;
 }
 
+#ifdef FX_STAMP
+// debug builds only: read and clear the phase accumulators
+int fxamd_debug_stamps(unsigned long long* out) {
+   unsigned long long z[16] = {0};
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_stamp_acc), sizeof(z)) != hipSuccess) return 1;
+   if (hipMemcpyToSymbol(HIP_SYMBOL(fx_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
+   return 0;
+}
+#endif
 }   // extern "C"
