@@ -280,12 +280,15 @@ template <int CH, bool SPANS, bool FIXUP, bool CHAIN, bool RAGGED>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
-                                                        uint32_t Lr) {
+                                                        uint32_t Lr, uint32_t* __restrict__ clear_next) {
    // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
    // instantiation keeps the row length a compile-time constant (the hot path).
    const uint32_t L = RAGGED ? Lr : 16u * CH;
    constexpr bool ragged = RAGGED;
    if (FIXUP && *n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
+   // the "something was deferred" words of consecutive calls alternate: this call's first pass zeroes the NEXT call's word (no
+   // memset node per call; nobody reads that word before the next call's second pass)
+   if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;
    using F = typename FxF<CHAIN>::type;
    __shared__ uint2 permR[CHAIN ? 1 : 256];
    __shared__ uint2 permA[CHAIN ? 1 : 256];
@@ -634,10 +637,11 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
 template <int CH, bool FIXUP, bool CHAIN, bool RAGGED>
 __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
-                                                       uint32_t class_map_in_lds, uint32_t Lr) {
+                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next) {
    const uint32_t L = RAGGED ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
    constexpr bool ragged = RAGGED;
    if (FIXUP && *n_deferred == 0) return;
+   if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;
    using F = typename FxF<CHAIN>::type;
    __shared__ uint2 permA[CHAIN ? 1 : 256];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
@@ -893,7 +897,9 @@ struct fxamd_program {
    std::mutex mu;
    int device = -1;
    uint8_t* d_blob = nullptr;
-   uint32_t* d_counter = nullptr;   // set by the first fast pass when it deferred a (non-ASCII) tile, reset per call
+   uint32_t* d_counter = nullptr;   // two words used by alternate calls: set by a first fast pass that deferred a (non-ASCII) tile; each
+                                    // first pass zeroes the other word for the call after it
+   uint32_t parity = 0;             // which word the next call uses
    uint32_t* d_nfa_scratch = nullptr;   // bitset scratch of the NFA-simulation kernel (FXP_F_NFA_SIM programs)
    size_t nfa_scratch_rows = 0;
    int last_path = 0;
@@ -920,6 +926,7 @@ static int tile_chunks(int64_t row_len) {
 template <int CH, bool FIXUP, bool CHAIN>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
                               int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 4u);   // the pair's other word (8-byte aligned pair)
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
@@ -938,11 +945,11 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
       if (e != hipSuccess) return e;
    }
    if (ragged) {
-      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
-      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
+      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
+      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
    } else {
-      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
-      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr);
+      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
+      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
    }
    return hipGetLastError();
 }
@@ -950,6 +957,7 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
 template <int CH, bool FIXUP, bool CHAIN>
 static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
                                uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 4u);
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    if (blocks > 256 * 8) blocks = 256 * 8;
@@ -962,8 +970,8 @@ static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
-   if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr);
-   else hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr);
+   if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next);
+   else hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next);
    return hipGetLastError();
 }
 
@@ -1142,7 +1150,10 @@ int fxamd_program_upload(fxamd_program* p) {
       p->d_blob = nullptr;
    }
    FX_HIP(hipMalloc((void**)&p->d_blob, p->prog.blob.size()));
-   if (!p->d_counter) FX_HIP(hipMalloc((void**)&p->d_counter, 16));
+   if (!p->d_counter) {
+      FX_HIP(hipMalloc((void**)&p->d_counter, 16));
+      FX_HIP(hipMemset(p->d_counter, 0, 16));
+   }
    FX_HIP(hipMemcpy(p->d_blob, p->prog.blob.data(), p->prog.blob.size(), hipMemcpyHostToDevice));
    p->device = dev;
    return FXAMD_OK;
@@ -1159,9 +1170,9 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (scheme == 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
-   FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, (hipStream_t)hip_stream));
-   if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, (hipStream_t)hip_stream)));
-   else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, (hipStream_t)hip_stream)));
+   uint32_t* ctr = p->d_counter + (p->parity ^= 1u);
+   if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream)));
+   else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream)));
    return FXAMD_OK;
 }
 
@@ -1216,12 +1227,12 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    }
    const int scheme = fast_scheme(h, d_rows, row_len);
    if (scheme != 0 && h.mode == FXP_MODE_MATCH_ENGINE) {
-      FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
-      if (scheme == 1) FX_HIP((launch_match_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
-      else FX_HIP((launch_match_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
+      uint32_t* ctr = p->d_counter + (p->parity ^= 1u);
+      if (scheme == 1) FX_HIP((launch_match_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
+      else FX_HIP((launch_match_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
       if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
-         if (scheme == 1) FX_HIP((launch_match_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
-         else FX_HIP((launch_match_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, p->d_counter, st)));
+         if (scheme == 1) FX_HIP((launch_match_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
+         else FX_HIP((launch_match_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
          p->last_path = scheme == 1 ? 1 : 5;
          return FXAMD_OK;
       }
@@ -1236,17 +1247,17 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       return FXAMD_OK;
    }
    if (scheme != 0) {
-      FX_HIP(hipMemsetAsync(p->d_counter, 0, 4, st));
-      if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
-      else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+      uint32_t* ctr = p->d_counter + (p->parity ^= 1u);
+      if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
+      else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
       if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing was deferred
          p->last_path = scheme == 1 ? 1 : 5;
          return FXAMD_OK;
       }
       if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
          // tiles holding bytes >= 0x80 were deferred: the second pass decodes UTF-8 in LDS and scans only those tiles
-         if (scheme == 1) FX_HIP((launch_fast_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
-         else FX_HIP((launch_fast_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, p->d_counter, st)));
+         if (scheme == 1) FX_HIP((launch_fast_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
+         else FX_HIP((launch_fast_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
          p->last_path = scheme == 1 ? 1 : 5;
          return FXAMD_OK;
       }
