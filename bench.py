@@ -147,7 +147,7 @@ def main():
     reps = max(5, min(args.steps, 50))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     kernel_ms = None
-    fast = prog.last_path() in (1, 3, 5, 6)
+    fast = prog.last_path() in (1, 3, 5, 6, 7, 8)
     whole_step = cfg == "cfg4"   # non-ASCII rows: the work is in the SECOND pass (on-device UTF-8 decode + scan) -> time the whole step
     if fast and whole_step:
         for a, b in evs:
@@ -183,6 +183,24 @@ def main():
                 "achieved": (alg_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms else None,
                 "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
+
+    # ---- measured device-copy ceiling in the same run: rows -> scratch, read + write bytes per second ----
+    copy_gbs = None
+    try:
+        scratch = torch.empty_like(rows)
+        for _ in range(2):
+            scratch.copy_(rows)
+        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ca.record(stream)
+        for _ in range(5):
+            scratch.copy_(rows)
+        cb.record(stream)
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * rows.numel() * 5 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+        del scratch
+    except Exception:
+        copy_gbs = None
+    roofline["device_copy_gbs"] = copy_gbs   # bytes read + bytes written per second of a plain device-to-device copy of the batch
 
     # ---- packed result gather over RCCL (not part of `value`) ---------------------------------------------------
     gather_ms = None

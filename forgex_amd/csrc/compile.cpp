@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 
 using namespace fxfe;
@@ -37,10 +38,11 @@ struct Dfa {
 };
 
 // Moore partition refinement; keeps `keep0` (the dead state of A) as state 0 when >= 0.
-void minimise(Dfa& d, int keep0) {
+// `labels` (optional) refines the initial partition beyond `out`; `old2new` (optional) receives the state renumbering (-1 = dropped).
+void minimise(Dfa& d, int keep0, const std::vector<int>* labels = nullptr, std::vector<int>* old2new = nullptr) {
    int n = d.n, nc = d.ncol;
    std::vector<int> block(static_cast<size_t>(n));
-   for (int s = 0; s < n; ++s) block[static_cast<size_t>(s)] = d.out[static_cast<size_t>(s)];
+   for (int s = 0; s < n; ++s) block[static_cast<size_t>(s)] = d.out[static_cast<size_t>(s)] + (labels ? 2 * (*labels)[static_cast<size_t>(s)] : 0);
    int nblocks = 0;
    {
       std::map<int, int> m;
@@ -107,7 +109,230 @@ void minimise(Dfa& d, int keep0) {
       for (int c = 0; c < nc; ++c) r.T[static_cast<size_t>(id) * nc + c] = newid[static_cast<size_t>(block[static_cast<size_t>(d.T[static_cast<size_t>(s) * nc + c])])];
    }
    r.init = newid[static_cast<size_t>(block[static_cast<size_t>(d.init)])];
+   if (old2new) {
+      old2new->assign(static_cast<size_t>(n), -1);
+      for (int s = 0; s < n; ++s) (*old2new)[static_cast<size_t>(s)] = newid[static_cast<size_t>(block[static_cast<size_t>(s)])];
+   }
    d = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Byte-level automata: a class-level DFA composed with the UTF-8 decoder, so that the device walks raw bytes.
+// The decoder is the reference's arithmetic one (utf8_m.f90:338-430 `ichar_utf8`): EVERY structurally valid sequence (lead
+// byte C0..F7 followed by its 1..3 continuation bytes) yields the code point its payload bits spell, overlong forms and
+// values beyond U+10FFFF included.  Structure errors (utf8_m.f90:168-246: a continuation byte without a lead, a lead without
+// its continuation bytes, F8..FF) are NOT modelled here: they lead to one absorbing INVALID state and the row is redone by
+// the decode pass.
+// ---------------------------------------------------------------------------------------------------------------------------
+using Sig = std::vector<std::pair<uint32_t, int>>;   // piecewise-constant class function: ascending (start, class), first start 0
+
+void sig_normalise(Sig& s) {
+   Sig o;
+   for (const auto& pr : s) {
+      if (!o.empty() && o.back().first == pr.first) o.pop_back();   // an empty piece: the later one wins
+      if (!o.empty() && o.back().second == pr.second) continue;
+      o.push_back(pr);
+   }
+   s.swap(o);
+}
+int sig_eval(const Sig& s, uint32_t x) {
+   int c = s[0].second;
+   for (const auto& pr : s) {
+      if (pr.first > x) break;
+      c = pr.second;
+   }
+   return c;
+}
+// the function on [lo, hi) re-based to 0
+Sig sig_slice(const Sig& s, uint32_t lo, uint32_t hi) {
+   Sig o;
+   o.emplace_back(0u, sig_eval(s, lo));
+   for (const auto& pr : s)
+      if (pr.first > lo && pr.first < hi) o.emplace_back(pr.first - lo, pr.second);
+   sig_normalise(o);
+   return o;
+}
+// g'(h) = g(64 h + v) for h < limit
+Sig sig_shrink(const Sig& s, uint32_t v, uint32_t limit) {
+   Sig o;
+   for (const auto& pr : s) {
+      const uint32_t ns = pr.first <= v ? 0u : (pr.first - v + 63u) / 64u;
+      if (ns >= limit) break;
+      o.emplace_back(ns, pr.second);
+   }
+   sig_normalise(o);
+   return o;
+}
+
+struct ByteDfa {
+   Dfa d;                  // ncol = 256 until the byte classes are merged
+   std::vector<int> fin;   // verdict at the end of a row: 0 / 1, 2 = redo by the decode pass (inside a character, INVALID)
+   int inv = -1;           // the INVALID state (-1: none; structure errors lead to the dead state 0 instead)
+   bool ok = false;
+};
+
+struct ClassDfaView {
+   int n;
+   std::function<int(int, int)> T;   // (state, class) -> state
+   const std::vector<uint8_t>* out;
+   int init;
+};
+
+constexpr int kMaxByteStates = 4096;
+
+// forward: (q, node); node 0 = between characters, else (continuation bytes still expected, class function of what they can spell)
+ByteDfa build_forward_bytes(const ClassDfaView& A, const Sig& full, const std::vector<int>& fin_class, bool invalid_sink) {
+   ByteDfa r;
+   std::vector<std::pair<int, Sig>> nodes{{0, Sig{}}};
+   std::map<std::pair<int, Sig>, int> node_id{{nodes[0], 0}};
+   auto intern = [&](int rem, Sig sg) {
+      auto key = std::make_pair(rem, std::move(sg));
+      auto it = node_id.find(key);
+      if (it != node_id.end()) return it->second;
+      nodes.push_back(key);
+      node_id.emplace(std::move(key), static_cast<int>(nodes.size()) - 1);
+      return static_cast<int>(nodes.size()) - 1;
+   };
+   std::vector<std::pair<int, int>> keys;   // (q, node); q = -1: INVALID
+   std::map<std::pair<int, int>, int> ids;
+   auto state_of = [&](int q, int node) {
+      if (q == 0) node = 0;   // dead is dead
+      auto key = std::make_pair(q, node);
+      auto it = ids.find(key);
+      if (it != ids.end()) return it->second;
+      keys.push_back(key);
+      ids.emplace(key, static_cast<int>(keys.size()) - 1);
+      return static_cast<int>(keys.size()) - 1;
+   };
+   state_of(0, 0);   // state 0 = dead
+   const int init = state_of(A.init, 0);
+   const int inv = invalid_sink ? state_of(-1, 0) : 0;
+   std::vector<int> T;
+   for (size_t s = 0; s < keys.size(); ++s) {
+      if (static_cast<int>(keys.size()) > kMaxByteStates) return r;
+      const int q = keys[s].first, nd = keys[s].second;
+      T.resize((s + 1) * 256);
+      for (int b = 0; b < 256; ++b) {
+         int dst;
+         if (q == 0) dst = 0;
+         else if (q < 0) dst = static_cast<int>(s);
+         else if (nd == 0) {
+            if (b < 0x80) dst = state_of(A.T(q, sig_eval(full, static_cast<uint32_t>(b))), 0);
+            else if (b < 0xC0 || b >= 0xF8) dst = inv;
+            else {
+               const int rem = b < 0xE0 ? 1 : (b < 0xF0 ? 2 : 3);
+               const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
+               const uint32_t span = 1u << (6 * rem);
+               dst = state_of(q, intern(rem, sig_slice(full, pay * span, (pay + 1) * span)));
+            }
+         } else {
+            const int rem = nodes[static_cast<size_t>(nd)].first;
+            if (b < 0x80 || b >= 0xC0) dst = inv;
+            else {
+               const uint32_t v = static_cast<uint32_t>(b) & 0x3Fu, span = 1u << (6 * (rem - 1));
+               const Sig sub = sig_slice(nodes[static_cast<size_t>(nd)].second, v * span, (v + 1) * span);
+               dst = rem == 1 ? state_of(A.T(q, sub[0].second), 0) : state_of(q, intern(rem - 1, sub));
+            }
+         }
+         T[s * 256 + static_cast<size_t>(b)] = dst;
+      }
+   }
+   const int n = static_cast<int>(keys.size());
+   r.d.n = n;
+   r.d.ncol = 256;
+   r.d.T = std::move(T);
+   r.d.init = init;
+   r.d.out.assign(static_cast<size_t>(n), 0);
+   std::vector<int> fin(static_cast<size_t>(n), 0), labels(static_cast<size_t>(n), 0);
+   for (int s = 0; s < n; ++s) {
+      const int q = keys[static_cast<size_t>(s)].first, nd = keys[static_cast<size_t>(s)].second;
+      if (q > 0 && nd == 0) {
+         r.d.out[static_cast<size_t>(s)] = (*A.out)[static_cast<size_t>(q)];
+         fin[static_cast<size_t>(s)] = fin_class[static_cast<size_t>(q)];
+      } else if (q != 0) {
+         fin[static_cast<size_t>(s)] = 2;
+      }
+      labels[static_cast<size_t>(s)] = fin[static_cast<size_t>(s)] + (q < 0 ? 4 : 0);
+   }
+   std::vector<int> o2n;
+   minimise(r.d, 0, &labels, &o2n);
+   r.fin.assign(static_cast<size_t>(r.d.n), 0);
+   for (int s = 0; s < n; ++s)
+      if (o2n[static_cast<size_t>(s)] >= 0) r.fin[static_cast<size_t>(o2n[static_cast<size_t>(s)])] = fin[static_cast<size_t>(s)];
+   r.inv = invalid_sink ? o2n[static_cast<size_t>(inv)] : -1;
+   r.ok = true;
+   return r;
+}
+
+// reverse (the row is scanned right to left: continuation bytes arrive before their lead byte): (r, node); node 0 = between
+// characters, else (k continuation bytes seen, class of the character as a function of the payload bits still to come)
+ByteDfa build_reverse_bytes(const ClassDfaView& R, const Sig& full) {
+   ByteDfa r;
+   std::vector<std::pair<int, Sig>> nodes{{0, Sig{}}};
+   std::map<std::pair<int, Sig>, int> node_id{{nodes[0], 0}};
+   auto intern = [&](int k, Sig sg) {
+      auto key = std::make_pair(k, std::move(sg));
+      auto it = node_id.find(key);
+      if (it != node_id.end()) return it->second;
+      nodes.push_back(key);
+      node_id.emplace(std::move(key), static_cast<int>(nodes.size()) - 1);
+      return static_cast<int>(nodes.size()) - 1;
+   };
+   std::vector<std::pair<int, int>> keys;   // (r, node); r = -1: INVALID
+   std::map<std::pair<int, int>, int> ids;
+   auto state_of = [&](int q, int node) {
+      auto key = std::make_pair(q, node);
+      auto it = ids.find(key);
+      if (it != ids.end()) return it->second;
+      keys.push_back(key);
+      ids.emplace(key, static_cast<int>(keys.size()) - 1);
+      return static_cast<int>(keys.size()) - 1;
+   };
+   const int init = state_of(R.init, 0);
+   const int inv = state_of(-1, 0);
+   std::vector<int> T;
+   for (size_t s = 0; s < keys.size(); ++s) {
+      if (static_cast<int>(keys.size()) > kMaxByteStates) return r;
+      const int q = keys[s].first, nd = keys[s].second;
+      T.resize((s + 1) * 256);
+      for (int b = 0; b < 256; ++b) {
+         int dst;
+         const bool cont = b >= 0x80 && b < 0xC0, lead = b >= 0xC0 && b < 0xF8;
+         if (q < 0) dst = static_cast<int>(s);
+         else if (nd == 0) {
+            if (b < 0x80) dst = state_of(R.T(q, sig_eval(full, static_cast<uint32_t>(b))), 0);
+            else if (cont) dst = state_of(q, intern(1, sig_shrink(full, static_cast<uint32_t>(b) & 0x3Fu, 1u << 15)));
+            else dst = inv;   // a lead byte with nothing behind it, F8..FF
+         } else {
+            const int k = nodes[static_cast<size_t>(nd)].first;
+            if (cont) dst = k == 3 ? inv : state_of(q, intern(k + 1, sig_shrink(nodes[static_cast<size_t>(nd)].second, static_cast<uint32_t>(b) & 0x3Fu, 1u << (21 - 6 * (k + 1)))));
+            else if (lead) {
+               const int len = b < 0xE0 ? 2 : (b < 0xF0 ? 3 : 4);
+               const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
+               dst = len - 1 == k ? state_of(R.T(q, sig_eval(nodes[static_cast<size_t>(nd)].second, pay)), 0) : inv;
+            } else dst = inv;   // continuation bytes without their lead
+         }
+         T[s * 256 + static_cast<size_t>(b)] = dst;
+      }
+   }
+   const int n = static_cast<int>(keys.size());
+   r.d.n = n;
+   r.d.ncol = 256;
+   r.d.T = std::move(T);
+   r.d.init = init;
+   r.d.out.assign(static_cast<size_t>(n), 0);
+   std::vector<int> labels(static_cast<size_t>(n), 0);
+   for (int s = 0; s < n; ++s) {
+      const int q = keys[static_cast<size_t>(s)].first, nd = keys[static_cast<size_t>(s)].second;
+      if (q >= 0 && nd == 0) r.d.out[static_cast<size_t>(s)] = (*R.out)[static_cast<size_t>(q)];
+      labels[static_cast<size_t>(s)] = q < 0 ? 1 : 0;
+   }
+   std::vector<int> o2n;
+   minimise(r.d, -1, &labels, &o2n);
+   r.fin.assign(static_cast<size_t>(r.d.n), 0);
+   r.inv = o2n[static_cast<size_t>(inv)];
+   r.ok = true;
+   return r;
 }
 
 struct Blob {
@@ -708,6 +933,85 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       h.off_chain_cls = bl.put(cm.data(), cm.size() * 2);
       h.off_chain_TR = bl.put(ctr.data(), ctr.size() * 2);
       h.off_chain_TA = bl.put(cta.data(), cta.size() * 2);
+   }
+
+   // ---- 9. byte-level chain tables: A and R composed with the UTF-8 decoder (no decode pass on the device) ---------------------
+   // Only where the tile kernels' brute-force semantics hold for non-ASCII rows too: `.match.`, or a search without a
+   // prefilter literal (the candidate list is an INDEX over raw bytes, api_internal_m.F90:76-104).
+   {
+      std::vector<uint16_t> bcm(256, 0), btr, bta;
+      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK)) != 0 && (is_match || (brute_equiv && !prefilter));
+      if (want) {
+         Sig full;
+         for (int k = 0; k < nI; ++k) full.emplace_back(static_cast<uint32_t>(bounds[static_cast<size_t>(k)]), cls_of[static_cast<size_t>(k)]);
+         sig_normalise(full);
+         ClassDfaView va{A.n, [&](int st, int c) { return TA(st, c); }, &A.out, static_cast<int>(is_match ? h.M_start : h.A_init)};
+         std::vector<int> fin_i(fin.begin(), fin.end());
+         ByteDfa Ab = build_forward_bytes(va, full, fin_i, is_match);
+         ByteDfa Rb;
+         if (!is_match) {
+            ClassDfaView vr{R.n, [&](int st, int c) { return TR(st, c); }, &R.out, R.init};
+            Rb = build_reverse_bytes(vr, full);
+         }
+         if (Ab.ok && (is_match || Rb.ok)) {
+            // byte classes: byte values with identical columns in both automata
+            std::map<std::vector<int>, int> m;
+            std::vector<int> bcls(256), rep;
+            for (int b = 0; b < 256; ++b) {
+               std::vector<int> col;
+               for (int st = 0; st < Ab.d.n; ++st) col.push_back(Ab.d.T[static_cast<size_t>(st) * 256 + b]);
+               if (!is_match)
+                  for (int st = 0; st < Rb.d.n; ++st) col.push_back(Rb.d.T[static_cast<size_t>(st) * 256 + b]);
+               auto it = m.find(col);
+               if (it == m.end()) {
+                  it = m.emplace(col, static_cast<int>(m.size())).first;
+                  rep.push_back(b);
+               }
+               bcls[static_cast<size_t>(b)] = it->second;
+            }
+            const uint32_t nbc = static_cast<uint32_t>(m.size()), ncols = nbc + 3, row_bytes = ncols * 2;
+            const uint32_t col_skip = nbc, col_kill = nbc + 1, col_final = nbc + 2;
+            const uint64_t ta_bytes = static_cast<uint64_t>(Ab.d.n) * row_bytes, tr_bytes = is_match ? 0 : static_cast<uint64_t>(Rb.d.n) * row_bytes;
+            if (ta_bytes < 65536u && tr_bytes < 65536u && ta_bytes + tr_bytes <= 48u * 1024u) {
+               for (int b = 0; b < 256; ++b) bcm[static_cast<size_t>(b)] = static_cast<uint16_t>(2 * bcls[static_cast<size_t>(b)]);
+               bta.assign(static_cast<size_t>(Ab.d.n) * ncols, 0);
+               for (int st = 0; st < Ab.d.n; ++st) {
+                  for (uint32_t c = 0; c < nbc; ++c)
+                     bta[static_cast<size_t>(st) * ncols + c] = static_cast<uint16_t>(Ab.d.T[static_cast<size_t>(st) * 256 + rep[c]] * row_bytes);
+                  bta[static_cast<size_t>(st) * ncols + col_skip] = static_cast<uint16_t>(st * row_bytes);
+                  bta[static_cast<size_t>(st) * ncols + col_kill] = 0;
+                  bta[static_cast<size_t>(st) * ncols + col_final] = static_cast<uint16_t>(Ab.fin[static_cast<size_t>(st)]);
+               }
+               if (!is_match) {
+                  btr.assign(static_cast<size_t>(Rb.d.n) * ncols, 0);
+                  for (int st = 0; st < Rb.d.n; ++st) {
+                     for (uint32_t c = 0; c < nbc; ++c)
+                        btr[static_cast<size_t>(st) * ncols + c] = static_cast<uint16_t>(Rb.d.T[static_cast<size_t>(st) * 256 + rep[c]] * row_bytes);
+                     btr[static_cast<size_t>(st) * ncols + col_skip] = static_cast<uint16_t>(st * row_bytes);
+                     btr[static_cast<size_t>(st) * ncols + col_kill] = static_cast<uint16_t>(st * row_bytes);
+                  }
+               }
+               int accmin = Ab.d.n, hitmin = is_match ? 0 : Rb.d.n;
+               for (int st = Ab.d.n - 1; st >= 0 && Ab.d.out[static_cast<size_t>(st)]; --st) accmin = st;
+               if (!is_match)
+                  for (int st = Rb.d.n - 1; st >= 0 && Rb.d.out[static_cast<size_t>(st)]; --st) hitmin = st;
+               h.flags |= FXP_F_BYTE_DFA;
+               h.byte_n_classes = nbc;
+               h.byte_row_bytes = row_bytes;
+               h.byte_A_init = static_cast<uint32_t>(Ab.d.init) * row_bytes;
+               h.byte_R_start = is_match ? 0u : static_cast<uint32_t>(Rb.d.init) * row_bytes;
+               h.byte_acc_min = static_cast<uint32_t>(accmin) * row_bytes;
+               h.byte_hit_min = static_cast<uint32_t>(hitmin) * row_bytes;
+               h.byte_TA_bytes = static_cast<uint32_t>(bta.size() * 2);
+               h.byte_TR_bytes = static_cast<uint32_t>(btr.size() * 2);
+               h.byte_inv_A = Ab.inv >= 0 ? static_cast<uint32_t>(Ab.inv) * row_bytes : 0u;
+               h.byte_inv_R = is_match ? 0u : static_cast<uint32_t>(Rb.inv) * row_bytes;
+            }
+         }
+      }
+      h.off_byte_cls = bl.put(bcm.data(), bcm.size() * 2);
+      h.off_byte_TR = bl.put(btr.data(), btr.size() * 2);
+      h.off_byte_TA = bl.put(bta.data(), bta.size() * 2);
    }
    return finish(h, bl);
 }

@@ -13,6 +13,8 @@
 //                        rows the fast kernel flags as non-ASCII.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -44,13 +46,14 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
 #endif
 template <int CH>
-__device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane) {
+__device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, bool enable = true) {
    // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH.  row0 is wave-uniform:
    // the tile is addressed through a buffer resource whose base is the tile and whose extent is the tile's valid bytes, so
    // each piece is ONE buffer_load_dwordx4 (scalar base, lane offset, immediate piece offset) and the pieces of rows >= n
    // come back as zero from the hardware range check instead of per-piece predication.
    const int64_t rows_left = n - row0;
-   const uint32_t valid = rows_left >= 64 ? 64u * 16u * CH : (rows_left > 0 ? (uint32_t)rows_left * 16u * CH : 0u);
+   // enable == false (wave-uniform): a tile this pass skips -- zero valid bytes, the loads are issued and range-checked away
+   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * 16u * CH : (rows_left > 0 ? (uint32_t)rows_left * 16u * CH : 0u));
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)(16 * CH);
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
@@ -139,8 +142,10 @@ __device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, ui
 // copies of the automaton and `state >= hit_min` can compare whole registers without masking
 struct FastParams {
    uint32_t R_start, A_init, hit_min, acc_min;
-   uint2 H;   // (unused)
-   uint32_t lit_len;   // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
+   uint32_t inv;            // BYTES modes: the INVALID state (structurally invalid UTF-8): the row is left to the decode path
+   uint32_t defer_tiles;    // first pass: tiles holding a byte >= 0x80 are deferred whole (a later pass handles them)
+   uint32_t gate_word;      // marked-tile passes: which of the call's two words says whether there is anything to do
+   uint32_t lit_len;        // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
 };
 
 // 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
@@ -266,29 +271,42 @@ __device__ unsigned long long fx_stamp_acc[16];
    } while (0)
 // prefetch of a tile that may lie behind the last one: the aligned loader needs no guard (zero valid bytes -> every piece is
 // range-checked away), and an unguarded load keeps the staging registers free of control-flow merges
-#define PREFETCH_TILE(st, tn)                                          \
+#define PREFETCH_TILE(st, tn, en)                                      \
    do {                                                                \
-      if (!RAGGED) load_tile<CH>(st, rows, (tn) << 6, n, lane);        \
-      else if ((tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
+      if (!RAGGED) load_tile<CH>(st, rows, (tn) << 6, n, lane, (en));  \
+      else if ((en) && (tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
    } while (0)
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
 //                 the offending rows are marked individually for the general kernel's fix-up.
 // FIXUP = true:  second pass: only marked tiles are loaded, decoded from UTF-8 to symbol ids in LDS, then scanned.
-template <int CH, bool SPANS, bool FIXUP, bool CHAIN, bool RAGGED>
+// MODE 0: first pass (class-level tables), as above.            MODE 1: the decode second pass (FIXUP), marked tiles only.
+// MODE 2: byte-level tables (FXP_F_BYTE_DFA) over ALL tiles: raw bytes are the symbols, nothing is decoded or deferred; rows
+//         whose backward pass ends in the INVALID state keep FX_NEEDS_GENERAL for the row-level fix-up (fx_fixup).
+// MODE 3: the same over the tiles a MODE 0 pass deferred.
+// MODE 4: the decode pass over a WORKLIST of row indices (the exception rows a BYTES pass appended): each lane gathers its own
+//         row into its LDS cells, results are scattered back to the rows' own slots.
+// n_deferred points at this call's two words: [0] "a first pass deferred tiles", [1] number of exception rows in `worklist`.
+template <int CH, bool SPANS, int MODE, bool CHAIN, bool RAGGED>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
-                                                        uint32_t Lr, uint32_t* __restrict__ clear_next) {
+                                                        uint32_t Lr, uint32_t* __restrict__ clear_next, uint32_t* __restrict__ worklist) {
    // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
    // instantiation keeps the row length a compile-time constant (the hot path).
    const uint32_t L = RAGGED ? Lr : 16u * CH;
    constexpr bool ragged = RAGGED;
-   if (FIXUP && *n_deferred == 0) return;   // the first pass deferred nothing: pure-ASCII batch
+   constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
+   static_assert(!BYTES || (CHAIN && !RAGGED), "byte-level tables use the chain scheme on whole chunks");
+   static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
+   if ((MARKED || LIST) && n_deferred[fp.gate_word] == 0) return;   // nothing was left for this pass
    // the "something was deferred" words of consecutive calls alternate: this call's first pass zeroes the NEXT call's word (no
    // memset node per call; nobody reads that word before the next call's second pass)
-   if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;
+   if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
+      clear_next[0] = 0u;
+      clear_next[1] = 0u;
+   }
    using F = typename FxF<CHAIN>::type;
    __shared__ uint2 permR[CHAIN ? 1 : 256];
    __shared__ uint2 permA[CHAIN ? 1 : 256];
@@ -296,14 +314,15 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
    uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * (CH + 1));
-   const uint32_t chain_bytes = CHAIN ? ((512u + h->chain_TR_bytes + h->chain_TA_bytes + 15u) & ~15u) : 0u;
+   const uint32_t tr_bytes = BYTES ? h->byte_TR_bytes : h->chain_TR_bytes, ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
+   const uint32_t chain_bytes = CHAIN ? ((512u + tr_bytes + ta_bytes + 15u) & ~15u) : 0u;
    const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cmap) + 512;
-   const uint8_t* TAp = TRp + (CHAIN ? h->chain_TR_bytes : 0u);
+   const uint8_t* TAp = TRp + (CHAIN ? tr_bytes : 0u);
    if (CHAIN) {
-      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_chain_cls);
-      const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TR);
-      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TA);
-      const uint32_t nr = h->chain_TR_bytes / 2, na = h->chain_TA_bytes / 2;
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_cls : h->off_chain_cls));
+      const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TR : h->off_chain_TR));
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
+      const uint32_t nr = tr_bytes / 2, na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else {
       const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
@@ -318,8 +337,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permR);
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
-   const bool raw = (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search: bytes are symbols, nothing is decoded or deferred
-   const bool utf8 = !raw && (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
+   const bool raw = BYTES || (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search, byte-level tables: bytes are symbols, nothing is decoded or deferred
+   const bool utf8 = !raw && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
    // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
@@ -346,30 +365,48 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    STAMP_DECL;
    // One tile: `stage` holds its global loads (issued DEPTH tiles ago); once they are stored to LDS the same registers take the
    // loads of tile t_next, which stay in flight while this and the following DEPTH-1 tiles are scanned.
-   auto do_tile = [&](uint4 (&stage)[CH], const int64_t t, const int64_t t_next) {
+   // marked-tile passes: does tile t hold a row the pass before left behind (FX_NEEDS_GENERAL)?  wave-uniform
+   auto tile_marked = [&](const int64_t t) -> bool {
+      const int64_t rr = (t << 6) + lane;
+      return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
+   };
+   const uint32_t list_count = LIST ? n_deferred[1] : 0u;
+   // `live`: the tile in `stage` is to be scanned (always, except in the marked-tile passes); on return it says so for t_next
+   auto do_tile = [&](uint4 (&stage)[CH], bool& live, const int64_t t, const int64_t t_next) {
       const int64_t row0 = t << 6;
       STAMP(7);
-      if (FIXUP) {
-         const int64_t rr = row0 + lane;
-         const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
-         if (__builtin_amdgcn_ballot_w64(marked) == 0) return;   // wave-uniform: nothing deferred in this tile
-         LOAD_TILE(stage, row0);
-      }
-      // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
-      // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
+      int64_t row = row0 + lane;   // the row this lane owns and whether it exists
+      bool row_ok = row < n;
       bool defer_early = false;
-      if (!FIXUP && utf8) {
-         const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
-         defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+      if (LIST) {
+         // worklist pass: lane r gathers row worklist[64 t + r] straight into its own cells (one row per lane: nothing to transpose)
+         const uint32_t slot = (uint32_t)row0 + lane;
+         row_ok = slot < list_count;
+         row = row_ok ? (int64_t)worklist[slot] : 0;
+         const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+#pragma unroll
+         for (int k = 0; k < CH; ++k) stage[k] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+         for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = stage[k];
+      } else {
+         const bool process = live;
+         // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
+         // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
+         if (MODE == 0 && utf8) {
+            const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+            defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+         }
+         if (process) store_tile<CH>(stage, tile, lane);
+         STAMP(0);
+         // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
+         // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
+         // loop's back edge: copies behind a vmcnt(0)).  A tile the pass skips is "loaded" with zero valid bytes.
+         live = MARKED ? tile_marked(t_next) : true;
+         PREFETCH_TILE(stage, t_next, live);
+         if (!process) return;
       }
-      store_tile<CH>(stage, tile, lane);
-      STAMP(0);
-      // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
-      // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
-      // loop's back edge: copies behind a vmcnt(0))
-      if (!FIXUP) PREFETCH_TILE(stage, t_next);
       if (defer_early) {
-         if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
+         if (row_ok) flags[row] = FX_NEEDS_GENERAL;
          any_deferred = true;
          return;
       }
@@ -469,10 +506,21 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
       // TILE is deferred to the second pass (wave-uniform; the raw-byte scan above is discarded and the
       // forward walk below is skipped).
-      const bool row_hi = !FIXUP && !raw && (na & 0x80808080u) != 0;
-      const bool defer_tile = !FIXUP && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
-      const bool nonascii = (row_hi && !utf8) || defer_tile;
-      const int64_t row = row0 + lane;
+      const bool row_hi = MODE == 0 && !raw && (na & 0x80808080u) != 0;
+      const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
+      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8, the row-level fix-up redoes it
+      const bool exception = BYTES && state == fp.inv;
+      const bool nonascii = (row_hi && !utf8) || defer_tile || exception;
+      if (BYTES) {
+         // exception rows are appended to the worklist of the decode pass: one atomic per tile that has any
+         const uint64_t em = __builtin_amdgcn_ballot_w64(exception && row_ok);
+         if (em != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (exception && row_ok) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+         }
+      }
 
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
       // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk.
@@ -560,7 +608,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       }
       if (nonascii) flag = FX_NEEDS_GENERAL;
       any_deferred = any_deferred || defer_tile;
-      if (row < n) {
+      if (row_ok) {
          flags[row] = (uint8_t)flag;
          if (SPANS) {
             from[row] = fr;
@@ -568,16 +616,21 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          }
       }
    };
-   if (FIXUP) {
+   if (LIST) {
       uint4 stage[CH];
-      for (int64_t t = wave_global; t < n_tiles; t += wave_stride) do_tile(stage, t, n_tiles);
+      bool live = true;
+      for (int64_t t = wave_global; (uint64_t)(t << 6) < list_count; t += wave_stride) do_tile(stage, live, t, t);
    } else {
-      // first pass: DEPTH tiles of global loads in flight per wave (HBM latency under load is several microseconds: one tile
-      // ahead leaves the wave waiting for its data for a quarter of its time)
+      // DEPTH tiles of global loads in flight per wave (HBM latency under load is several microseconds).  The marked-tile passes
+      // run the same pipeline: a tile they skip costs one read of its flags and 16 loads that are range-checked away.
       constexpr int DEPTH = FX_PREFETCH_DEPTH;
       uint4 stage[DEPTH][CH];
+      bool live[DEPTH];
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) PREFETCH_TILE(stage[d], wave_global + d * wave_stride);
+      for (int d = 0; d < DEPTH; ++d) {
+         live[d] = MARKED ? tile_marked(wave_global + d * wave_stride) : true;
+         PREFETCH_TILE(stage[d], wave_global + d * wave_stride, live[d]);
+      }
       for (int64_t t = wave_global;;) {   // (leaving the loop from the middle keeps the staging registers free of merges)
          bool done = false;
 #pragma unroll
@@ -586,7 +639,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
                done = true;
                continue;
             }
-            do_tile(stage[d], t, t + DEPTH * wave_stride);
+            do_tile(stage[d], live[d], t, t + DEPTH * wave_stride);
             t += wave_stride;
          }
          if (done) break;
@@ -595,7 +648,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    STAMP(6);
    STAMP_FLUSH;
    // one plain store per wave (not an atomic per tile: 16k same-address atomics cost ~0.2 ms); the value only gates the second pass
-   if (!FIXUP && any_deferred && lane == 0) *n_deferred = 1u;
+   if (MODE == 0 && any_deferred && lane == 0) n_deferred[0] = 1u;
 }
 
 // =========================================================================================================
@@ -611,48 +664,41 @@ __device__ __forceinline__ void chain8_fwd(const F (&f)[8], uint32_t& state, con
    for (int i = 0; i < 8; ++i) state = fxstep(f[i], state, T);
 }
 
-// 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides
+// 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides (fxrow::match_gate on the row's bytes in the LDS tile)
 __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t* __restrict__ prog, const uint8_t* tb, uint32_t lane, uint32_t L) {
-   const uint32_t lp = h->len_prefix, ls = h->len_suffix, la = h->len_all;
    auto row = [&](uint32_t j) -> uint32_t { return tb[(tile_cell(lane, j >> 4) << 4) + (j & 15u)]; };
-   if ((h->flags & FXP_F_MATCH_LITERAL) && L == la) {
-      bool eq = true;
-      for (uint32_t k = 0; k < la; ++k) eq = eq && row(k) == prog[h->off_all + k];
-      return eq ? 2u : 0u;
-   }
-   if (lp > 0 && lp == L) {
-      bool eq = true;
-      for (uint32_t k = 0; k < lp; ++k) eq = eq && row(k) == prog[h->off_prefix + k];
-      if (eq) return 2u;
-   }
-   if (lp > L || ls > L) return 0u;
-   bool ok = true;
-   if (h->flags & FXP_F_PREFILTER)
-      for (uint32_t k = 0; k < lp; ++k) ok = ok && row(k) == prog[h->off_prefix + k];
-   if (h->flags & FXP_F_HAS_SUFFIX)
-      for (uint32_t k = 0; k < ls; ++k) ok = ok && row(L - ls + k) == prog[h->off_suffix + k];
-   return ok ? 1u : 0u;
+   return fxrow::match_gate(h, prog, row, L);
 }
 
-template <int CH, bool FIXUP, bool CHAIN, bool RAGGED>
+// MODE as in fx_search_fast (BYTES modes: a row whose walk ends inside a character or in the INVALID state -- FINAL column 2 -- is
+// left to the row-level fix-up)
+template <int CH, int MODE, bool CHAIN, bool RAGGED>
 __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
-                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next) {
+                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
+                                                       uint32_t* __restrict__ worklist) {
    const uint32_t L = RAGGED ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
    constexpr bool ragged = RAGGED;
-   if (FIXUP && *n_deferred == 0) return;
-   if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;
+   constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
+   static_assert(!BYTES || (CHAIN && !RAGGED), "byte-level tables use the chain scheme on whole chunks");
+   static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
+   if ((MARKED || LIST) && n_deferred[fp.gate_word] == 0) return;
+   if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
+      clear_next[0] = 0u;
+      clear_next[1] = 0u;
+   }
    using F = typename FxF<CHAIN>::type;
    __shared__ uint2 permA[CHAIN ? 1 : 256];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
-   const uint32_t chain_bytes = CHAIN ? ((512u + h->chain_TA_bytes + 15u) & ~15u) : 0u;
+   const uint32_t ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
+   const uint32_t chain_bytes = CHAIN ? ((512u + ta_bytes + 15u) & ~15u) : 0u;
    const uint8_t* TAp = reinterpret_cast<const uint8_t*>(cmap) + 512;
    if (CHAIN) {
-      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_chain_cls);
-      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TA);
-      const uint32_t na = h->chain_TA_bytes / 2;
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_cls : h->off_chain_cls));
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
+      const uint32_t na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + na; i += 256u) cmap[i] = i < 256u ? g[i] : ga[i - 256u];
    } else {
       permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
@@ -661,7 +707,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-   const bool utf8 = (h->flags & (CHAIN ? FXP_F_CHAIN_UTF8 : FXP_F_FAST_UTF8)) != 0;
+   const bool utf8 = !BYTES && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
    if (FIXUP && class_map_in_lds) {
@@ -680,25 +726,45 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    bool any_deferred = false;
+   auto tile_marked = [&](const int64_t t) -> bool {
+      const int64_t rr = (t << 6) + lane;
+      return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
+   };
+   const uint32_t list_count = LIST ? n_deferred[1] : 0u;
    uint4 stage[CH];
-   if (!FIXUP) PREFETCH_TILE(stage, wave_global);
-   for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
+   bool live = true;   // the tile in `stage` is to be scanned (always, except in the marked-tile passes)
+   if (!LIST) {
+      live = MARKED ? tile_marked(wave_global) : true;
+      PREFETCH_TILE(stage, wave_global, live);
+   }
+   for (int64_t t = wave_global; LIST ? (uint64_t)(t << 6) < list_count : t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
-      if (FIXUP) {
-         const int64_t rr = row0 + lane;
-         const bool marked = rr < n && flags[rr] == FX_NEEDS_GENERAL;
-         if (__builtin_amdgcn_ballot_w64(marked) == 0) continue;
-         LOAD_TILE(stage, row0);
-      }
+      int64_t row = row0 + lane;   // the row this lane owns and whether it exists
+      bool row_ok = row < n;
       bool defer_early = false;
-      if (!FIXUP && utf8) {
-         const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
-         defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+      if (LIST) {
+         // worklist pass: lane r gathers row worklist[64 t + r] straight into its own cells
+         const uint32_t slot = (uint32_t)row0 + lane;
+         row_ok = slot < list_count;
+         row = row_ok ? (int64_t)worklist[slot] : 0;
+         const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+#pragma unroll
+         for (int k = 0; k < CH; ++k) stage[k] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+         for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = stage[k];
+      } else {
+         const bool process = live;
+         if (MODE == 0 && utf8) {
+            const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+            defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+         }
+         if (process) store_tile<CH>(stage, tile, lane);
+         live = MARKED ? tile_marked(t + wave_stride) : true;
+         PREFETCH_TILE(stage, t + wave_stride, live);   // the one reload site of the staging registers
+         if (!process) continue;
       }
-      store_tile<CH>(stage, tile, lane);
-      if (!FIXUP) PREFETCH_TILE(stage, t + wave_stride);   // the one reload site of the staging registers
       if (defer_early) {
-         if (row0 + lane < n) flags[row0 + lane] = FX_NEEDS_GENERAL;
+         if (row_ok) flags[row] = FX_NEEDS_GENERAL;
          any_deferred = true;
          continue;
       }
@@ -739,17 +805,26 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          __builtin_amdgcn_sched_barrier(0);
       }
       uint32_t fin;
-      if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * (h->n_classes + 2u));   // FINAL column
+      if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * ((BYTES ? h->byte_n_classes : h->n_classes) + 2u));   // FINAL column
       else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
-      uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin != 0 ? 1u : 0u));
-      const bool row_hi = !FIXUP && (na & 0x80808080u) != 0;
-      const bool defer_tile = !FIXUP && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
-      if ((row_hi && !utf8) || defer_tile) flag = FX_NEEDS_GENERAL;
+      uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin == 1u ? 1u : 0u));
+      const bool row_hi = MODE == 0 && (na & 0x80808080u) != 0;
+      const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
+      const bool exception = BYTES && gate == 1u && st != 0 && fin == 2u;   // inside a character / INVALID at the end of the row
+      if (BYTES) {   // exception rows are appended to the worklist of the decode pass
+         const uint64_t em = __builtin_amdgcn_ballot_w64(exception && row_ok);
+         if (em != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (exception && row_ok) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+         }
+      }
+      if ((row_hi && !utf8) || defer_tile || exception) flag = FX_NEEDS_GENERAL;
       any_deferred = any_deferred || defer_tile;
-      const int64_t row = row0 + lane;
-      if (row < n) flags[row] = (uint8_t)flag;
+      if (row_ok) flags[row] = (uint8_t)flag;
    }
-   if (!FIXUP && any_deferred && lane == 0) *n_deferred = 1u;
+   if (MODE == 0 && any_deferred && lane == 0) n_deferred[0] = 1u;
 }
 
 // =========================================================================================================
@@ -804,7 +879,9 @@ __global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ ro
 // Fix-up pass after the fast kernel: every thread inspects 16 flags with one 16-byte load and only rows marked
 // FX_NEEDS_GENERAL (bytes >= 0x80: on-device UTF-8 decode needed) are re-matched, with the tables read from global memory.
 __global__ __launch_bounds__(256) void fx_fixup(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
-                                                 uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to) {
+                                                 uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
+                                                 const uint32_t* __restrict__ gate) {
+   if (gate && *gate == 0) return;   // the pass before left no row behind
    const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
    if (base >= n) return;
    uint32_t marks = 0;
@@ -900,6 +977,8 @@ struct fxamd_program {
    uint32_t* d_counter = nullptr;   // two words used by alternate calls: set by a first fast pass that deferred a (non-ASCII) tile; each
                                     // first pass zeroes the other word for the call after it
    uint32_t parity = 0;             // which word the next call uses
+   uint32_t* d_worklist = nullptr;  // row indices a byte-level pass left to the decode pass (structurally invalid UTF-8); grown on demand
+   int64_t worklist_rows = 0;
    uint32_t* d_nfa_scratch = nullptr;   // bitset scratch of the NFA-simulation kernel (FXP_F_NFA_SIM programs)
    size_t nfa_scratch_rows = 0;
    int last_path = 0;
@@ -923,73 +1002,108 @@ static int tile_chunks(int64_t row_len) {
       if (row_len <= 16 * c) return c;
    return 0;
 }
-template <int CH, bool FIXUP, bool CHAIN>
+// MODE: 0 first pass, 1 decode second pass, 2 byte-level tables over all tiles, 3 byte-level tables over marked tiles
+// n_deferred: this call's two words ([0] tiles deferred, [1] exception rows left); the other call parity's pair is 8 bytes away
+template <int CH, int MODE, bool CHAIN>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
-                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st) {
-   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 4u);   // the pair's other word (8-byte aligned pair)
-   const int64_t n_tiles = (n + 63) >> 6;
+                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);   // the other parity's pair (16-byte aligned block)
+   const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;   // (worklist pass: the host only knows an upper bound)
    int64_t blocks = (n_tiles + 3) / 4;
-   const int64_t cap = 256 * 8;   // grid-stride beyond this (guide §6 G11)
+   const int64_t cap = MODE == 4 ? 256 : 256 * 8;   // grid-stride beyond this (guide §6 G11)
    if (blocks > cap) blocks = cap;
-   // second pass: the BMP class map rides behind the tiles when it fits
-   const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   // decode passes: the BMP class map rides behind the tiles when it fits
+   const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
-   const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN, true>)
-                                    : reinterpret_cast<const void*>(&fx_search_fast<CH, false, FIXUP, CHAIN, true>))
-                           : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, FIXUP, CHAIN, false>)
-                                    : reinterpret_cast<const void*>(&fx_search_fast<CH, false, FIXUP, CHAIN, false>));
-   if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-   }
-   if (ragged) {
-      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
-      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
+   if constexpr (MODE >= 2) {   // whole-chunk rows only: byte-level tables (2, 3: chain scheme) and the worklist decode pass (4)
+      constexpr bool CHN = MODE == 4 ? CHAIN : true;
+      if (ragged) return hipErrorInvalidValue;   // (never dispatched)
+      const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false>)
+                             : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false>);
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      return hipGetLastError();
    } else {
-      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
-      else hipLaunchKernelGGL((fx_search_fast<CH, false, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next);
+      const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHAIN, true>)
+                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHAIN, true>))
+                              : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHAIN, false>)
+                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHAIN, false>));
+      if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      if (ragged) {
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      } else {
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      }
+      return hipGetLastError();
    }
-   return hipGetLastError();
 }
 
-template <int CH, bool FIXUP, bool CHAIN>
+template <int CH, int MODE, bool CHAIN>
 static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
-                               uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st) {
-   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 4u);
-   const int64_t n_tiles = (n + 63) >> 6;
+                               uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);
+   const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
-   if (blocks > 256 * 8) blocks = 256 * 8;
-   const uint32_t map_lds = (FIXUP && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   if (blocks > (MODE == 4 ? 256 : 256 * 8)) blocks = MODE == 4 ? 256 : 256 * 8;
+   const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
-   if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, FIXUP, CHAIN, true>)
-                                                : reinterpret_cast<const void*>(&fx_match_fast<CH, FIXUP, CHAIN, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
+   if constexpr (MODE >= 2) {
+      constexpr bool CHN = MODE == 4 ? CHAIN : true;
+      if (ragged) return hipErrorInvalidValue;
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      return hipGetLastError();
+   } else {
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHAIN, true>)
+                                                   : reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHAIN, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      else hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      return hipGetLastError();
    }
-   if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next);
-   else hipLaunchKernelGGL((fx_match_fast<CH, FIXUP, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next);
-   return hipGetLastError();
 }
 
-template <bool FIXUP, bool CHAIN>
+// what a pass needs to know beyond the tables: deferral policy of a first pass, gate word of a marked-tile pass
+struct PassOpts {
+   uint32_t defer_tiles = 0, gate_word = 0;
+   uint32_t* worklist = nullptr;   // BYTES passes append exception rows, the worklist decode pass (MODE 4) reads them
+   int64_t grid_tiles = 0;         // MODE 4: upper bound of the worklist's tiles (the count itself lives on the device)
+};
+
+template <int MODE, bool CHAIN>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
-                                   uint8_t* d_flags, uint32_t* n_deferred, hipStream_t st) {
+                                   uint8_t* d_flags, uint32_t* n_deferred, hipStream_t st, PassOpts po = PassOpts()) {
+   constexpr bool BYTES = MODE == 2 || MODE == 3;
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
-   const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TA_bytes + 15u) & ~15u) : 0u;
-   FastParams fp{0, CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u, 0, 0, make_uint2(0, 0), 0};
+   const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
+   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, po.defer_tiles, po.gate_word, 0};
    switch (tile_chunks(row_len)) {
-      case 1: return launch_match<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 2: return launch_match<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 3: return launch_match<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 4: return launch_match<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 6: return launch_match<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 8: return launch_match<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 12: return launch_match<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      default: return launch_match<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 1: return launch_match<1, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 2: return launch_match<2, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 3: return launch_match<3, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 4: return launch_match<4, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 6: return launch_match<6, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 8: return launch_match<8, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 12: return launch_match<12, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      default: return launch_match<16, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
    }
 }
 
@@ -1009,29 +1123,42 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    }
    return 0;
 }
+// byte-level tables usable for these rows: whole chunks only (no inert pad byte exists: every byte value means something)
+static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+   if (std::getenv("FXAMD_NO_BYTE_DFA")) return false;   // test hook: exercise the decode pass instead
+   if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || row_len != 16 * tile_chunks(row_len)) return false;
+   return (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
+}
 
-template <bool FIXUP, bool CHAIN>
+template <int MODE, bool CHAIN>
 static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
-                                  uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st) {
+                                  uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st, PassOpts po = PassOpts()) {
+   constexpr bool BYTES = MODE == 2 || MODE == 3;
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
-   const uint32_t chain_bytes = CHAIN ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u;
+   const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TR_bytes + h.byte_TA_bytes : h.chain_TR_bytes + h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 make_uint2(0, 0), h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
-   if (CHAIN) {   // states are row byte offsets, compared as plain integers
+                 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
+   if (BYTES) {
+      fp.R_start = h.byte_R_start;
+      fp.A_init = h.byte_A_init;
+      fp.hit_min = h.byte_hit_min;
+      fp.acc_min = h.byte_acc_min;
+      fp.inv = h.byte_inv_R;
+   } else if (CHAIN) {   // states are row byte offsets, compared as plain integers
       fp.R_start = h.chain_R_start;
       fp.A_init = h.chain_A_init;
       fp.hit_min = h.chain_hit_min;
       fp.acc_min = h.chain_acc_min;
    }
    switch (tile_chunks(row_len)) {
-      case 1: return launch_fast<1, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 2: return launch_fast<2, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 3: return launch_fast<3, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 4: return launch_fast<4, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 6: return launch_fast<6, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 8: return launch_fast<8, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      case 12: return launch_fast<12, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
-      default: return launch_fast<16, FIXUP, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st);
+      case 1: return launch_fast<1, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 2: return launch_fast<2, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 3: return launch_fast<3, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 4: return launch_fast<4, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 6: return launch_fast<6, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 8: return launch_fast<8, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 12: return launch_fast<12, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      default: return launch_fast<16, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
    }
 }
 
@@ -1098,6 +1225,7 @@ void fxamd_program_free(fxamd_program* p) {
    if (!p) return;
    if (p->d_blob) (void)hipFree(p->d_blob);
    if (p->d_counter) (void)hipFree(p->d_counter);
+   if (p->d_worklist) (void)hipFree(p->d_worklist);
    if (p->d_nfa_scratch) (void)hipFree(p->d_nfa_scratch);
    delete p;
 }
@@ -1170,9 +1298,14 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (scheme == 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
-   uint32_t* ctr = p->d_counter + (p->parity ^= 1u);
-   if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream)));
-   else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream)));
+   uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);
+   PassOpts po;
+   po.defer_tiles = ((h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0 || bytes_ok(h, d_rows, row_len)) ? 1u : 0u;
+   if (scheme == 2 && bytes_ok(h, d_rows, row_len) && p->worklist_rows >= n) {
+      po.worklist = p->d_worklist;
+      FX_HIP((launch_fast_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
+   } else if (scheme == 1) FX_HIP((launch_fast_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
+   else FX_HIP((launch_fast_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
    return FXAMD_OK;
 }
 
@@ -1226,51 +1359,84 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       d_to = nullptr;
    }
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme != 0 && h.mode == FXP_MODE_MATCH_ENGINE) {
-      uint32_t* ctr = p->d_counter + (p->parity ^= 1u);
-      if (scheme == 1) FX_HIP((launch_match_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
-      else FX_HIP((launch_match_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
-      if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
-         if (scheme == 1) FX_HIP((launch_match_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
-         else FX_HIP((launch_match_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st)));
-         p->last_path = scheme == 1 ? 1 : 5;
-         return FXAMD_OK;
-      }
-      if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
-         const unsigned fblocks = (unsigned)((n + 4095) / 4096);
-         hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to);
-      } else {
-         hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
-      }
-      FX_HIP(hipGetLastError());
-      p->last_path = scheme == 1 ? 3 : 6;
-      return FXAMD_OK;
-   }
    if (scheme != 0) {
-      uint32_t* ctr = p->d_counter + (p->parity ^= 1u);
-      if (scheme == 1) FX_HIP((launch_fast_any<false, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
-      else FX_HIP((launch_fast_any<false, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
-      if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing was deferred
+      const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
+      uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);   // this call's words: [0] tiles deferred, [1] exception rows left
+      const bool utf8_tables = (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0;
+      const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
+      // row-level fix-up through the general engine: rows still marked FX_NEEDS_GENERAL (gate: skip when the word says none are)
+      auto fixup_rows = [&](const uint32_t* gate) -> int {
+         if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
+            const unsigned fblocks = (unsigned)((n + 4095) / 4096);
+            hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, gate);
+         } else {
+            hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
+         }
+         FX_HIP(hipGetLastError());
+         return FXAMD_OK;
+      };
+      PassOpts first, marked, listp;
+      first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
+      if (bytes) {   // worklist of the rows the byte-level tables cannot answer (structurally invalid UTF-8)
+         std::lock_guard<std::mutex> g(p->mu);
+         if (p->worklist_rows < n) {
+            if (p->d_worklist) (void)hipFree(p->d_worklist);
+            p->d_worklist = nullptr;
+            p->worklist_rows = 0;
+            FX_HIP(hipMalloc((void**)&p->d_worklist, (size_t)n * 4));
+            p->worklist_rows = n;
+         }
+         first.worklist = marked.worklist = listp.worklist = p->d_worklist;
+         listp.gate_word = 1;
+         listp.grid_tiles = (n + 63) >> 6;
+      }
+      // exception rows of a byte-level pass: the decode pass over the gathered worklist when the class-level tables can decode,
+      // else the row-level fix-up through the general engine
+      auto exceptions = [&]() -> int {
+         if (!utf8_tables) return fixup_rows(ctr + 1);
+         if (is_match) FX_HIP(scheme == 1 ? (launch_match_any<4, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp))
+                                          : (launch_match_any<4, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp)));
+         else FX_HIP(scheme == 1 ? (launch_fast_any<4, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp))
+                                 : (launch_fast_any<4, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp)));
+         return FXAMD_OK;
+      };
+      if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
+         FX_HIP(scheme == 1 ? (launch_fast_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first))
+                            : (launch_fast_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first)));
          p->last_path = scheme == 1 ? 1 : 5;
          return FXAMD_OK;
       }
-      if (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) {
-         // tiles holding bytes >= 0x80 were deferred: the second pass decodes UTF-8 in LDS and scans only those tiles
-         if (scheme == 1) FX_HIP((launch_fast_any<true, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
-         else FX_HIP((launch_fast_any<true, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st)));
+      if (bytes && scheme == 2) {
+         // the class-level scheme is the chain scheme anyway: the byte-level tables take every tile, UTF-8 or not, in one pass
+         if (is_match) FX_HIP((launch_match_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first)));
+         else FX_HIP((launch_fast_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first)));
+         p->last_path = 7;
+         return exceptions();
+      }
+      // first pass with the class-level tables: pure-ASCII tiles are finished here
+      if (is_match) FX_HIP(scheme == 1 ? (launch_match_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first))
+                                       : (launch_match_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first)));
+      else FX_HIP(scheme == 1 ? (launch_fast_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first))
+                              : (launch_fast_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first)));
+      if (bytes) {
+         // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
+         if (is_match) FX_HIP((launch_match_any<3, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked)));
+         else FX_HIP((launch_fast_any<3, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked)));
+         p->last_path = 8;
+         return exceptions();
+      }
+      if (utf8_tables) {
+         // deferred tiles: the decode pass rewrites UTF-8 to symbol ids in LDS and scans only those tiles
+         if (is_match) FX_HIP(scheme == 1 ? (launch_match_any<1, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked))
+                                          : (launch_match_any<1, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked)));
+         else FX_HIP(scheme == 1 ? (launch_fast_any<1, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked))
+                                 : (launch_fast_any<1, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked)));
          p->last_path = scheme == 1 ? 1 : 5;
          return FXAMD_OK;
       }
-      // fix-up pass for rows holding bytes >= 0x80 (general kernel's decode path); a cheap read of the flags otherwise
-      if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
-         const unsigned fblocks = (unsigned)((n + 4095) / 4096);
-         hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to);
-      } else {
-         hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
-      }
-      FX_HIP(hipGetLastError());
+      // rows holding bytes >= 0x80 were marked one by one: row-level fix-up (a cheap read of the flags otherwise)
       p->last_path = scheme == 1 ? 3 : 6;
-      return FXAMD_OK;
+      return fixup_rows(nullptr);
    }
    if (aligned16 && row_len <= 1024) {
       const unsigned tblocks = (unsigned)((n + 63) / 64);

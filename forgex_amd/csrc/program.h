@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 8u
+#define FXP_VERSION 9u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -34,6 +34,7 @@ enum FxpFlags {
    FXP_F_NFA_SIM = 1u << 7,
    FXP_F_CHAIN_OK = 1u << 8,        // class-indexed LDS chain tables present (automata too large for the v_perm tables)
    FXP_F_CHAIN_UTF8 = 1u << 9,
+   FXP_F_BYTE_DFA = 1u << 12,       // byte-level chain tables present (UTF-8 composed into the automata)
    FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it
    FXP_F_RAW_BYTES = 1u << 10,      // literal INDEX search: symbols are raw bytes (no UTF-8 decode, no deferral), hit = occurrence start      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
 };
@@ -76,7 +77,17 @@ struct FxpHeader {
    uint32_t off_chain_TR;     // uint16 [nR][n_classes + 3]
    uint32_t off_chain_TA;     // uint16 [nA][n_classes + 3]   row 0 = dead
    uint32_t fast_finalM[2];   // v_perm scheme, `.match.`: byte q = 1 when state q gives a true verdict after the last text byte
-   uint32_t reserved[3];
+   // ---- byte-level chain tables (FXP_F_BYTE_DFA): A and R composed with the UTF-8 decoder (reference utf8_m.f90:338-430
+   //      `ichar_utf8`: arithmetic decode of every structurally valid sequence), so the tile kernels walk RAW bytes -- no
+   //      decode pass.  Same row layout as the class-level chain tables with byte classes as columns.  A structurally invalid
+   //      byte sequence (utf8_m.f90:168-246) leads to the absorbing state `byte_inv_*`; such rows (and `.match.` rows ending
+   //      inside a character: FINAL column = 2) are redone by the decode pass, which treats every invalid byte as U+FFFF. ----
+   uint32_t byte_n_classes, byte_row_bytes, byte_R_start, byte_A_init, byte_hit_min, byte_acc_min, byte_TR_bytes, byte_TA_bytes;
+   uint32_t byte_inv_R, byte_inv_A;   // row offsets of the INVALID states (A: `.match.` programs only, else 0 = dead)
+   uint32_t off_byte_cls;    // uint16 [256]   2 * column of each byte value
+   uint32_t off_byte_TR;     // uint16 [nRb][byte_n_classes + 3]
+   uint32_t off_byte_TA;     // uint16 [nAb][byte_n_classes + 3]   row 0 = dead
+   uint32_t reserved[2];
 };
 
 #define FXP_STATE_MASK 0x7FFFu

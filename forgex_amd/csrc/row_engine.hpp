@@ -373,6 +373,30 @@ FX_HD Cell16 translate_cell16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3
    return Cell16{out[0], out[1], out[2], out[3]};
 }
 
+// `.match.` gate on the raw row bytes (forgex.F90:207-213, api_internal_m.F90:199-233), shared by the tile kernel and the
+// byte-table walk below: 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides
+template <class RowFn>
+FX_HD uint32_t match_gate(const FxpHeader* h, const uint8_t* prog, const RowFn& row, uint32_t L) {
+   const uint32_t lp = h->len_prefix, ls = h->len_suffix, la = h->len_all;
+   if ((h->flags & FXP_F_MATCH_LITERAL) && L == la) {
+      bool eq = true;
+      for (uint32_t k = 0; k < la; ++k) eq = eq && row(k) == prog[h->off_all + k];
+      return eq ? 2u : 0u;
+   }
+   if (lp > 0 && lp == L) {
+      bool eq = true;
+      for (uint32_t k = 0; k < lp; ++k) eq = eq && row(k) == prog[h->off_prefix + k];
+      if (eq) return 2u;
+   }
+   if (lp > L || ls > L) return 0u;
+   bool ok = true;
+   if (h->flags & FXP_F_PREFILTER)
+      for (uint32_t k = 0; k < lp; ++k) ok = ok && row(k) == prog[h->off_prefix + k];
+   if (h->flags & FXP_F_HAS_SUFFIX)
+      for (uint32_t k = 0; k < ls; ++k) ok = ok && row(L - ls + k) == prog[h->off_suffix + k];
+   return ok ? 1u : 0u;
+}
+
 struct Result {
    uint32_t flag;   // verdict of `.in.` / `.match.`
    int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none
@@ -579,6 +603,64 @@ FX_HD void run_row(const ProgView& pv, Sim& sim, const Row& r, int L, Result& ou
          out.to = 0;
          break;
    }
+}
+
+// Byte-level chain tables (FXP_F_BYTE_DFA) walked one byte at a time: the per-row meaning of the tile kernels' BYTES modes
+// (backward pass of R over the raw bytes for the leftmost start, forward pass of A for the longest end; `.match.`: one
+// forward pass and the FINAL column).  Returns 0 = `out` is the row's result, 1 = the row must be redone by the decode
+// path (structurally invalid UTF-8), -1 = the program has no byte tables / the row is outside the tile kernels' domain.
+template <class Row>
+FX_HD int byte_tables_row(const uint8_t* base, const Row& r, int L, Result& out) {
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(base);
+   if (!(h->flags & FXP_F_BYTE_DFA) || L < 1 || (L == 1 && r[0] == 0x20u)) return -1;   // (empty / single-blank text: api_internal_m.F90:68-74)
+   const uint16_t* cmap = reinterpret_cast<const uint16_t*>(base + h->off_byte_cls);
+   const uint8_t *TRp = base + h->off_byte_TR, *TAp = base + h->off_byte_TA;
+   auto step = [&](const uint8_t* T, uint32_t st, uint32_t byte) -> uint32_t { return *reinterpret_cast<const uint16_t*>(T + st + cmap[byte]); };
+   out.flag = 0;
+   out.from = 0;
+   out.to = 0;
+   if (h->mode == FXP_MODE_MATCH_ENGINE) {
+      auto row = [&](uint32_t j) -> uint32_t { return r[static_cast<int>(j)]; };
+      const uint32_t gate = match_gate(h, base, row, static_cast<uint32_t>(L));
+      uint32_t st = h->byte_A_init;
+      for (int j = 0; j < L; ++j) st = step(TAp, st, r[j]);
+      const uint32_t fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * (h->byte_n_classes + 2u));
+      if (gate == 2u) out.flag = 1;
+      else if (gate == 0u) out.flag = 0;
+      else if (st != 0 && fin == 2u) return 1;
+      else out.flag = (st != 0 && fin == 1u) ? 1u : 0u;
+      return 0;
+   }
+   uint32_t state = h->byte_R_start, s = 0;
+   for (int j = L - 1; j >= 0; --j) {
+      state = step(TRp, state, r[j]);
+      if (state >= h->byte_hit_min) s = static_cast<uint32_t>(j) + 2u;
+   }
+   state = step(TRp, state, 0u);   // leading NUL
+   if (state >= h->byte_hit_min) s = 1;
+   if (state == h->byte_inv_R) return 1;
+   if (s == 0) return 0;
+   uint32_t cur = h->byte_A_init, mm = 0, j = s >= 2 ? s - 2 : 0;
+   if (s == 1) {
+      cur = step(TAp, cur, 0u);
+      mm = cur >= h->byte_acc_min ? 2u : 0u;
+   }
+   while (cur != 0 && j <= static_cast<uint32_t>(L)) {   // position L holds the trailing NUL, later positions kill the state
+      cur = step(TAp, cur, j < static_cast<uint32_t>(L) ? r[static_cast<int>(j)] : 0u);
+      if (cur >= h->byte_acc_min) mm = j + 3u;
+      ++j;
+   }
+   if (mm != 0) {   // api_internal_m.F90:140-148
+      int32_t fr = static_cast<int32_t>(s) - 1;
+      if (fr == 0) fr = 1;
+      const int32_t tt = mm >= static_cast<uint32_t>(L) + 2u ? L : static_cast<int32_t>(mm) - 2;
+      if (fr > 0 && tt > 0) {
+         out.flag = 1;
+         out.from = fr;
+         out.to = tt;
+      }
+   }
+   return 0;
 }
 
 }   // namespace fxrow

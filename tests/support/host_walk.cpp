@@ -5,6 +5,7 @@
 // Speaks the I/M/R/V protocol of oracle/ref_driver.f90 (answers "U <status>" for patterns the GPU build
 // does not support, e.g. DFA state explosion).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -18,7 +19,17 @@ struct HostRow {
    const uint8_t* p;
    uint32_t operator[](int j) const { return p[j]; }
 };
+long g_byte_rows = 0, g_byte_exceptions = 0;   // FX_HW_BYTES=1: rows answered by the byte tables / sent on to the decode path
 void run_any(const fxrow::ProgView& pv, const fxc::Program& p, const HostRow& r, int L, fxrow::Result& res) {
+   static const bool use_bytes = std::getenv("FX_HW_BYTES") != nullptr;
+   if (use_bytes && (p.hdr().flags & FXP_F_BYTE_DFA)) {   // what the tile kernels' BYTES modes compute; exceptions fall through
+      const int rc = fxrow::byte_tables_row(p.blob.data(), r, L, res);
+      if (rc == 0) {
+         ++g_byte_rows;
+         return;
+      }
+      if (rc == 1) ++g_byte_exceptions;
+   }
    if (p.hdr().flags & FXP_F_NFA_SIM) {   // bitset simulation of NFA state sets (DFA too large)
       std::vector<uint32_t> scratch(2 * p.hdr().nfa_words);
       fxrow::NfaSim sim(pv, scratch.data());
@@ -109,6 +120,20 @@ int hw_translate(const char* pat, int64_t plen, const uint8_t* row, int64_t L, u
    return 0;
 }
 
+// byte-level tables of a pattern: info[0..4] = present, byte classes, states of A, states of R, table bytes
+void hw_byte_info(const char* pat, int64_t plen, int op, int32_t* info) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
+   const FxpHeader& h = p.hdr();
+   info[0] = (h.flags & FXP_F_BYTE_DFA) ? 1 : 0;
+   info[1] = static_cast<int32_t>(h.byte_n_classes);
+   info[2] = h.byte_row_bytes ? static_cast<int32_t>(h.byte_TA_bytes / h.byte_row_bytes) : 0;
+   info[3] = h.byte_row_bytes ? static_cast<int32_t>(h.byte_TR_bytes / h.byte_row_bytes) : 0;
+   info[4] = static_cast<int32_t>(h.byte_TA_bytes + h.byte_TR_bytes);
+}
+void hw_byte_stats(long* rows, long* exceptions) {
+   *rows = g_byte_rows;
+   *exceptions = g_byte_exceptions;
+}
 // program facts for tests: fills info[0..7] = mode, flags, nA, nR, n_classes, status, total_bytes, n_bounds
 void hw_info(const char* pat, int64_t plen, int op, int32_t* info) {
    fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);

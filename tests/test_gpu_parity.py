@@ -84,7 +84,7 @@ def test_config_rows_vs_oracle(fx, cfg, n):
     _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
     assert np.array_equal(f2, of)
     if cfg in ("cfg2", "cfg3", "cfg5"):
-        assert prog.last_path() in (1, 3)   # fast kernel
+        assert prog.last_path() in (1, 3, 8)   # fast kernel
 
 
 def test_fast_and_general_kernels_agree(fx):
@@ -95,7 +95,7 @@ def test_fast_and_general_kernels_agree(fx):
     pat = synth.PATTERNS["cfg3"]
     p = fx.Program(pat, fx.OP_SEARCH)
     f1, a1, b1 = p.match_device(rows)
-    assert p.last_path() in (1, 3)
+    assert p.last_path() in (1, 3, 8)
     wide = torch.cat([rows, torch.full((rows.shape[0], 1), 33, dtype=torch.uint8, device=rows.device)], dim=1).contiguous()  # '!' appended
     f2, a2, b2 = p.match_device(wide)
     assert p.last_path() == 2
@@ -255,20 +255,24 @@ def test_nfa_simulation_fallback_vs_oracle(fx):
     assert np.array_equal(fm, om) and 0 < int(om.sum()) < 600
 
 
-def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
-    """The hot kernel under random PATTERNS: every generated pattern that qualifies for the fast path is run over batches
+@pytest.mark.parametrize("byte_tables", [True, False])
+def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch):
+    """(byte_tables False: FXAMD_NO_BYTE_DFA=1 keeps the deferred tiles on the decode pass instead of the byte-level tables.)
+    The hot kernel under random PATTERNS: every generated pattern that qualifies for the fast path is run over batches
     of random rows at each row length the fast kernel is instantiated for (ASCII-only, and mixed with valid and broken
     UTF-8 so that the deferred-tile pass with on-device decode runs), flags and spans vs the oracle."""
     import random
     import fuzz_diff
-    rng = random.Random(99)
+    if not byte_tables:
+        monkeypatch.setenv("FXAMD_NO_BYTE_DFA", "1")
+    rng = random.Random(99 if byte_tables else 100)
     nrng = np.random.default_rng(99)
     ascii_alpha = np.frombuffer(b"abcxyz019 .-\n\tAZ_@", dtype=np.uint8)
     pieces = [b"a", b"b", b"c", b"x", b"0", b"9", b" ", b".", "あ".encode(), "ん".encode(), "α".encode(), "ω".encode(), "é".encode(),
               b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
     n_fast = 0
     tried = 0
-    while n_fast < 90 and tried < 1200:
+    while n_fast < 60 and tried < 1200:
         tried += 1
         pat = fuzz_diff.gen_pattern(rng).encode()
         p = fx.Program(pat, fx.OP_SEARCH)
@@ -287,7 +291,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
         rows_m = np.stack(mixed)
         for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]])):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (1, 3, 5, 6), (pat, L)
+            assert prog.last_path() in (1, 3, 5, 6, 7, 8), (pat, L)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -298,6 +302,41 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx):
             om, _, _ = oracle_lib.batch(1, pat, rows, NT)
             assert np.array_equal(fm, om), (pat, L, "match", pm.last_path())
     assert n_fast >= 60
+
+
+def test_utf8_rows_byte_tables_and_decode_pass(fx, monkeypatch):
+    """Non-ASCII rows two ways: the byte-level tables (UTF-8 composed into the automata, structurally invalid rows through the
+    row-level fix-up) and, with FXAMD_NO_BYTE_DFA=1, the decode pass; both bit-exact against the oracle."""
+    import torch
+    from forgex_amd import synth
+    nrng = np.random.default_rng(5)
+    rows4 = synth.batch("cfg4", 0, 20000, torch.device("cuda")).cpu().numpy()
+    pieces = [s.encode() for s in "あいうえおかんアイウαβγωé　"] + [b"a", b"z", b"0", b"7", b" ", b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80",
+                                                                  b"\xff", b"\xf4\x90\x80\x80", b"\xed\xa0\x80", b"\xc3"]
+    mixed = np.stack([np.frombuffer((b"".join(pieces[i] for i in nrng.integers(0, len(pieces), size=80)))[:64], dtype=np.uint8) for _ in range(6000)])
+    cases = [(synth.PATTERNS["cfg4"].encode(), rows4, 8), ("[ぁ-ん]+[0-9]*".encode(), mixed, 8), (b".+", mixed, 8), ("[^a]+".encode(), mixed, 8),
+             ("[ぁ-ん]{3}[ァ-ヶ]{3}[0-9]{3}".encode(), mixed, 7), (rb"\S+\d", mixed, 8), ("(あ|ア)+い".encode(), mixed, 7)]
+    for pat, rows, path in cases:
+        of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+        om, _, _ = oracle_lib.batch(1, pat, rows, NT)
+        for bytes_on in (True, False):
+            if bytes_on:
+                monkeypatch.delenv("FXAMD_NO_BYTE_DFA", raising=False)
+            else:
+                monkeypatch.setenv("FXAMD_NO_BYTE_DFA", "1")
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            if bytes_on:
+                assert prog.info()["flags"] & 4096, pat
+                assert prog.last_path() in (7, 8), (pat, prog.last_path())
+            else:
+                assert prog.last_path() in (1, 3, 5, 6), (pat, prog.last_path())
+            assert np.array_equal(f, of), (pat, bytes_on)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, bytes_on)
+            _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+            assert np.array_equal(f2, of), (pat, bytes_on, "flags-only")
+            pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+            assert np.array_equal(fm, om), (pat, bytes_on, "match", pm.last_path())
+    monkeypatch.delenv("FXAMD_NO_BYTE_DFA", raising=False)
 
 
 CHAIN_PATTERNS = [rb"\d{3}-\d{4}", rb"\w+@\w+\.(com|org|net)", rb"(19|20)\d\d-(0[1-9]|1[012])-(0[1-9]|[12][0-9]|3[01])",
@@ -320,7 +359,7 @@ def test_chain_scheme_patterns_vs_oracle(fx):
                 off = int(nrng.integers(0, L - len(sd)))
                 rows[i, off:off + len(sd)] = sd
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (5, 6), (pat, L, prog.last_path())
+            assert prog.last_path() in (5, 6, 7), (pat, L, prog.last_path())
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -353,7 +392,7 @@ def test_match_operator_on_tile_kernel(fx):
         if L == 52:
             rows[::3] = np.frombuffer(b"abcdefghijkl" * 4 + b"ab42"[:4], dtype=np.uint8)
         prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
-        assert prog.last_path() in (1, 3, 5, 6), (pat, prog.last_path())
+        assert prog.last_path() in (1, 3, 5, 6, 7, 8), (pat, prog.last_path())
         of, _, _ = oracle_lib.batch(1, pat, rows, NT)
         assert np.array_equal(f, of), pat
     # 8-byte rows of BASELINE config 1 go through the general kernel (row length not a multiple of 16): still bit-exact

@@ -35,6 +35,35 @@ def test_tables_equal_oracle_on_fuzz(built):
     assert total > 5000
 
 
+def test_byte_level_tables_equal_oracle_on_utf8_fuzz(built, monkeypatch):
+    """FXP_F_BYTE_DFA: the automata composed with the UTF-8 decoder, walked over raw bytes by the host harness exactly as the
+    tile kernels' BYTES modes do (structurally invalid rows fall through to the decode path), against the oracle on texts full
+    of multi-byte, overlong, out-of-range and broken sequences; also the golden vectors once more through these tables."""
+    import random
+    import fuzz_bytes
+    monkeypatch.setenv("FX_HW_BYTES", "1")
+    rng = random.Random(11)
+    cases = []
+    for _ in range(4000):
+        pat = rng.choice(fuzz_bytes.EXTRA_PATTERNS) if rng.random() < 0.4 else fuzz_diff.gen_pattern(rng)
+        cases.append((rng.choice(["I", "M", "R", "R"]), pat.encode(), fuzz_bytes.gen_text(rng)))
+    a = golden.run_protocol(HW, cases)
+    b = golden.run_protocol(golden.ORACLE_CLI, cases)
+    diffs = [(c, x, y) for c, x, y in zip(cases, a, b) if not x.startswith("U") and x != y]
+    assert not diffs, diffs[:5]
+    pairs = [(c, e) for c, e in golden.expected_lines_from_golden(golden.load_ref_tests()) if c[0] in "IMR"]
+    out = golden.run_protocol(HW, [c for c, _ in pairs])
+    bad = [(c, e, x) for (c, e), x in zip(pairs, out) if not x.startswith("U") and not golden.line_matches(e, x)]
+    assert not bad, bad[:5]
+    # the tables exist for the BASELINE patterns without a prefilter literal and are small
+    lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
+    lib.hw_byte_info.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    for pat, want in (("[a-z]+\\d+", 1), ("[α-ωぁ-ん]+", 1), ("foo(bar|baz)", 0)):
+        info = (ctypes.c_int32 * 8)()
+        lib.hw_byte_info(pat.encode(), len(pat.encode()), 0, info)
+        assert info[0] == want and info[4] < 8192, (pat, list(info))
+
+
 def test_config_rows_tables_vs_oracle(built):
     """Small slices of the five BASELINE configs through the host walker (one compile per batch) and the oracle."""
     import torch
