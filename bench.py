@@ -82,6 +82,10 @@ def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
                 "sample": "first %d rows of %s, %.2f s wall, one compile per batch" % (nrows, cfg, dt)}
 
     try:
+        walker = table_walker()
+    except Exception as e:
+        walker = {"value": None, "sample": "failed: %r" % (e,)}
+    try:
         probe = 4 * threads
         t = run(probe)
         per_row = max(t / probe, 1e-9)
@@ -92,7 +96,7 @@ def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
                 "kind": "reference" if use_ref else "port",
                 "sample": "first %d rows of %s (%d B each), %.1f s wall, per-row compile as the elemental operator does" % (
                     sample, cfg, row_len, t),
-                "us_per_row": t / sample * 1e6 * 1.0, "table_walker": table_walker()}
+                "us_per_row": t / sample * 1e6 * 1.0, "table_walker": walker}
     except Exception as e:   # the baseline is reported, never allowed to sink the bench line
         return {"value": None, "unit": "GB/s", "cores": threads, "kind": "reference" if use_ref else "port", "sample": "failed: %r" % (e,)}
 
