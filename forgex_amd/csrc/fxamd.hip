@@ -65,6 +65,26 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
    }
 }
 
+// Long rows (Lr a multiple of 256, > 256): the tile is walked in 256-byte SEGMENTS.  Piece q*64+lane of segment `seg` = row
+// 4q + lane/16, chunk lane%16 of that segment: 16 lanes read 256 contiguous bytes of one row.  Same buffer resource trick:
+// extent = the tile's valid bytes, the row / segment distance rides in the scalar offset (which the range check includes).
+__device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
+                                              uint32_t seg, bool enable) {
+   const int64_t rows_left = n - row0;
+   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u));
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)Lr;
+   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+   const uint32_t voff = (lane >> 4) * Lr + (lane & 15u) * 16u;
+   const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg * 256u);
+#pragma unroll
+   for (int q = 0; q < 16; ++q) {
+      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)(4 * q) * Lr, FX_LOAD_AUX);
+      v[q] = make_uint4(t.x, t.y, t.z, t.w);
+   }
+}
+
 // Rows whose length Lr is not 16*CH (Lr % 4 == 0, 16 <= Lr <= 16*CH): the same 64-row tile, but piece (R, k) comes from byte
 // R*Lr + 16k of the tile (dword aligned, not 16-byte aligned) and the bytes behind the row end are delivered as ZERO.  The
 // last partial chunk is read as the row's LAST 16 bytes and shifted down, so nothing beyond the caller's buffer is touched.
@@ -198,8 +218,20 @@ __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state
 // non-continuation byte within 3 to its left is a lead whose whole sequence is continuation bytes).
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
 // at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
-template <bool RAGGED>
+template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
+   if (LONG) {
+      // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); L % 8 == 0
+      if (p < L) {
+         const uint2 r = *reinterpret_cast<const uint2*>(tb + p);
+         lo = r.x;
+         hi = r.y;
+      } else {
+         lo = p == L ? 0xFEFEFE00u : 0xFEFEFEFEu;
+         hi = 0xFEFEFEFEu;
+      }
+      return;
+   }
    if (!RAGGED) {
       // whole chunks: index L.. lives in the row's extra chunk column (NUL, then KILL symbols); anything further reads its KILL half
       const uint32_t pc = p < L + 8u ? p : L + 8u;   // p and L are multiples of 8
@@ -214,12 +246,12 @@ __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const ui
    lo = p + 4u <= L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
    hi = p + 8u <= L ? r.y : (p + 4u == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
 }
-template <bool RAGGED>
+template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;
    uint32_t d[10];
 #pragma unroll
-   for (int g = 0; g < 5; ++g) group_words<RAGGED>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
+   for (int g = 0; g < 5; ++g) group_words<RAGGED, LONG>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
    const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
    uint32_t e[9];
 #pragma unroll
@@ -227,12 +259,12 @@ __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uin
 #pragma unroll
    for (int k = 0; k < 8; ++k) o[k] = __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u);
 }
-template <bool RAGGED>
+template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;
    uint32_t d[4];
-   group_words<RAGGED>(d[0], d[1], tb, lane, base, L);
-   group_words<RAGGED>(d[2], d[3], tb, lane, base + 8u, L);
+   group_words<RAGGED, LONG>(d[0], d[1], tb, lane, base, L);
+   group_words<RAGGED, LONG>(d[2], d[3], tb, lane, base + 8u, L);
    const uint32_t up = 0u - ((sh >> 2) & 1u);
    uint32_t e[3];
 #pragma unroll
@@ -277,6 +309,8 @@ __device__ unsigned long long fx_stamp_acc[16];
       else if ((en) && (tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
    } while (0)
 
+#define PREFETCH_SEG(st, tn, sg, en) load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg), (en))
+
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
 //                 the offending rows are marked individually for the general kernel's fix-up.
@@ -288,15 +322,19 @@ __device__ unsigned long long fx_stamp_acc[16];
 // MODE 4: the decode pass over a WORKLIST of row indices (the exception rows a BYTES pass appended): each lane gathers its own
 //         row into its LDS cells, results are scattered back to the rows' own slots.
 // n_deferred points at this call's two words: [0] "a first pass deferred tiles", [1] number of exception rows in `worklist`.
-template <int CH, bool SPANS, int MODE, bool CHAIN, bool RAGGED>
+// LONG: rows longer than 256 bytes (a multiple of 256), CH = 16: the backward pass walks the row segment by segment through the
+// same LDS tile, the short forward pass reads its bytes straight from global memory.  First-pass and BYTES modes only.
+template <int CH, bool SPANS, int MODE, bool CHAIN, bool RAGGED, bool LONG = false>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
                                                         uint32_t Lr, uint32_t* __restrict__ clear_next, uint32_t* __restrict__ worklist) {
    // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
    // instantiation keeps the row length a compile-time constant (the hot path).
-   const uint32_t L = RAGGED ? Lr : 16u * CH;
+   const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;
+   const uint32_t S = LONG ? (Lr >> 8) : 1u;   // 256-byte segments per row
    constexpr bool ragged = RAGGED;
+   static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (CHAIN && !RAGGED), "byte-level tables use the chain scheme on whole chunks");
    static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
@@ -388,108 +426,117 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          for (int k = 0; k < CH; ++k) stage[k] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
          for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = stage[k];
-      } else {
-         const bool process = live;
-         // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
-         // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
-         if (MODE == 0 && utf8) {
-            const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
-            defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
-         }
-         if (process) store_tile<CH>(stage, tile, lane);
-         STAMP(0);
-         // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
-         // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
-         // loop's back edge: copies behind a vmcnt(0)).  A tile the pass skips is "loaded" with zero valid bytes.
-         live = MARKED ? tile_marked(t_next) : true;
-         PREFETCH_TILE(stage, t_next, live);
-         if (!process) return;
       }
-      if (defer_early) {
-         if (row_ok) flags[row] = FX_NEEDS_GENERAL;
-         any_deferred = true;
-         return;
-      }
-      if (FIXUP) {
-         // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
-         // (fxrow::translate_cell16).  The 4 bytes before / after a cell are taken from the ORIGINAL neighbours: the
-         // previous cell's last dword is kept in a register, the next cell is read before anything overwrites it.
-         uint32_t prev = 0;
-         uint4 cur = tile[tile_cell(lane, 0)];
-         for (int k = 0; k < CH; ++k) {
-            const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
-            const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
-            tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
-            prev = cur.w;
-            cur = nxt;
-         }
-      }
-      const uint32_t na_ragged = ragged ? pad_rows<CH>(tile, lane, Lr) : 0u;
-
-      // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
-      // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
-      // expressible) while the state chain of the current group runs.  Per group only "did any state hit" and the
-      // group's entry state are kept; the exact byte is recovered afterwards by re-walking ONE group per row.
-      STAMP(1);
-#ifdef FX_EXP_NOCOMPUTE
-      {   // experiment: memory path only (loads, LDS staging, outputs), no automaton work
-         uint32_t acc = na_ragged;
-#pragma unroll
-         for (int k = 0; k < CH; ++k) {
-            const uint4 c = tile[tile_cell(lane, k)];
-            acc |= c.x | c.y | c.z | c.w;
-         }
-         if (row0 + lane < n) {
-            flags[row0 + lane] = (uint8_t)(acc & 1u);
-            if (SPANS) {
-               from[row0 + lane] = (int32_t)acc;
-               to[row0 + lane] = (int32_t)(acc >> 1);
-            }
-         }
-         return;
-      }
-#endif
       uint32_t state = fp.R_start;
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
-      uint32_t na = na_ragged;
-      F fa[8], fb[8];
-      uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
-      if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
-      lookup8(fa, wk.z, wk.w, tabR);
+      uint32_t na = 0;
+      for (uint32_t seg = S - 1u;; --seg) {   // one pass unless LONG: the row's 256-byte segments, right to left
+         if (!LIST) {
+            const bool process = live;
+            // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
+            // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
+            if (MODE == 0 && utf8 && seg == S - 1u) {
+               const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+               defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+            }
+            if (process) store_tile<CH>(stage, tile, lane);
+            STAMP(0);
+            // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
+            // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
+            // loop's back edge: copies behind a vmcnt(0)).  A tile the pass skips is "loaded" with zero valid bytes.
+            const bool last = !LONG || !process || defer_early || seg == 0u;   // nothing more of this tile is wanted
+            if (last) live = MARKED ? tile_marked(t_next) : true;
+            if constexpr (LONG) PREFETCH_SEG(stage, last ? t_next : t, last ? S - 1u : seg - 1u, last ? live : true);
+            else PREFETCH_TILE(stage, t_next, live);
+            if (!process) return;
+         }
+         if (defer_early) {
+            if (row_ok) flags[row] = FX_NEEDS_GENERAL;
+            any_deferred = true;
+            return;
+         }
+         if (FIXUP) {
+            // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
+            // (fxrow::translate_cell16).  The 4 bytes before / after a cell are taken from the ORIGINAL neighbours: the
+            // previous cell's last dword is kept in a register, the next cell is read before anything overwrites it.
+            uint32_t prev = 0;
+            uint4 cur = tile[tile_cell(lane, 0)];
+            for (int k = 0; k < CH; ++k) {
+               const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+               tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+               prev = cur.w;
+               cur = nxt;
+            }
+         }
+         if (ragged) na |= pad_rows<CH>(tile, lane, Lr);
+
+         // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
+         // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
+         // expressible) while the state chain of the current group runs.  Per group only "did any state hit" and the
+         // group's entry state are kept; the exact byte is recovered afterwards by re-walking ONE group per row.
+         STAMP(1);
+#ifdef FX_EXP_NOCOMPUTE
+         {   // experiment: memory path only (loads, LDS staging, outputs), no automaton work
+            uint32_t acc = na;
 #pragma unroll
-      for (int k = CH - 1; k >= 0; --k) {
-         if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
-         lookup8(fb, wk.x, wk.y, tabR);
-         __builtin_amdgcn_sched_barrier(0);
-         {
-            const uint32_t entry = state;
-            const uint32_t mx = chain8_back(fa, state, TRp);
-            gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
-            esel = mx >= fp.hit_min ? entry : esel;
-            asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+            for (int k = 0; k < CH; ++k) {
+               const uint4 c = tile[tile_cell(lane, k)];
+               acc |= c.x | c.y | c.z | c.w;
+            }
+            if (row0 + lane < n) {
+               flags[row0 + lane] = (uint8_t)(acc & 1u);
+               if (SPANS) {
+                  from[row0 + lane] = (int32_t)acc;
+                  to[row0 + lane] = (int32_t)(acc >> 1);
+               }
+            }
+            return;
          }
-         __builtin_amdgcn_sched_barrier(0);
-         if (k >= 1) {
-            wk = wn;
-            lookup8(fa, wk.z, wk.w, tabR);
-            if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+#endif
+         const uint32_t gbase = LONG ? seg * 32u : 0u;   // 8-byte groups to the left of this segment
+         F fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
+         if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+         lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll
+         for (int k = CH - 1; k >= 0; --k) {
+            if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
+            lookup8(fb, wk.x, wk.y, tabR);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fa, state, TRp);
+               gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k + 1) : gsel;
+               esel = mx >= fp.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 1) {
+               wk = wn;
+               lookup8(fa, wk.z, wk.w, tabR);
+               if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fb, state, TRp);
+               gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k) : gsel;
+               esel = mx >= fp.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));
+            }
+            __builtin_amdgcn_sched_barrier(0);
          }
-         __builtin_amdgcn_sched_barrier(0);
-         {
-            const uint32_t entry = state;
-            const uint32_t mx = chain8_back(fb, state, TRp);
-            gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
-            esel = mx >= fp.hit_min ? entry : esel;
-            asm volatile("" : "+v"(esel));
-         }
-         __builtin_amdgcn_sched_barrier(0);
+         if (!LONG || seg == 0u) break;
       }
       STAMP(2);
       uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
       {
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
          const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
-         const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+         uint2 rw;
+         if (LONG) rw = row_ok ? *reinterpret_cast<const uint2*>(rows + row * (int64_t)L + (int64_t)g * 8) : make_uint2(0, 0);   // (its segment left the tile)
+         else rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
          F f[8];
          lookup8(f, rw.x, rw.y, tabR);
          uint32_t st = esel, loc = 8;
@@ -502,7 +549,9 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          const F fz = tabR[0];   // leading NUL
          state = fxstep(fz, state, TRp);
          s = state >= fp.hit_min ? 1u : s;
+         if (LONG && !row_ok) s = 0;   // (no row: the forward pass would read global memory)
       }
+      const uint8_t* fsrc = LONG ? rows + row * (int64_t)L : tb;   // where the forward pass finds the row's bytes
       // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
       // TILE is deferred to the second pass (wave-uniform; the raw-byte scan above is discarded and the
       // forward walk below is skipped).
@@ -540,7 +589,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          // all 32 table lookups issued before the chain; per 8-byte group only "any accept" (v_max3) + entry state
          // are kept and the last accepting group is re-walked for the exact byte.
          uint32_t o[8];
-         fetch32<RAGGED>(o, tb, lane, j, (uint32_t)L);
+         fetch32<RAGGED, LONG>(o, fsrc, lane, j, (uint32_t)L);
          F f[32];
 #pragma unroll
          for (int g = 0; g < 4; ++g) lookup8(&f[8 * g], o[2 * g], o[2 * g + 1], tabA);
@@ -578,7 +627,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             if (cur != 0) {
                uint32_t o8[2];
-               fetch8<RAGGED>(o8, tb, lane, j, (uint32_t)L);
+               fetch8<RAGGED, LONG>(o8, fsrc, lane, j, (uint32_t)L);
                F f8[8];
                lookup8(f8, o8[0], o8[1], tabA);
                uint32_t loc = 8;
@@ -629,7 +678,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
          live[d] = MARKED ? tile_marked(wave_global + d * wave_stride) : true;
-         PREFETCH_TILE(stage[d], wave_global + d * wave_stride, live[d]);
+         if constexpr (LONG) PREFETCH_SEG(stage[d], wave_global + d * wave_stride, S - 1u, live[d]);
+         else PREFETCH_TILE(stage[d], wave_global + d * wave_stride, live[d]);
       }
       for (int64_t t = wave_global;;) {   // (leaving the loop from the middle keeps the staging registers free of merges)
          bool done = false;
@@ -672,13 +722,15 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
 
 // MODE as in fx_search_fast (BYTES modes: a row whose walk ends inside a character or in the INVALID state -- FINAL column 2 -- is
 // left to the row-level fix-up)
-template <int CH, int MODE, bool CHAIN, bool RAGGED>
+template <int CH, int MODE, bool CHAIN, bool RAGGED, bool LONG = false>
 __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
                                                        uint32_t* __restrict__ worklist) {
-   const uint32_t L = RAGGED ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
+   const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
+   const uint32_t S = LONG ? (Lr >> 8) : 1u;                // LONG: 256-byte segments per row, walked left to right through the same tile
    constexpr bool ragged = RAGGED;
+   static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (CHAIN && !RAGGED), "byte-level tables use the chain scheme on whole chunks");
    static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
@@ -735,7 +787,8 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    bool live = true;   // the tile in `stage` is to be scanned (always, except in the marked-tile passes)
    if (!LIST) {
       live = MARKED ? tile_marked(wave_global) : true;
-      PREFETCH_TILE(stage, wave_global, live);
+      if constexpr (LONG) PREFETCH_SEG(stage, wave_global, 0u, live);
+      else PREFETCH_TILE(stage, wave_global, live);
    }
    for (int64_t t = wave_global; LIST ? (uint64_t)(t << 6) < list_count : t < n_tiles; t += wave_stride) {
       const int64_t row0 = t << 6;
@@ -752,58 +805,80 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          for (int k = 0; k < CH; ++k) stage[k] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
          for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = stage[k];
-      } else {
-         const bool process = live;
-         if (MODE == 0 && utf8) {
-            const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
-            defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
-         }
-         if (process) store_tile<CH>(stage, tile, lane);
-         live = MARKED ? tile_marked(t + wave_stride) : true;
-         PREFETCH_TILE(stage, t + wave_stride, live);   // the one reload site of the staging registers
-         if (!process) continue;
       }
-      if (defer_early) {
-         if (row_ok) flags[row] = FX_NEEDS_GENERAL;
-         any_deferred = true;
-         continue;
-      }
-      const uint32_t gate = match_gate(h, prog, tb, lane, L);   // on the raw bytes, before any decode
-      if (FIXUP) {
-         uint32_t prev = 0;
-         uint4 cur = tile[tile_cell(lane, 0)];
-         for (int k = 0; k < CH; ++k) {
-            const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
-            const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
-            tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
-            prev = cur.w;
-            cur = nxt;
-         }
-      }
-      const uint32_t na_ragged = ragged ? pad_rows<CH>(tile, lane, Lr) : 0u;
-      // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
       uint32_t st = fp.A_init;   // = M_start
-      uint32_t na = na_ragged;
-      F fa[8], fb[8];
-      uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
-      if (CH >= 2) wn = tile[tile_cell(lane, 1)];
-      lookup8(fa, wk.x, wk.y, tabA);
-#pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
-      for (int k = 0; k < CH; ++k) {
-         if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
-         lookup8(fb, wk.z, wk.w, tabA);
-         __builtin_amdgcn_sched_barrier(0);
-         chain8_fwd(fa, st, TAp);
-         __builtin_amdgcn_sched_barrier(0);
-         if (k + 1 < CH) {
-            wk = wn;
-            lookup8(fa, wk.x, wk.y, tabA);
-            if (k + 2 < CH) wn = tile[tile_cell(lane, k + 2)];
+      uint32_t na = 0;
+      uint32_t gate = 1u;
+      bool skip = false;
+      for (uint32_t seg = 0;; ++seg) {   // one pass unless LONG: the row's 256-byte segments, left to right
+         if (!LIST) {
+            const bool process = live;
+            if (MODE == 0 && utf8 && seg == 0u) {
+               const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+               defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+            }
+            if (process) store_tile<CH>(stage, tile, lane);
+            const bool last = !LONG || !process || defer_early || seg + 1u == S;   // nothing more of this tile is wanted
+            if (last) live = MARKED ? tile_marked(t + wave_stride) : true;
+            // the one reload site of the staging registers
+            if constexpr (LONG) PREFETCH_SEG(stage, last ? t + wave_stride : t, last ? 0u : seg + 1u, last ? live : true);
+            else PREFETCH_TILE(stage, t + wave_stride, live);
+            if (!process) {
+               skip = true;
+               break;
+            }
          }
-         __builtin_amdgcn_sched_barrier(0);
-         chain8_fwd(fb, st, TAp);
-         __builtin_amdgcn_sched_barrier(0);
+         if (defer_early) {
+            if (row_ok) flags[row] = FX_NEEDS_GENERAL;
+            any_deferred = true;
+            skip = true;
+            break;
+         }
+         if (seg == 0u) {   // on the raw bytes, before any decode (long rows: straight from global memory)
+            if (LONG) {
+               const uint8_t* rp = rows + row * (int64_t)L;
+               auto rowb = [&](uint32_t j) -> uint32_t { return rp[j]; };
+               gate = row_ok ? fxrow::match_gate(h, prog, rowb, L) : 0u;
+            } else {
+               gate = match_gate(h, prog, tb, lane, L);
+            }
+         }
+         if (FIXUP) {
+            uint32_t prev = 0;
+            uint4 cur = tile[tile_cell(lane, 0)];
+            for (int k = 0; k < CH; ++k) {
+               const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+               tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+               prev = cur.w;
+               cur = nxt;
+            }
+         }
+         if (ragged) na |= pad_rows<CH>(tile, lane, Lr);
+         // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
+         F fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
+         if (CH >= 2) wn = tile[tile_cell(lane, 1)];
+         lookup8(fa, wk.x, wk.y, tabA);
+#pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
+         for (int k = 0; k < CH; ++k) {
+            if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
+            lookup8(fb, wk.z, wk.w, tabA);
+            __builtin_amdgcn_sched_barrier(0);
+            chain8_fwd(fa, st, TAp);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < CH) {
+               wk = wn;
+               lookup8(fa, wk.x, wk.y, tabA);
+               if (k + 2 < CH) wn = tile[tile_cell(lane, k + 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            chain8_fwd(fb, st, TAp);
+            __builtin_amdgcn_sched_barrier(0);
+         }
+         if (!LONG || seg + 1u == S) break;
       }
+      if (skip) continue;
       uint32_t fin;
       if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * ((BYTES ? h->byte_n_classes : h->n_classes) + 2u));   // FINAL column
       else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
@@ -1002,6 +1077,9 @@ static int tile_chunks(int64_t row_len) {
       if (row_len <= 16 * c) return c;
    return 0;
 }
+// long rows: a multiple of 256 bytes, walked segment by segment by the CH = 16 instantiations
+static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536 && (row_len & 255) == 0; }
+static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : tile_chunks(row_len); }
 // MODE: 0 first pass, 1 decode second pass, 2 byte-level tables over all tiles, 3 byte-level tables over marked tiles
 // n_deferred: this call's two words ([0] tiles deferred, [1] exception rows left); the other call parity's pair is 8 bytes away
 template <int CH, int MODE, bool CHAIN>
@@ -1017,6 +1095,22 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
    const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
+   if (Lr > 256u) {   // long rows (a multiple of 256 bytes): segment-walking instantiation, CH = 16, first-pass / byte-level modes only
+      if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
+         constexpr bool CHN = MODE == 0 ? CHAIN : true;
+         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<16, true, MODE, CHN, false, true>)
+                                : reinterpret_cast<const void*>(&fx_search_fast<16, false, MODE, CHN, false, true>);
+         if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+         }
+         if (spans) hipLaunchKernelGGL((fx_search_fast<16, true, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<16, false, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         return hipGetLastError();
+      } else {
+         return hipErrorInvalidValue;   // (never dispatched)
+      }
+   }
    if constexpr (MODE >= 2) {   // whole-chunk rows only: byte-level tables (2, 3: chain scheme) and the worklist decode pass (4)
       constexpr bool CHN = MODE == 4 ? CHAIN : true;
       if (ragged) return hipErrorInvalidValue;   // (never dispatched)
@@ -1059,6 +1153,20 @@ static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
+   if (Lr > 256u) {   // long rows
+      if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
+         constexpr bool CHN = MODE == 0 ? CHAIN : true;
+         const void* fn = reinterpret_cast<const void*>(&fx_match_fast<16, MODE, CHN, false, true>);
+         if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+         }
+         hipLaunchKernelGGL((fx_match_fast<16, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+         return hipGetLastError();
+      } else {
+         return hipErrorInvalidValue;
+      }
+   }
    if constexpr (MODE >= 2) {
       constexpr bool CHN = MODE == 4 ? CHAIN : true;
       if (ragged) return hipErrorInvalidValue;
@@ -1095,7 +1203,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, po.defer_tiles, po.gate_word, 0};
-   switch (tile_chunks(row_len)) {
+   switch (chunks_of(row_len)) {
       case 1: return launch_match<1, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_match<2, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_match<3, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -1108,8 +1216,9 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
 }
 
 static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if (row_len < 16 || row_len > 256 || (row_len & 3) != 0) return false;
    if ((reinterpret_cast<uintptr_t>(d_rows) & 15u) != 0) return false;
+   if (long_row(row_len)) return true;
+   if (row_len < 16 || row_len > 256 || (row_len & 3) != 0) return false;
    if (row_len == 16 * tile_chunks(row_len)) return true;       // whole chunks: fully coalesced tile loads
    return (h.flags & FXP_F_RAGGED_OK) != 0;                        // padded in LDS with the inert symbol 255
 }
@@ -1118,7 +1227,7 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return 0;
    if (h.flags & FXP_F_FAST_OK) return 1;
    if (h.flags & FXP_F_CHAIN_OK) {
-      const size_t need = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
+      const size_t need = (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
       if (need <= 150 * 1024) return 2;
    }
    return 0;
@@ -1126,8 +1235,8 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
 // byte-level tables usable for these rows: whole chunks only (no inert pad byte exists: every byte value means something)
 static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
    if (std::getenv("FXAMD_NO_BYTE_DFA")) return false;   // test hook: exercise the decode pass instead
-   if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || row_len != 16 * tile_chunks(row_len)) return false;
-   return (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
+   if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || (!long_row(row_len) && row_len != 16 * tile_chunks(row_len))) return false;
+   return (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
 
 template <int MODE, bool CHAIN>
@@ -1150,7 +1259,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.hit_min = h.chain_hit_min;
       fp.acc_min = h.chain_acc_min;
    }
-   switch (tile_chunks(row_len)) {
+   switch (chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_fast<2, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_fast<3, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -1300,7 +1409,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (rc != FXAMD_OK) return rc;
    uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);
    PassOpts po;
-   po.defer_tiles = ((h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0 || bytes_ok(h, d_rows, row_len)) ? 1u : 0u;
+   po.defer_tiles = (((h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0 && !long_row(row_len)) || bytes_ok(h, d_rows, row_len)) ? 1u : 0u;
    if (scheme == 2 && bytes_ok(h, d_rows, row_len) && p->worklist_rows >= n) {
       po.worklist = p->d_worklist;
       FX_HIP((launch_fast_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
@@ -1362,7 +1471,8 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    if (scheme != 0) {
       const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
       uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);   // this call's words: [0] tiles deferred, [1] exception rows left
-      const bool utf8_tables = (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0;
+      // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
+      const bool utf8_tables = (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0 && !long_row(row_len);
       const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
       // row-level fix-up through the general engine: rows still marked FX_NEEDS_GENERAL (gate: skip when the word says none are)
       auto fixup_rows = [&](const uint32_t* gate) -> int {

@@ -425,3 +425,44 @@ def test_literal_index_search_on_tile_kernel(fx):
         assert np.array_equal(a, oa) and np.array_equal(b, ob), lit
         _, f2, _, _ = _device_run(fx, lit, fx.OP_SEARCH, rows, spans=False)
         assert np.array_equal(f2, of)
+
+
+def test_long_rows_on_tile_kernels(fx):
+    """Rows longer than 256 bytes (a multiple of 256): the tile kernels walk them in 256-byte segments (backward pass through the
+    LDS tile, forward pass from global memory); matches planted across segment borders, UTF-8 through the byte-level tables,
+    structurally invalid rows through the row-level fix-up, `.match.` and literal search."""
+    import random
+    rng = random.Random(41)
+    nrng = np.random.default_rng(41)
+    alpha = np.frombuffer(b"abcxyz .-_@\n", dtype=np.uint8)
+    pieces = [s.encode() for s in "あいうえおかんアイウαβγω"] + [b"a", b"z", b"0", b"7", b" ", b".", b"\x80", b"\xe3\x81", b"\xff", b"\xc3"]
+    for L in (512, 768, 1024, 2048):
+        n = 1500
+        rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+        seeds = [b"abc123", b"555-1234", b"needle in a hay", b"bob@mail.org", "あいう".encode(), b"zz9"]
+        for i in range(0, n, 3):
+            sd = np.frombuffer(seeds[(i // 3) % len(seeds)], dtype=np.uint8)
+            # around the segment borders as well as anywhere
+            off = int(nrng.integers(0, L - len(sd))) if i % 2 else int(256 * nrng.integers(1, L // 256) - nrng.integers(0, len(sd) + 1))
+            rows[i, off:off + len(sd)] = sd
+        mixed = np.stack([np.frombuffer((b"".join(rng.choice(pieces) for _ in range(L)))[:L], dtype=np.uint8) for _ in range(300)])
+        both = np.concatenate([rows[:700], mixed, rows[700:]])
+        for pat in (rb"[a-z]+\d+", rb"\d{3}-\d{4}", "[α-ωぁ-ん]+".encode(), b"needle in a hay", rb"\w+@\w+\.[a-z]+", rb"^[a-c]", rb"[0-9]$", "[ぁ-ん]+[0-9]*".encode()):
+            for data in (rows, both):
+                prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, data)
+                assert prog.last_path() != 2, (pat, L, prog.last_path())
+                of, oa, ob = oracle_lib.batch(2, pat, data, NT)
+                assert np.array_equal(f, of), (pat, L, prog.last_path())
+                assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L, prog.last_path())
+                _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, data, spans=False)
+                assert np.array_equal(f2, of), (pat, L, "flags-only")
+        # `.match.`: whole-row patterns
+        full = rows.copy()
+        full[::4] = np.frombuffer((b"ab" * (L // 2)), dtype=np.uint8)
+        for pat in (rb"(ab)+", rb"[a-z .@_\n-]+", rb"(ab)*a?", "[^あ]+".encode()):
+            for data in (full, np.concatenate([full[:200], mixed, full[200:400]])):
+                pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, data, spans=False)
+                assert pm.last_path() != 2, (pat, L, pm.last_path())
+                om, _, _ = oracle_lib.batch(1, pat, data, NT)
+                assert np.array_equal(fm, om), (pat, L, "match", pm.last_path())
+                assert int(om.sum()) > 0 or pat != rb"(ab)+"
