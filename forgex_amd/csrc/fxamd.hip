@@ -65,19 +65,24 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
    }
 }
 
-// Long rows (Lr a multiple of 256, > 256): the tile is walked in 256-byte SEGMENTS.  Piece q*64+lane of segment `seg` = row
+// Long rows (Lr a multiple of 16, > 256): the tile is walked in 256-byte SEGMENTS (one of them shorter when Lr % 256 != 0).  Piece q*64+lane of segment `seg` = row
 // 4q + lane/16, chunk lane%16 of that segment: 16 lanes read 256 contiguous bytes of one row.  Same buffer resource trick:
 // extent = the tile's valid bytes, the row / segment distance rides in the scalar offset (which the range check includes).
 __device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
-                                              uint32_t seg, bool enable) {
+                                              uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable) {
+   // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
+   // (k_lo, k_hi) = (0, 15); the short one of a row whose length is not a multiple of 256 sits RIGHT-aligned (search: k_lo = 16 - c,
+   // the backward loop stops there) or LEFT-aligned (`.match.`: k_hi = c - 1) and its other chunks repeat a neighbour (never walked).
    const int64_t rows_left = n - row0;
    const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u));
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)Lr;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
                                                                          __builtin_amdgcn_readfirstlane(valid), 0x00020000);
-   const uint32_t voff = (lane >> 4) * Lr + (lane & 15u) * 16u;
-   const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg * 256u);
+   uint32_t kc = lane & 15u;
+   kc = kc < k_lo ? k_lo : (kc > k_hi ? k_hi : kc);
+   const uint32_t voff = (lane >> 4) * Lr + (kc - k_lo) * 16u;
+   const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_byte);
 #pragma unroll
    for (int q = 0; q < 16; ++q) {
       const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)(4 * q) * Lr, FX_LOAD_AUX);
@@ -309,7 +314,18 @@ __device__ unsigned long long fx_stamp_acc[16];
       else if ((en) && (tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
    } while (0)
 
-#define PREFETCH_SEG(st, tn, sg, en) load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg), (en))
+__device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr);
+// segment sg of a long row, search order (the SHORT segment is the leftmost one, sg = 0, right-aligned in the tile)
+#define PREFETCH_SEG(st, tn, sg, en) \
+   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, seg_byte_search((sg), Lr), ((sg) == 0u && (Lr & 255u)) ? 16u - ((Lr & 255u) >> 4) : 0u, 15u, (en))
+// `.match.` order (the SHORT segment is the rightmost one, left-aligned in the tile)
+#define PREFETCH_SEG_FWD(st, tn, sg, en) \
+   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? ((Lr & 255u) >> 4) - 1u : 15u, (en))
+// first byte of segment sg when the short segment (Lr % 256 bytes) comes first
+__device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr) {
+   const uint32_t rem = Lr & 255u;
+   return sg == 0u ? 0u : (rem ? rem + (sg - 1u) * 256u : sg * 256u);
+}
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
@@ -332,7 +348,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
    // instantiation keeps the row length a compile-time constant (the hot path).
    const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;
-   const uint32_t S = LONG ? (Lr >> 8) : 1u;   // 256-byte segments per row
+   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;   // segments per row: 256 bytes each, the LEFTMOST one shorter when Lr % 256 != 0
    constexpr bool ragged = RAGGED;
    static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
@@ -494,13 +510,16 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             return;
          }
 #endif
-         const uint32_t gbase = LONG ? seg * 32u : 0u;   // 8-byte groups to the left of this segment
+         // 8-byte groups to the left of this segment's chunk 0 (the short segment sits right-aligned: its first chunks are not walked)
+         const uint32_t kmin = (LONG && seg == 0u && (Lr & 255u)) ? 16u - ((Lr & 255u) >> 4) : 0u;
+         const uint32_t gbase = LONG ? (seg_byte_search(seg, Lr) >> 3) - 2u * kmin : 0u;
          F fa[8], fb[8];
          uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
          if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
          lookup8(fa, wk.z, wk.w, tabR);
 #pragma unroll
          for (int k = CH - 1; k >= 0; --k) {
+            if (LONG && (uint32_t)k < kmin) break;   // wave-uniform: the short segment ends here (the lookups already issued for this chunk are dropped)
             if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
             lookup8(fb, wk.x, wk.y, tabR);
             __builtin_amdgcn_sched_barrier(0);
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
                                                        uint32_t* __restrict__ worklist) {
    const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
-   const uint32_t S = LONG ? (Lr >> 8) : 1u;                // LONG: 256-byte segments per row, walked left to right through the same tile
+   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;       // LONG: 256-byte segments per row (the last one shorter when Lr % 256 != 0), left to right
    constexpr bool ragged = RAGGED;
    static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
@@ -787,7 +806,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    bool live = true;   // the tile in `stage` is to be scanned (always, except in the marked-tile passes)
    if (!LIST) {
       live = MARKED ? tile_marked(wave_global) : true;
-      if constexpr (LONG) PREFETCH_SEG(stage, wave_global, 0u, live);
+      if constexpr (LONG) PREFETCH_SEG_FWD(stage, wave_global, 0u, live);
       else PREFETCH_TILE(stage, wave_global, live);
    }
    for (int64_t t = wave_global; LIST ? (uint64_t)(t << 6) < list_count : t < n_tiles; t += wave_stride) {
@@ -821,7 +840,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
             const bool last = !LONG || !process || defer_early || seg + 1u == S;   // nothing more of this tile is wanted
             if (last) live = MARKED ? tile_marked(t + wave_stride) : true;
             // the one reload site of the staging registers
-            if constexpr (LONG) PREFETCH_SEG(stage, last ? t + wave_stride : t, last ? 0u : seg + 1u, last ? live : true);
+            if constexpr (LONG) PREFETCH_SEG_FWD(stage, last ? t + wave_stride : t, last ? 0u : seg + 1u, last ? live : true);
             else PREFETCH_TILE(stage, t + wave_stride, live);
             if (!process) {
                skip = true;
@@ -860,8 +879,9 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
          if (CH >= 2) wn = tile[tile_cell(lane, 1)];
          lookup8(fa, wk.x, wk.y, tabA);
+         const int nch = (LONG && (seg + 1u) * 256u > Lr) ? (int)((Lr & 255u) >> 4) : CH;   // chunks of this segment
 #pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
-         for (int k = 0; k < CH; ++k) {
+         for (int k = 0; k < nch; ++k) {
             if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
             lookup8(fb, wk.z, wk.w, tabA);
             __builtin_amdgcn_sched_barrier(0);
@@ -1077,8 +1097,8 @@ static int tile_chunks(int64_t row_len) {
       if (row_len <= 16 * c) return c;
    return 0;
 }
-// long rows: a multiple of 256 bytes, walked segment by segment by the CH = 16 instantiations
-static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536 && (row_len & 255) == 0; }
+// long rows: a multiple of 16 bytes, walked in 256-byte segments by the CH = 16 instantiations
+static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536 && (row_len & 15) == 0; }
 static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : tile_chunks(row_len); }
 // MODE: 0 first pass, 1 decode second pass, 2 byte-level tables over all tiles, 3 byte-level tables over marked tiles
 // n_deferred: this call's two words ([0] tiles deferred, [1] exception rows left); the other call parity's pair is 8 bytes away

@@ -428,7 +428,7 @@ def test_literal_index_search_on_tile_kernel(fx):
 
 
 def test_long_rows_on_tile_kernels(fx):
-    """Rows longer than 256 bytes (a multiple of 256): the tile kernels walk them in 256-byte segments (backward pass through the
+    """Rows longer than 256 bytes (a multiple of 16): the tile kernels walk them in 256-byte segments (backward pass through the
     LDS tile, forward pass from global memory); matches planted across segment borders, UTF-8 through the byte-level tables,
     structurally invalid rows through the row-level fix-up, `.match.` and literal search."""
     import random
@@ -436,14 +436,15 @@ def test_long_rows_on_tile_kernels(fx):
     nrng = np.random.default_rng(41)
     alpha = np.frombuffer(b"abcxyz .-_@\n", dtype=np.uint8)
     pieces = [s.encode() for s in "あいうえおかんアイウαβγω"] + [b"a", b"z", b"0", b"7", b" ", b".", b"\x80", b"\xe3\x81", b"\xff", b"\xc3"]
-    for L in (512, 768, 1024, 2048):
+    for L in (512, 1024, 2048, 272, 400, 1008, 784):   # multiples of 256 and of 16 (one shorter segment)
         n = 1500
         rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
         seeds = [b"abc123", b"555-1234", b"needle in a hay", b"bob@mail.org", "あいう".encode(), b"zz9"]
         for i in range(0, n, 3):
             sd = np.frombuffer(seeds[(i // 3) % len(seeds)], dtype=np.uint8)
             # around the segment borders as well as anywhere
-            off = int(nrng.integers(0, L - len(sd))) if i % 2 else int(256 * nrng.integers(1, L // 256) - nrng.integers(0, len(sd) + 1))
+            border = (L % 256) + 256 * int(nrng.integers(0, L // 256)) if L % 256 else 256 * int(nrng.integers(1, L // 256))   # a segment border
+            off = int(nrng.integers(0, L - len(sd))) if i % 2 else max(0, min(L - len(sd), border - int(nrng.integers(0, len(sd) + 1))))
             rows[i, off:off + len(sd)] = sd
         mixed = np.stack([np.frombuffer((b"".join(rng.choice(pieces) for _ in range(L)))[:L], dtype=np.uint8) for _ in range(300)])
         both = np.concatenate([rows[:700], mixed, rows[700:]])
