@@ -2,6 +2,7 @@
 #include "compile.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -164,6 +165,19 @@ Sig sig_shrink(const Sig& s, uint32_t v, uint32_t limit) {
    return o;
 }
 
+// the class function with everything outside [lo, hi) marked -1 ("not encodable at this length")
+Sig sig_restrict(const Sig& full, uint32_t lo, uint32_t hi) {
+   Sig o;
+   if (lo > 0) o.emplace_back(0u, -1);
+   o.emplace_back(lo, sig_eval(full, lo));
+   for (const auto& pr : full)
+      if (pr.first > lo && pr.first < hi) o.push_back(pr);
+   o.emplace_back(hi, -1);
+   sig_normalise(o);
+   return o;
+}
+bool sig_all_invalid(const Sig& sg) { return sg.size() == 1 && sg[0].second < 0; }
+
 struct ByteDfa {
    Dfa d;                  // ncol = 256 until the byte classes are merged
    std::vector<int> fin;   // verdict at the end of a row: 0 / 1, 2 = redo by the decode pass (inside a character, INVALID)
@@ -207,6 +221,10 @@ ByteDfa build_forward_bytes(const ClassDfaView& A, const Sig& full, const std::v
    state_of(0, 0);   // state 0 = dead
    const int init = state_of(A.init, 0);
    const int inv = invalid_sink ? state_of(-1, 0) : 0;
+   // Only CANONICAL sequences are modelled (shortest form, <= U+10FFFF): the reference decodes overlong and out-of-range forms
+   // arithmetically too, but they are as good as absent from real text and cost states; like structure errors they lead to
+   // INVALID and the decode pass answers the row exactly.
+   const Sig canon[3] = {sig_restrict(full, 0x80u, 0x800u), sig_restrict(full, 0x800u, 0x10000u), sig_restrict(full, 0x10000u, 0x110000u)};
    std::vector<int> T;
    for (size_t s = 0; s < keys.size(); ++s) {
       if (static_cast<int>(keys.size()) > kMaxByteStates) return r;
@@ -223,15 +241,17 @@ ByteDfa build_forward_bytes(const ClassDfaView& A, const Sig& full, const std::v
                const int rem = b < 0xE0 ? 1 : (b < 0xF0 ? 2 : 3);
                const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
                const uint32_t span = 1u << (6 * rem);
-               dst = state_of(q, intern(rem, sig_slice(full, pay * span, (pay + 1) * span)));
+               Sig sub = sig_slice(canon[rem - 1], pay * span, (pay + 1) * span);
+               dst = sig_all_invalid(sub) ? inv : state_of(q, intern(rem, std::move(sub)));   // C0, C1, F5..F7: nothing canonical starts here
             }
          } else {
             const int rem = nodes[static_cast<size_t>(nd)].first;
             if (b < 0x80 || b >= 0xC0) dst = inv;
             else {
                const uint32_t v = static_cast<uint32_t>(b) & 0x3Fu, span = 1u << (6 * (rem - 1));
-               const Sig sub = sig_slice(nodes[static_cast<size_t>(nd)].second, v * span, (v + 1) * span);
-               dst = rem == 1 ? state_of(A.T(q, sub[0].second), 0) : state_of(q, intern(rem - 1, sub));
+               Sig sub = sig_slice(nodes[static_cast<size_t>(nd)].second, v * span, (v + 1) * span);
+               if (sig_all_invalid(sub)) dst = inv;   // overlong form / beyond U+10FFFF
+               else dst = rem == 1 ? state_of(A.T(q, sub[0].second), 0) : state_of(q, intern(rem - 1, std::move(sub)));
             }
          }
          T[s * 256 + static_cast<size_t>(b)] = dst;
@@ -249,9 +269,9 @@ ByteDfa build_forward_bytes(const ClassDfaView& A, const Sig& full, const std::v
       if (q > 0 && nd == 0) {
          r.d.out[static_cast<size_t>(s)] = (*A.out)[static_cast<size_t>(q)];
          fin[static_cast<size_t>(s)] = fin_class[static_cast<size_t>(q)];
-      } else if (q != 0) {
-         fin[static_cast<size_t>(s)] = 2;
-      }
+      } else if (q != 0 && invalid_sink) {
+         fin[static_cast<size_t>(s)] = 2;   // (`.match.` only: a search never asks where its forward walk stopped, and without the
+      }                                     //  label a continuation node whose every path dies merges with the dead state)
       labels[static_cast<size_t>(s)] = fin[static_cast<size_t>(s)] + (q < 0 ? 4 : 0);
    }
    std::vector<int> o2n;
@@ -268,10 +288,14 @@ ByteDfa build_forward_bytes(const ClassDfaView& A, const Sig& full, const std::v
 // characters, else (k continuation bytes seen, class of the character as a function of the payload bits still to come)
 ByteDfa build_reverse_bytes(const ClassDfaView& R, const Sig& full) {
    ByteDfa r;
-   std::vector<std::pair<int, Sig>> nodes{{0, Sig{}}};
-   std::map<std::pair<int, Sig>, int> node_id{{nodes[0], 0}};
-   auto intern = [&](int k, Sig sg) {
-      auto key = std::make_pair(k, std::move(sg));
+   // node: k continuation bytes seen, and for every length n = k+1 .. 4 the character could still have, its class as a function
+   // of the payload bits still to come -- derived from the class function restricted to what is CANONICAL at that length (see
+   // build_forward_bytes), so an overlong or out-of-range form evaluates to -1 when its lead byte arrives
+   using Node = std::pair<int, std::array<Sig, 3>>;
+   std::vector<Node> nodes{Node{0, {}}};
+   std::map<Node, int> node_id{{nodes[0], 0}};
+   auto intern = [&](int k, std::array<Sig, 3> sg) {
+      Node key{k, std::move(sg)};
       auto it = node_id.find(key);
       if (it != node_id.end()) return it->second;
       nodes.push_back(key);
@@ -290,6 +314,17 @@ ByteDfa build_reverse_bytes(const ClassDfaView& R, const Sig& full) {
    };
    const int init = state_of(R.init, 0);
    const int inv = state_of(-1, 0);
+   const std::array<Sig, 3> canon = {sig_restrict(full, 0x80u, 0x800u), sig_restrict(full, 0x800u, 0x10000u), sig_restrict(full, 0x10000u, 0x110000u)};
+   // k continuation bytes seen -> k + 1: the lengths still possible are n >= k + 2 (index i = n - 2 >= k); each takes the payload
+   auto shrink_all = [&](const std::array<Sig, 3>& from, int k, uint32_t v) {
+      std::array<Sig, 3> o;
+      bool any = false;
+      for (int i = k; i < 3; ++i) {
+         o[static_cast<size_t>(i)] = sig_shrink(from[static_cast<size_t>(i)], v, 1u << (21 - 6 * (k + 1)));
+         if (!sig_all_invalid(o[static_cast<size_t>(i)])) any = true;
+      }
+      return std::make_pair(o, any);
+   };
    std::vector<int> T;
    for (size_t s = 0; s < keys.size(); ++s) {
       if (static_cast<int>(keys.size()) > kMaxByteStates) return r;
@@ -301,15 +336,26 @@ ByteDfa build_reverse_bytes(const ClassDfaView& R, const Sig& full) {
          if (q < 0) dst = static_cast<int>(s);
          else if (nd == 0) {
             if (b < 0x80) dst = state_of(R.T(q, sig_eval(full, static_cast<uint32_t>(b))), 0);
-            else if (cont) dst = state_of(q, intern(1, sig_shrink(full, static_cast<uint32_t>(b) & 0x3Fu, 1u << 15)));
-            else dst = inv;   // a lead byte with nothing behind it, F8..FF
+            else if (cont) {
+               auto pr = shrink_all(canon, 0, static_cast<uint32_t>(b) & 0x3Fu);
+               dst = pr.second ? state_of(q, intern(1, std::move(pr.first))) : inv;
+            } else dst = inv;   // a lead byte with nothing behind it, F8..FF
          } else {
             const int k = nodes[static_cast<size_t>(nd)].first;
-            if (cont) dst = k == 3 ? inv : state_of(q, intern(k + 1, sig_shrink(nodes[static_cast<size_t>(nd)].second, static_cast<uint32_t>(b) & 0x3Fu, 1u << (21 - 6 * (k + 1)))));
-            else if (lead) {
+            if (cont) {
+               if (k == 3) dst = inv;
+               else {
+                  auto pr = shrink_all(nodes[static_cast<size_t>(nd)].second, k, static_cast<uint32_t>(b) & 0x3Fu);
+                  dst = pr.second ? state_of(q, intern(k + 1, std::move(pr.first))) : inv;
+               }
+            } else if (lead) {
                const int len = b < 0xE0 ? 2 : (b < 0xF0 ? 3 : 4);
                const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
-               dst = len - 1 == k ? state_of(R.T(q, sig_eval(nodes[static_cast<size_t>(nd)].second, pay)), 0) : inv;
+               if (len - 1 != k) dst = inv;
+               else {
+                  const int c = sig_eval(nodes[static_cast<size_t>(nd)].second[static_cast<size_t>(len - 2)], pay);
+                  dst = c < 0 ? inv : state_of(R.T(q, c), 0);
+               }
             } else dst = inv;   // continuation bytes without their lead
          }
          T[s * 256 + static_cast<size_t>(b)] = dst;
@@ -935,12 +981,57 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       h.off_chain_TA = bl.put(cta.data(), cta.size() * 2);
    }
 
+   // ---- 8b. 16-state v_perm tables for automata with 9..16 states (same conditions as the 8-state fast tables) ----------------------
+   auto enc16 = [](int i) -> uint8_t { return static_cast<uint8_t>(i < 8 ? i : 0x80 + i - 8); };
+   auto min16 = [&](int first_out, int n) -> uint32_t { return first_out >= n ? 0xFFu : enc16(first_out); };   // "no such state": never reached
+   {
+      const bool w16 = !fast && (is_match ? A.n <= 16 : (brute_equiv && A.n <= 16 && R.n <= 16));
+      std::vector<uint8_t> wa(256 * 16, 0), wr(256 * 16, 0);
+      if (w16) {
+         auto put = [&](uint32_t sym, int c_or_neg, bool skip) {   // one symbol row of both tables; c < 0: all-dead (KILL)
+            for (int st = 0; st < 16; ++st) {
+               int ta = 0, tr = 0;
+               if (skip) {
+                  ta = st < A.n ? st : 0;
+                  tr = (is_match || st >= R.n) ? 0 : (r_has_skip ? R.T[static_cast<size_t>(st) * R.ncol + nI] : st);
+               } else if (c_or_neg >= 0) {
+                  ta = st < A.n ? TA(st, c_or_neg) : 0;
+                  tr = (!is_match && st < R.n) ? TR(st, c_or_neg) : 0;
+               }
+               wa[sym * 16 + static_cast<uint32_t>(st)] = enc16(ta);
+               wr[sym * 16 + static_cast<uint32_t>(st)] = enc16(tr);
+            }
+         };
+         for (uint32_t b = 0; b < 128; ++b) put(b, ac[b], false);
+         h.flags |= FXP_F_W16_OK | FXP_F_RAGGED_OK;
+         if ((is_match || (r_has_skip && !prefilter)) && ncls <= 126) {
+            h.flags |= FXP_F_W16_UTF8;
+            for (int c = 0; c < ncls; ++c) put(128u + static_cast<uint32_t>(c), c, false);
+         }
+         put(255u, 0, true);
+         int accmin = A.n, hitmin = is_match ? 0 : R.n;
+         for (int st = A.n - 1; st >= 0 && A.out[static_cast<size_t>(st)]; --st) accmin = st;
+         if (!is_match)
+            for (int st = R.n - 1; st >= 0 && R.out[static_cast<size_t>(st)]; --st) hitmin = st;
+         h.w16_acc_min = min16(accmin, A.n);
+         h.w16_hit_min = is_match ? 0xFFu : min16(hitmin, R.n);
+         h.w16_R_start = enc16(static_cast<int>(h.R_start));
+         h.w16_A_init = enc16(static_cast<int>(is_match ? h.M_start : h.A_init));
+         uint8_t fm[16] = {0};
+         for (int st = 0; st < A.n && st < 16; ++st) fm[st] = fin[static_cast<size_t>(st)];
+         std::memcpy(h.w16_finalM, fm, 16);
+      }
+      h.off_w16A = bl.put(wa.data(), w16 ? wa.size() : 0);
+      h.off_w16R = bl.put(wr.data(), w16 ? wr.size() : 0);
+   }
+
    // ---- 9. byte-level chain tables: A and R composed with the UTF-8 decoder (no decode pass on the device) ---------------------
    // Only where the tile kernels' brute-force semantics hold for non-ASCII rows too: `.match.`, or a search without a
    // prefilter literal (the candidate list is an INDEX over raw bytes, api_internal_m.F90:76-104).
    {
       std::vector<uint16_t> bcm(256, 0), btr, bta;
-      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK)) != 0 && (is_match || (brute_equiv && !prefilter));
+      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || (brute_equiv && !prefilter));
+      std::vector<uint8_t> bwa, bwr;
       if (want) {
          Sig full;
          for (int k = 0; k < nI; ++k) full.emplace_back(static_cast<uint32_t>(bounds[static_cast<size_t>(k)]), cls_of[static_cast<size_t>(k)]);
@@ -1006,12 +1097,34 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                h.byte_TR_bytes = static_cast<uint32_t>(btr.size() * 2);
                h.byte_inv_A = Ab.inv >= 0 ? static_cast<uint32_t>(Ab.inv) * row_bytes : 0u;
                h.byte_inv_R = is_match ? 0u : static_cast<uint32_t>(Rb.inv) * row_bytes;
+               // the same automata in the 16-state v_perm format, indexed by the raw byte
+               if (Ab.d.n <= 16 && (is_match || Rb.d.n <= 16)) {
+                  bwa.assign(256 * 16, 0);
+                  bwr.assign(256 * 16, 0);
+                  for (int b = 0; b < 256; ++b)
+                     for (int st2 = 0; st2 < 16; ++st2) {
+                        bwa[static_cast<size_t>(b) * 16 + st2] = enc16(st2 < Ab.d.n ? Ab.d.T[static_cast<size_t>(st2) * 256 + b] : 0);
+                        bwr[static_cast<size_t>(b) * 16 + st2] = enc16((!is_match && st2 < Rb.d.n) ? Rb.d.T[static_cast<size_t>(st2) * 256 + b] : 0);
+                     }
+                  h.flags |= FXP_F_BYTE_W16;
+                  h.bw16_acc_min = min16(accmin, Ab.d.n);
+                  h.bw16_hit_min = is_match ? 0xFFu : min16(hitmin, Rb.d.n);
+                  h.bw16_A_init = enc16(Ab.d.init);
+                  h.bw16_R_start = is_match ? 0u : enc16(Rb.d.init);
+                  h.bw16_inv_A = Ab.inv >= 0 ? enc16(Ab.inv) : 0u;
+                  h.bw16_inv_R = is_match ? 0u : enc16(Rb.inv);
+                  uint8_t fm[16] = {0};
+                  for (int st2 = 0; st2 < Ab.d.n; ++st2) fm[st2] = static_cast<uint8_t>(Ab.fin[static_cast<size_t>(st2)]);
+                  std::memcpy(h.bw16_finalM, fm, 16);
+               }
             }
          }
       }
       h.off_byte_cls = bl.put(bcm.data(), bcm.size() * 2);
       h.off_byte_TR = bl.put(btr.data(), btr.size() * 2);
       h.off_byte_TA = bl.put(bta.data(), bta.size() * 2);
+      h.off_bw16A = bl.put(bwa.data(), bwa.size());
+      h.off_bw16R = bl.put(bwr.data(), bwr.size());
    }
    return finish(h, bl);
 }

@@ -609,45 +609,54 @@ FX_HD void run_row(const ProgView& pv, Sim& sim, const Row& r, int L, Result& ou
 // (backward pass of R over the raw bytes for the leftmost start, forward pass of A for the longest end; `.match.`: one
 // forward pass and the FINAL column).  Returns 0 = `out` is the row's result, 1 = the row must be redone by the decode
 // path (structurally invalid UTF-8), -1 = the program has no byte tables / the row is outside the tile kernels' domain.
+// `w16`: walk the 16-state v_perm format of the same automata instead (states are encoded bytes: i < 8 -> i, else 0x80 + i - 8)
 template <class Row>
-FX_HD int byte_tables_row(const uint8_t* base, const Row& r, int L, Result& out) {
+FX_HD int byte_tables_row(const uint8_t* base, const Row& r, int L, Result& out, bool w16 = false) {
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(base);
    if (!(h->flags & FXP_F_BYTE_DFA) || L < 1 || (L == 1 && r[0] == 0x20u)) return -1;   // (empty / single-blank text: api_internal_m.F90:68-74)
+   if (w16 && !(h->flags & FXP_F_BYTE_W16)) return -1;
    const uint16_t* cmap = reinterpret_cast<const uint16_t*>(base + h->off_byte_cls);
-   const uint8_t *TRp = base + h->off_byte_TR, *TAp = base + h->off_byte_TA;
-   auto step = [&](const uint8_t* T, uint32_t st, uint32_t byte) -> uint32_t { return *reinterpret_cast<const uint16_t*>(T + st + cmap[byte]); };
+   const uint8_t *TRp = base + (w16 ? h->off_bw16R : h->off_byte_TR), *TAp = base + (w16 ? h->off_bw16A : h->off_byte_TA);
+   auto step = [&](const uint8_t* T, uint32_t st, uint32_t byte) -> uint32_t {
+      if (w16) return T[byte * 16u + (st < 8u ? st : st - 0x80u + 8u)];
+      return *reinterpret_cast<const uint16_t*>(T + st + cmap[byte]);
+   };
+   const uint32_t A_init = w16 ? h->bw16_A_init : h->byte_A_init, R_start = w16 ? h->bw16_R_start : h->byte_R_start;
+   const uint32_t hit_min = w16 ? h->bw16_hit_min : h->byte_hit_min, acc_min = w16 ? h->bw16_acc_min : h->byte_acc_min;
+   const uint32_t inv_R = w16 ? h->bw16_inv_R : h->byte_inv_R;
    out.flag = 0;
    out.from = 0;
    out.to = 0;
    if (h->mode == FXP_MODE_MATCH_ENGINE) {
       auto row = [&](uint32_t j) -> uint32_t { return r[static_cast<int>(j)]; };
       const uint32_t gate = match_gate(h, base, row, static_cast<uint32_t>(L));
-      uint32_t st = h->byte_A_init;
+      uint32_t st = A_init;
       for (int j = 0; j < L; ++j) st = step(TAp, st, r[j]);
-      const uint32_t fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * (h->byte_n_classes + 2u));
+      const uint32_t fin = w16 ? reinterpret_cast<const uint8_t*>(h->bw16_finalM)[st < 8u ? st : st - 0x80u + 8u]
+                               : *reinterpret_cast<const uint16_t*>(TAp + st + 2u * (h->byte_n_classes + 2u));
       if (gate == 2u) out.flag = 1;
       else if (gate == 0u) out.flag = 0;
       else if (st != 0 && fin == 2u) return 1;
       else out.flag = (st != 0 && fin == 1u) ? 1u : 0u;
       return 0;
    }
-   uint32_t state = h->byte_R_start, s = 0;
+   uint32_t state = R_start, s = 0;
    for (int j = L - 1; j >= 0; --j) {
       state = step(TRp, state, r[j]);
-      if (state >= h->byte_hit_min) s = static_cast<uint32_t>(j) + 2u;
+      if (state >= hit_min) s = static_cast<uint32_t>(j) + 2u;
    }
    state = step(TRp, state, 0u);   // leading NUL
-   if (state >= h->byte_hit_min) s = 1;
-   if (state == h->byte_inv_R) return 1;
+   if (state >= hit_min) s = 1;
+   if (state == inv_R) return 1;
    if (s == 0) return 0;
-   uint32_t cur = h->byte_A_init, mm = 0, j = s >= 2 ? s - 2 : 0;
+   uint32_t cur = A_init, mm = 0, j = s >= 2 ? s - 2 : 0;
    if (s == 1) {
       cur = step(TAp, cur, 0u);
-      mm = cur >= h->byte_acc_min ? 2u : 0u;
+      mm = cur >= acc_min ? 2u : 0u;
    }
    while (cur != 0 && j <= static_cast<uint32_t>(L)) {   // position L holds the trailing NUL, later positions kill the state
       cur = step(TAp, cur, j < static_cast<uint32_t>(L) ? r[static_cast<int>(j)] : 0u);
-      if (cur >= h->byte_acc_min) mm = j + 3u;
+      if (cur >= acc_min) mm = j + 3u;
       ++j;
    }
    if (mm != 0) {   // api_internal_m.F90:140-148

@@ -37,7 +37,7 @@ def main():
             txt = b"".join(rng.choice(PIECES[:26]) for _ in range(rng.randint(1, 14)))
         cases.append((rng.choice(["I", "M", "R", "R"]), pat.encode(), txt))
     a = run_protocol(ORACLE_CLI, cases)
-    os.environ["FX_HW_BYTES"] = "1"
+    os.environ.setdefault("FX_HW_BYTES", "1")
     b = run_protocol(HOST_WALK, cases)
     bad = unsup = 0
     for c, x, y in zip(cases, a, b):

@@ -23,7 +23,9 @@ long g_byte_rows = 0, g_byte_exceptions = 0;   // FX_HW_BYTES=1: rows answered b
 void run_any(const fxrow::ProgView& pv, const fxc::Program& p, const HostRow& r, int L, fxrow::Result& res) {
    static const bool use_bytes = std::getenv("FX_HW_BYTES") != nullptr;
    if (use_bytes && (p.hdr().flags & FXP_F_BYTE_DFA)) {   // what the tile kernels' BYTES modes compute; exceptions fall through
-      const int rc = fxrow::byte_tables_row(p.blob.data(), r, L, res);
+      static const bool w16 = std::getenv("FX_HW_BYTES") && std::string(std::getenv("FX_HW_BYTES")) == "w16";   // the 16-state v_perm format
+      int rc = fxrow::byte_tables_row(p.blob.data(), r, L, res, w16);
+      if (rc == -1 && w16) rc = fxrow::byte_tables_row(p.blob.data(), r, L, res, false);
       if (rc == 0) {
          ++g_byte_rows;
          return;
