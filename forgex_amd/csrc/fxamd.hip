@@ -185,16 +185,26 @@ __device__ __forceinline__ void lookup8(F* __restrict__ f, uint32_t lo, uint32_t
    for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
 }
 __device__ __forceinline__ uint32_t fxstep(uint2 f, uint32_t st, const uint8_t*) { return __builtin_amdgcn_perm(f.y, f.x, st); }
+// wide scheme: F = 16 encoded next-state bytes (states 0..7 in x,y; 8..15 in z,w); the state byte is i (i < 8) or 0x80 + i - 8.
+// v_perm_b32 delivers 0xFF for a selector byte >= 13, so the half that does not hold the current state drops out of the AND.
+__device__ __forceinline__ uint32_t fxstep(uint4 f, uint32_t st, const uint8_t*) {
+   return __builtin_amdgcn_perm(f.y, f.x, st) & __builtin_amdgcn_perm(f.w, f.z, st ^ 0x80808080u);
+}
 __device__ __forceinline__ uint32_t fxstep(uint32_t f, uint32_t st, const uint8_t* T) {
    return *reinterpret_cast<const uint16_t*>(T + st + f);
 }
-template <bool CHAIN>
+// table scheme SCH: 0 = v_perm (<= 8 states), 1 = LDS chain, 2 = wide v_perm (<= 16 states, two v_perm_b32 per byte)
+template <int SCH>
 struct FxF {
    using type = uint2;
 };
 template <>
-struct FxF<true> {
+struct FxF<1> {
    using type = uint32_t;
+};
+template <>
+struct FxF<2> {
+   using type = uint4;
 };
 
 // Right-to-left state chain over 8 bytes.  All four bytes of `state` carry the same state id (v_perm_b32 advances four
@@ -340,7 +350,7 @@ __device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr) {
 // n_deferred points at this call's two words: [0] "a first pass deferred tiles", [1] number of exception rows in `worklist`.
 // LONG: rows longer than 256 bytes (a multiple of 256), CH = 16: the backward pass walks the row segment by segment through the
 // same LDS tile, the short forward pass reads its bytes straight from global memory.  First-pass and BYTES modes only.
-template <int CH, bool SPANS, int MODE, bool CHAIN, bool RAGGED, bool LONG = false>
+template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
@@ -351,8 +361,9 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;   // segments per row: 256 bytes each, the LEFTMOST one shorter when Lr % 256 != 0
    constexpr bool ragged = RAGGED;
    static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
+   constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
-   static_assert(!BYTES || (CHAIN && !RAGGED), "byte-level tables use the chain scheme on whole chunks");
+   static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
    static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
    if ((MARKED || LIST) && n_deferred[fp.gate_word] == 0) return;   // nothing was left for this pass
    // the "something was deferred" words of consecutive calls alternate: this call's first pass zeroes the NEXT call's word (no
@@ -361,9 +372,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       clear_next[0] = 0u;
       clear_next[1] = 0u;
    }
-   using F = typename FxF<CHAIN>::type;
-   __shared__ uint2 permR[CHAIN ? 1 : 256];
-   __shared__ uint2 permA[CHAIN ? 1 : 256];
+   using F = typename FxF<SCH>::type;
+   __shared__ uint2 permR[SCH == 0 ? 256 : 1];
+   __shared__ uint2 permA[SCH == 0 ? 256 : 1];
+   __shared__ uint4 wideR[WIDE ? 256 : 1];
+   __shared__ uint4 wideA[WIDE ? 256 : 1];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
@@ -378,6 +391,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
       const uint32_t nr = tr_bytes / 2, na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+   } else if (WIDE) {
+      const uint4* gR = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16R : h->off_w16R));
+      const uint4* gA = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16A : h->off_w16A));
+      wideR[threadIdx.x] = gR[threadIdx.x];
+      wideA[threadIdx.x] = gA[threadIdx.x];
    } else {
       const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
       const uint2* gA = reinterpret_cast<const uint2*>(prog + h->off_fastA);
@@ -387,9 +405,9 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    }
    __syncthreads();
    // symbol -> F tables of the two directions (the chain scheme shares one class map)
-   using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
-   const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permR);
-   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
+   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+   const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideR) : reinterpret_cast<const TabT*>(permR));
+   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
    const bool raw = BYTES || (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search, byte-level tables: bytes are symbols, nothing is decoded or deferred
    const bool utf8 = !raw && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
@@ -609,25 +627,29 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          // are kept and the last accepting group is re-walked for the exact byte.
          uint32_t o[8];
          fetch32<RAGGED, LONG>(o, fsrc, lane, j, (uint32_t)L);
-         F f[32];
-#pragma unroll
-         for (int g = 0; g < 4; ++g) lookup8(&f[8 * g], o[2 * g], o[2 * g + 1], tabA);
+         constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
          uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
-         for (int g = 0; g < 4; ++g) {
-            const uint32_t entry = cur;
-            uint32_t st[8];
+         for (int gb = 0; gb < 4; gb += GB) {
+            F f[8 * GB];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-               cur = fxstep(f[8 * g + q], cur, TAp);
-               st[q] = cur;
+            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+               const uint32_t entry = cur;
+               uint32_t st[8];
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f[8 * g + q], cur, TAp);
+                  st[q] = cur;
+               }
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool hit = mx >= fp.acc_min;
+               gl = hit ? (uint32_t)(gb + g) : gl;
+               el = hit ? entry : el;
+               blo = hit ? o[2 * (gb + g)] : blo;
+               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
             }
-            const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-            const bool hit = mx >= fp.acc_min;
-            gl = hit ? (uint32_t)g : gl;
-            el = hit ? entry : el;
-            blo = hit ? o[2 * g] : blo;
-            bhi = hit ? o[2 * g + 1] : bhi;
          }
          {
             F fr8[8];
@@ -741,7 +763,7 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
 
 // MODE as in fx_search_fast (BYTES modes: a row whose walk ends inside a character or in the INVALID state -- FINAL column 2 -- is
 // left to the row-level fix-up)
-template <int CH, int MODE, bool CHAIN, bool RAGGED, bool LONG = false>
+template <int CH, int MODE, int SCH, bool RAGGED, bool LONG = false>
 __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
@@ -750,16 +772,18 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;       // LONG: 256-byte segments per row (the last one shorter when Lr % 256 != 0), left to right
    constexpr bool ragged = RAGGED;
    static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
+   constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
-   static_assert(!BYTES || (CHAIN && !RAGGED), "byte-level tables use the chain scheme on whole chunks");
+   static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
    static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
    if ((MARKED || LIST) && n_deferred[fp.gate_word] == 0) return;
    if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
       clear_next[0] = 0u;
       clear_next[1] = 0u;
    }
-   using F = typename FxF<CHAIN>::type;
-   __shared__ uint2 permA[CHAIN ? 1 : 256];
+   using F = typename FxF<SCH>::type;
+   __shared__ uint2 permA[SCH == 0 ? 256 : 1];
+   __shared__ uint4 wideA[WIDE ? 256 : 1];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
@@ -771,12 +795,14 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
       const uint32_t na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + na; i += 256u) cmap[i] = i < 256u ? g[i] : ga[i - 256u];
+   } else if (WIDE) {
+      wideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16A : h->off_w16A))[threadIdx.x];
    } else {
       permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
    }
    __syncthreads();
-   using TabT = typename std::conditional<CHAIN, uint16_t, uint2>::type;
-   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : reinterpret_cast<const TabT*>(permA);
+   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const bool utf8 = !BYTES && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
@@ -901,7 +927,10 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
       if (skip) continue;
       uint32_t fin;
       if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * ((BYTES ? h->byte_n_classes : h->n_classes) + 2u));   // FINAL column
-      else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
+      else if (WIDE) {
+         const uint32_t* fm = BYTES ? h->bw16_finalM : h->w16_finalM;
+         fin = fxstep(make_uint4(fm[0], fm[1], fm[2], fm[3]), st, nullptr) & 3u;
+      } else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
       uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin == 1u ? 1u : 0u));
       const bool row_hi = MODE == 0 && (na & 0x80808080u) != 0;
       const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
@@ -1102,7 +1131,7 @@ static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536
 static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : tile_chunks(row_len); }
 // MODE: 0 first pass, 1 decode second pass, 2 byte-level tables over all tiles, 3 byte-level tables over marked tiles
 // n_deferred: this call's two words ([0] tiles deferred, [1] exception rows left); the other call parity's pair is 8 bytes away
-template <int CH, int MODE, bool CHAIN>
+template <int CH, int MODE, int SCH>
 static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
                               int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
    uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);   // the other parity's pair (16-byte aligned block)
@@ -1117,7 +1146,7 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
    const bool spans = from && to;
    if (Lr > 256u) {   // long rows (a multiple of 256 bytes): segment-walking instantiation, CH = 16, first-pass / byte-level modes only
       if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
-         constexpr bool CHN = MODE == 0 ? CHAIN : true;
+         constexpr int CHN = SCH;
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<16, true, MODE, CHN, false, true>)
                                 : reinterpret_cast<const void*>(&fx_search_fast<16, false, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
@@ -1132,7 +1161,7 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
       }
    }
    if constexpr (MODE >= 2) {   // whole-chunk rows only: byte-level tables (2, 3: chain scheme) and the worklist decode pass (4)
-      constexpr bool CHN = MODE == 4 ? CHAIN : true;
+      constexpr int CHN = SCH;
       if (ragged) return hipErrorInvalidValue;   // (never dispatched)
       const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false>)
                              : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false>);
@@ -1144,26 +1173,26 @@ static hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_b
       else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
       return hipGetLastError();
    } else {
-      const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHAIN, true>)
-                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHAIN, true>))
-                              : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHAIN, false>)
-                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHAIN, false>));
+      const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, true>)
+                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, true>))
+                              : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, false>)
+                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, false>));
       if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
          hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e != hipSuccess) return e;
       }
       if (ragged) {
-         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
-         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
       } else {
-         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
-         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
       }
       return hipGetLastError();
    }
 }
 
-template <int CH, int MODE, bool CHAIN>
+template <int CH, int MODE, int SCH>
 static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
                                uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
    uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);
@@ -1175,7 +1204,7 @@ static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_
    const bool ragged = Lr != 16u * CH;
    if (Lr > 256u) {   // long rows
       if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
-         constexpr bool CHN = MODE == 0 ? CHAIN : true;
+         constexpr int CHN = SCH;
          const void* fn = reinterpret_cast<const void*>(&fx_match_fast<16, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1188,7 +1217,7 @@ static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_
       }
    }
    if constexpr (MODE >= 2) {
-      constexpr bool CHN = MODE == 4 ? CHAIN : true;
+      constexpr int CHN = SCH;
       if (ragged) return hipErrorInvalidValue;
       if (lds > 64 * 1024) {
          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1198,13 +1227,13 @@ static hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_
       return hipGetLastError();
    } else {
       if (lds > 64 * 1024) {
-         hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHAIN, true>)
-                                                   : reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHAIN, false>),
+         hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, true>)
+                                                   : reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e != hipSuccess) return e;
       }
-      if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHAIN, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
-      else hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHAIN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      else hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
       return hipGetLastError();
    }
 }
@@ -1216,22 +1245,27 @@ struct PassOpts {
    int64_t grid_tiles = 0;         // MODE 4: upper bound of the worklist's tiles (the count itself lives on the device)
 };
 
-template <int MODE, bool CHAIN>
+template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                    uint8_t* d_flags, uint32_t* n_deferred, hipStream_t st, PassOpts po = PassOpts()) {
    constexpr bool BYTES = MODE == 2 || MODE == 3;
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
+   constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, po.defer_tiles, po.gate_word, 0};
+   if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
+      fp.A_init = (BYTES ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
+      fp.inv = BYTES ? h.bw16_inv_A * 0x01010101u : 0u;
+   }
    switch (chunks_of(row_len)) {
-      case 1: return launch_match<1, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 2: return launch_match<2, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 3: return launch_match<3, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 4: return launch_match<4, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 6: return launch_match<6, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 8: return launch_match<8, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 12: return launch_match<12, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      default: return launch_match<16, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 1: return launch_match<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 2: return launch_match<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 3: return launch_match<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 4: return launch_match<4, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 6: return launch_match<6, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 8: return launch_match<8, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 12: return launch_match<12, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      default: return launch_match<16, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
    }
 }
 
@@ -1242,16 +1276,20 @@ static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    if (row_len == 16 * tile_chunks(row_len)) return true;       // whole chunks: fully coalesced tile loads
    return (h.flags & FXP_F_RAGGED_OK) != 0;                        // padded in LDS with the inert symbol 255
 }
-// 0 = tile kernel not applicable, 1 = v_perm scheme, 2 = chain scheme (tables must fit the CU's LDS next to the tiles)
+// class-level table scheme for these rows: -1 = tile kernel not applicable, 0 = v_perm (<= 8 states), 2 = wide v_perm (<= 16),
+// 1 = chain (tables must fit the CU's LDS next to the tiles)   [the numbers are the kernels' SCH template argument]
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return 0;
-   if (h.flags & FXP_F_FAST_OK) return 1;
+   if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return -1;
+   if (h.flags & FXP_F_FAST_OK) return 0;
+   if ((h.flags & FXP_F_W16_OK) && !std::getenv("FXAMD_NO_W16")) return 2;
    if (h.flags & FXP_F_CHAIN_OK) {
       const size_t need = (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
-      if (need <= 150 * 1024) return 2;
+      if (need <= 150 * 1024) return 1;
    }
-   return 0;
+   return -1;
 }
+// scheme of the byte-level tables: 2 = wide v_perm when both automata have <= 16 states, else 1 = chain
+static int bytes_scheme(const FxpHeader& h) { return ((h.flags & FXP_F_BYTE_W16) && !std::getenv("FXAMD_NO_W16")) ? 2 : 1; }
 // byte-level tables usable for these rows: whole chunks only (no inert pad byte exists: every byte value means something)
 static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
    if (std::getenv("FXAMD_NO_BYTE_DFA")) return false;   // test hook: exercise the decode pass instead
@@ -1259,15 +1297,22 @@ static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len)
    return (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
 
-template <int MODE, bool CHAIN>
+template <int MODE, int SCH>
 static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                   uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st, PassOpts po = PassOpts()) {
    constexpr bool BYTES = MODE == 2 || MODE == 3;
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
+   constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TR_bytes + h.byte_TA_bytes : h.chain_TR_bytes + h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
                  0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
-   if (BYTES) {
+   if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
+      fp.R_start = (BYTES ? h.bw16_R_start : h.w16_R_start) * 0x01010101u;
+      fp.A_init = (BYTES ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
+      fp.hit_min = (BYTES ? h.bw16_hit_min : h.w16_hit_min) * 0x01010101u;
+      fp.acc_min = (BYTES ? h.bw16_acc_min : h.w16_acc_min) * 0x01010101u;
+      fp.inv = BYTES ? h.bw16_inv_R * 0x01010101u : 0u;
+   } else if (BYTES) {
       fp.R_start = h.byte_R_start;
       fp.A_init = h.byte_A_init;
       fp.hit_min = h.byte_hit_min;
@@ -1280,15 +1325,36 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.acc_min = h.chain_acc_min;
    }
    switch (chunks_of(row_len)) {
-      case 1: return launch_fast<1, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 2: return launch_fast<2, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 3: return launch_fast<3, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 4: return launch_fast<4, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 6: return launch_fast<6, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 8: return launch_fast<8, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 12: return launch_fast<12, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      default: return launch_fast<16, MODE, CHAIN>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 2: return launch_fast<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 3: return launch_fast<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 4: return launch_fast<4, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 6: return launch_fast<6, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 8: return launch_fast<8, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      case 12: return launch_fast<12, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
+      default: return launch_fast<16, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
    }
+}
+
+// runtime scheme -> instantiation (byte-level modes have no 8-state variant)
+template <int MODE>
+static hipError_t fast_by(int sch, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
+                          int32_t* d_from, int32_t* d_to, uint32_t* ctr, hipStream_t st, PassOpts po) {
+   if constexpr (MODE != 2 && MODE != 3)
+      if (sch == 0) return launch_fast_any<MODE, 0>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, po);
+   if (sch == 2) return launch_fast_any<MODE, 2>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, po);
+   return launch_fast_any<MODE, 1>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, po);
+}
+template <int MODE>
+static hipError_t match_by(int sch, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
+                           uint32_t* ctr, hipStream_t st, PassOpts po) {
+   if constexpr (MODE != 2 && MODE != 3)
+      if (sch == 0) return launch_match_any<MODE, 0>(h, d_blob, d_rows, n, row_len, d_flags, ctr, st, po);
+   if (sch == 2) return launch_match_any<MODE, 2>(h, d_blob, d_rows, n, row_len, d_flags, ctr, st, po);
+   return launch_match_any<MODE, 1>(h, d_blob, d_rows, n, row_len, d_flags, ctr, st, po);
+}
+static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-level tables hold the 128+class / SKIP rows
+   return (h.flags & (sch == 0 ? FXP_F_FAST_UTF8 : (sch == 2 ? FXP_F_W16_UTF8 : FXP_F_CHAIN_UTF8))) != 0;
 }
 
 extern "C" {
@@ -1424,17 +1490,19 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (p->prog.status != 0) return FXAMD_E_ARG;
    const FxpHeader& h = p->prog.hdr();
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme == 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
+   if (scheme < 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);
+   const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
-   po.defer_tiles = (((h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0 && !long_row(row_len)) || bytes_ok(h, d_rows, row_len)) ? 1u : 0u;
-   if (scheme == 2 && bytes_ok(h, d_rows, row_len) && p->worklist_rows >= n) {
+   po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
+   if (scheme != 0 && bytes && p->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = p->d_worklist;
-      FX_HIP((launch_fast_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
-   } else if (scheme == 1) FX_HIP((launch_fast_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
-   else FX_HIP((launch_fast_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po)));
+      FX_HIP(fast_by<2>(bytes_scheme(h), h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
+   } else {
+      FX_HIP(fast_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
+   }
    return FXAMD_OK;
 }
 
@@ -1488,12 +1556,14 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       d_to = nullptr;
    }
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme != 0) {
+   if (scheme >= 0) {
       const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
       uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);   // this call's words: [0] tiles deferred, [1] exception rows left
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
-      const bool utf8_tables = (h.flags & (scheme == 1 ? FXP_F_FAST_UTF8 : FXP_F_CHAIN_UTF8)) != 0 && !long_row(row_len);
+      const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
       const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
+      const int bsch = bytes_scheme(h);
+      const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
       // row-level fix-up through the general engine: rows still marked FX_NEEDS_GENERAL (gate: skip when the word says none are)
       auto fixup_rows = [&](const uint32_t* gate) -> int {
          if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
@@ -1507,7 +1577,7 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       };
       PassOpts first, marked, listp;
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
-      if (bytes) {   // worklist of the rows the byte-level tables cannot answer (structurally invalid UTF-8)
+      if (bytes) {   // worklist of the rows the byte-level tables cannot answer (structurally invalid or non-canonical UTF-8)
          std::lock_guard<std::mutex> g(p->mu);
          if (p->worklist_rows < n) {
             if (p->d_worklist) (void)hipFree(p->d_worklist);
@@ -1524,48 +1594,41 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       // else the row-level fix-up through the general engine
       auto exceptions = [&]() -> int {
          if (!utf8_tables) return fixup_rows(ctr + 1);
-         if (is_match) FX_HIP(scheme == 1 ? (launch_match_any<4, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp))
-                                          : (launch_match_any<4, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp)));
-         else FX_HIP(scheme == 1 ? (launch_fast_any<4, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp))
-                                 : (launch_fast_any<4, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp)));
+         if (is_match) FX_HIP(match_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp));
+         else FX_HIP(fast_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp));
          return FXAMD_OK;
       };
       if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
-         FX_HIP(scheme == 1 ? (launch_fast_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first))
-                            : (launch_fast_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first)));
-         p->last_path = scheme == 1 ? 1 : 5;
+         FX_HIP(fast_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+         p->last_path = 1 + big;
          return FXAMD_OK;
       }
-      if (bytes && scheme == 2) {
-         // the class-level scheme is the chain scheme anyway: the byte-level tables take every tile, UTF-8 or not, in one pass
-         if (is_match) FX_HIP((launch_match_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first)));
-         else FX_HIP((launch_fast_any<2, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first)));
+      if (bytes && scheme != 0) {
+         // no 8-state class-level tables to be faster with on ASCII: the byte-level tables take every tile, UTF-8 or not, in one pass
+         if (is_match) FX_HIP(match_by<2>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
+         else FX_HIP(fast_by<2>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          p->last_path = 7;
          return exceptions();
       }
       // first pass with the class-level tables: pure-ASCII tiles are finished here
-      if (is_match) FX_HIP(scheme == 1 ? (launch_match_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first))
-                                       : (launch_match_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first)));
-      else FX_HIP(scheme == 1 ? (launch_fast_any<0, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first))
-                              : (launch_fast_any<0, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first)));
+      if (is_match) FX_HIP(match_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
+      else FX_HIP(fast_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
       if (bytes) {
          // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
-         if (is_match) FX_HIP((launch_match_any<3, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked)));
-         else FX_HIP((launch_fast_any<3, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked)));
+         if (is_match) FX_HIP(match_by<3>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
+         else FX_HIP(fast_by<3>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
          p->last_path = 8;
          return exceptions();
       }
       if (utf8_tables) {
          // deferred tiles: the decode pass rewrites UTF-8 to symbol ids in LDS and scans only those tiles
-         if (is_match) FX_HIP(scheme == 1 ? (launch_match_any<1, false>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked))
-                                          : (launch_match_any<1, true>(h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked)));
-         else FX_HIP(scheme == 1 ? (launch_fast_any<1, false>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked))
-                                 : (launch_fast_any<1, true>(h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked)));
-         p->last_path = scheme == 1 ? 1 : 5;
+         if (is_match) FX_HIP(match_by<1>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
+         else FX_HIP(fast_by<1>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
+         p->last_path = 1 + big;
          return FXAMD_OK;
       }
       // rows holding bytes >= 0x80 were marked one by one: row-level fix-up (a cheap read of the flags otherwise)
-      p->last_path = scheme == 1 ? 3 : 6;
+      p->last_path = 3 + big - (big ? 1 : 0);
       return fixup_rows(nullptr);
    }
    if (aligned16 && row_len <= 1024) {

@@ -319,11 +319,13 @@ def test_utf8_rows_byte_tables_and_decode_pass(fx, monkeypatch):
     for pat, rows, path in cases:
         of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
         om, _, _ = oracle_lib.batch(1, pat, rows, NT)
-        for bytes_on in (True, False):
-            if bytes_on:
-                monkeypatch.delenv("FXAMD_NO_BYTE_DFA", raising=False)
-            else:
+        for bytes_on, wide in ((True, True), (True, False), (False, True), (False, False)):
+            monkeypatch.delenv("FXAMD_NO_BYTE_DFA", raising=False)
+            monkeypatch.delenv("FXAMD_NO_W16", raising=False)
+            if not bytes_on:
                 monkeypatch.setenv("FXAMD_NO_BYTE_DFA", "1")
+            if not wide:
+                monkeypatch.setenv("FXAMD_NO_W16", "1")   # chain tables instead of the 16-state v_perm ones
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             if bytes_on:
                 assert prog.info()["flags"] & 4096, pat
@@ -337,14 +339,19 @@ def test_utf8_rows_byte_tables_and_decode_pass(fx, monkeypatch):
             pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
             assert np.array_equal(fm, om), (pat, bytes_on, "match", pm.last_path())
     monkeypatch.delenv("FXAMD_NO_BYTE_DFA", raising=False)
+    monkeypatch.delenv("FXAMD_NO_W16", raising=False)
 
 
 CHAIN_PATTERNS = [rb"\d{3}-\d{4}", rb"\w+@\w+\.(com|org|net)", rb"(19|20)\d\d-(0[1-9]|1[012])-(0[1-9]|[12][0-9]|3[01])",
                   rb"[a-z]{3,5}\d{2,4}x", rb"(ab|cd|ef|gh|ij)+k", "[ぁ-ん]{3}[ァ-ヶ]{3}[0-9]{3}".encode()]
 
 
-def test_chain_scheme_patterns_vs_oracle(fx):
-    """Automata with more than 8 states run on the same tile kernel through class-indexed LDS chain tables."""
+@pytest.mark.parametrize("wide", [True, False])
+def test_chain_scheme_patterns_vs_oracle(fx, wide, monkeypatch):
+    """Automata with more than 8 states run on the same tile kernel: up to 16 states through the wide v_perm tables (two
+    v_perm_b32 per byte), beyond that -- or with FXAMD_NO_W16=1 -- through class-indexed LDS chain tables."""
+    if not wide:
+        monkeypatch.setenv("FXAMD_NO_W16", "1")
     nrng = np.random.default_rng(17)
     alpha = np.frombuffer(b"abcdefghijkx0123456789-@._ comrgnt", dtype=np.uint8)
     for pat in CHAIN_PATTERNS:
