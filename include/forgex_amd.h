@@ -88,10 +88,11 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
 
 /* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ second fast pass with
  * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up of non-ASCII rows,
- * 4 = NFA state-set simulation (DFA too large to build), 5 / 6 = like 1 / 3 with the class-indexed LDS chain tables
- * (automata with more than 8 states), 7 = byte-level chain tables (UTF-8 composed into the automata) over every tile + row-level
+ * 4 = NFA state-set simulation (DFA too large to build), 5 / 6 = like 1 / 3 for automata with more than 8 states (wide v_perm
+ * tables up to 16 states, class-indexed LDS chain tables beyond), 7 = byte-level chain tables (UTF-8 composed into the automata) over every tile + row-level
  * fix-up of structurally invalid rows, 8 = fast kernel on the pure-ASCII tiles, byte-level chain tables on the others, same fix-up.
- * (Environment FXAMD_NO_BYTE_DFA=1 disables 7 / 8: a test hook that keeps the decode pass of 1 / 5 reachable.) */
+ * (Environment FXAMD_NO_BYTE_DFA=1 disables 7 / 8 and FXAMD_NO_W16=1 the wide v_perm tables: test hooks that keep the decode pass
+ * and the chain kernels reachable.) */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);
