@@ -279,7 +279,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
         if p.status != 0 or not (p.info()["flags"] & (8 | 256)):   # v_perm tables or class-indexed chain tables
             continue
         n_fast += 1
-        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252])   # incl. ragged (not a multiple of 16)
+        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252, 272, 512, 784])   # incl. ragged (not a multiple of 16) and long rows
         n = 192
         rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
         mixed = []
