@@ -862,7 +862,61 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    // ---- 7. fast path: <= 8 states per automaton, fused ASCII byte tables -----------------------------------------
    // Candidate-list search == brute-force search on pure-ASCII rows iff the prefix is a NECESSARY, non-self-overlapping
    // beginning of every non-empty match; the suffix is only consulted by the candidate-list driver.
-   bool brute_equiv = op == OP_SEARCH && R.ok && !(prefilter && has_suffix);
+   bool brute_equiv = op == OP_SEARCH && R.ok;   // (a suffix literal without a prefix literal is never consulted: api_internal_m.F90:76-82)
+   if (brute_equiv && prefilter && has_suffix) {
+      // With a suffix literal the driver also (a) gives up when the suffix does not occur, (b) stops at candidates behind its
+      // last occurrence (api_internal_m.F90:99-116; one index is a text index, the other a wrapped one).  Neither changes a
+      // result when the suffix is a NECESSARY ending of every match and no match is shorter than prefix + suffix (then the
+      // suffix of the match found starts at least one byte behind the match start, which is all the off-by-one needs).
+      // Necessity is checked on the NFA walked BACKWARDS from the exit: at each of the last ls positions only the suffix's own
+      // symbol -- a singleton class -- leads anywhere, and the entry state (a complete, shorter match) is not met on the way.
+      bool ok = lit.suffix.find('\0') == std::string::npos;
+      const std::vector<int32_t> sc = decode_chars(lit.suffix), pc = decode_chars(lit.prefix);
+      for (int32_t c : sc) ok = ok && c < 128;
+      for (int32_t c : pc) ok = ok && c < 128;
+      Bits Wb = rclos[static_cast<size_t>(nfa.exit)];
+      for (size_t i = sc.size(); ok && i-- > 0;) {
+         if (bt(Wb, nfa.entry)) ok = false;
+         const int iv = interval_of(sc[i]);
+         if (!(bounds[static_cast<size_t>(iv)] == sc[i] && bounds[static_cast<size_t>(iv) + 1] == sc[i] + 1)) ok = false;
+         Bits nxt(W, 0);
+         for (int z = 1; ok && z <= N; ++z) {
+            if (!bt(Wb, z)) continue;
+            for (int ti : inc[static_cast<size_t>(z)]) {
+               const FlatTra& ft = tras[static_cast<size_t>(ti)];
+               for (int k : ft.acc) {
+                  if (k != iv) ok = false;   // some other symbol can stand at this distance from the end of a match
+                  else bor(nxt, rclos[static_cast<size_t>(ft.src)]);
+               }
+            }
+         }
+         Wb = nxt;
+         if (!bany(Wb)) ok = false;
+      }
+      // shortest accepted string (in symbols) >= prefix + suffix: breadth-first over A
+      if (ok) {
+         std::vector<int> dist(static_cast<size_t>(A.n), -1);
+         std::vector<int> queue{A.init};
+         dist[static_cast<size_t>(A.init)] = 0;
+         int shortest = -1;
+         for (size_t qi = 0; qi < queue.size() && shortest < 0; ++qi) {
+            const int st = queue[qi];
+            if (A.out[static_cast<size_t>(st)] && st != A.init) {
+               shortest = dist[static_cast<size_t>(st)];
+               break;
+            }
+            for (int k = 0; k < nI; ++k) {
+               const int t = A.T[static_cast<size_t>(st) * nI + k];
+               if (t != 0 && dist[static_cast<size_t>(t)] < 0) {
+                  dist[static_cast<size_t>(t)] = dist[static_cast<size_t>(st)] + 1;
+                  queue.push_back(t);
+               }
+            }
+         }
+         if (shortest < 0 || static_cast<size_t>(shortest) < pc.size() + sc.size()) ok = false;
+      }
+      brute_equiv = ok;
+   }
    if (brute_equiv && prefilter) {
       bool ok = border_free(lit.prefix) && lit.prefix.find('\0') == std::string::npos;
       int q = A.init;

@@ -402,8 +402,10 @@ struct Result {
    int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none
 };
 
+// force_brute: ignore the prefilter literals and search by brute force -- what the tile kernels do for programs whose candidate-list
+// search is PROVEN equal to it (compile.cpp, `brute_equiv`); the test harness uses it to check that proof against the oracle
 template <class Row, class Sim>
-FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out) {
+FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out, bool force_brute = false) {
    const FxpHeader& h = pv.h();
    out.flag = 0;
    out.from = 0;
@@ -413,7 +415,7 @@ FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Resu
       if (h.flags & FXP_F_INIT_ACCEPTING) out.flag = 1;   // ACCEPTED_EMPTY: .in. is true, regex() returns '' / 0 / 0
       return;
    }
-   bool brute = !(h.flags & FXP_F_PREFILTER);
+   bool brute = force_brute || !(h.flags & FXP_F_PREFILTER);
    int first = 0, suf_idx = -1;
    const int lp = static_cast<int>(h.len_prefix), ls = static_cast<int>(h.len_suffix);
    auto pre = [&](int k) { return pv.prefix(static_cast<uint32_t>(k)); };
@@ -592,9 +594,9 @@ FX_HD void match_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Resul
 }
 
 template <class Row, class Sim>
-FX_HD void run_row(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out) {
+FX_HD void run_row(const ProgView& pv, Sim& sim, const Row& r, int L, Result& out, bool force_brute = false) {
    switch (pv.h().mode) {
-      case FXP_MODE_SEARCH_ENGINE: search_engine(pv, sim, r, L, out); break;
+      case FXP_MODE_SEARCH_ENGINE: search_engine(pv, sim, r, L, out, force_brute); break;
       case FXP_MODE_SEARCH_LITERAL: search_literal(pv, r, L, out); break;
       case FXP_MODE_MATCH_ENGINE: match_engine(pv, sim, r, L, out); break;
       default:

@@ -32,13 +32,22 @@ void run_any(const fxrow::ProgView& pv, const fxc::Program& p, const HostRow& r,
       }
       if (rc == 1) ++g_byte_exceptions;
    }
+   // FX_HW_FAST=1: programs that carry tile-kernel tables are searched the way those kernels search pure-ASCII rows -- by brute
+   // force, prefilter literals ignored (the compile-time equivalence proof under test)
+   static const bool as_fast = std::getenv("FX_HW_FAST") != nullptr;
+   bool force_brute = false;
+   if (as_fast && (p.hdr().flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) && (p.hdr().flags & FXP_F_PREFILTER) && L >= 1) {
+      force_brute = true;
+      for (int j = 0; j < L; ++j) force_brute = force_brute && r[j] < 0x80u;
+      if (force_brute) ++g_byte_rows;
+   }
    if (p.hdr().flags & FXP_F_NFA_SIM) {   // bitset simulation of NFA state sets (DFA too large)
       std::vector<uint32_t> scratch(2 * p.hdr().nfa_words);
       fxrow::NfaSim sim(pv, scratch.data());
       fxrow::run_row(pv, sim, r, L, res);
    } else {
       fxrow::DfaSim sim(pv);
-      fxrow::run_row(pv, sim, r, L, res);
+      fxrow::run_row(pv, sim, r, L, res, force_brute);
    }
 }
 std::string unhex(const std::string& h) {
@@ -199,6 +208,7 @@ int main() {
       }
       std::fflush(stdout);
    }
+   if (std::getenv("FX_HW_STATS")) std::fprintf(stderr, "host_walk: %ld rows answered by the byte tables or by forced brute force, %ld exceptions\n", g_byte_rows, g_byte_exceptions);
    return 0;
 }
 #endif

@@ -474,3 +474,25 @@ def test_long_rows_on_tile_kernels(fx):
                 om, _, _ = oracle_lib.batch(1, pat, data, NT)
                 assert np.array_equal(fm, om), (pat, L, "match", pm.last_path())
                 assert int(om.sum()) > 0 or pat != rb"(ab)+"
+
+
+def test_prefix_and_suffix_literal_patterns_on_tile_kernel(fx):
+    """`literal.*literal` shapes: with the suffix proven a necessary ending (and no match shorter than prefix + suffix) the
+    candidate-list driver of the reference equals brute force, so these patterns run on the tile kernels too."""
+    nrng = np.random.default_rng(61)
+    alpha = np.frombuffer(b"abcxyz01 =;-", dtype=np.uint8)
+    pats = [rb"abc.*xyz", rb"id=\d+;", rb"ab[a-c]*ba", rb"x=.+;", rb"foo(bar|baz)+z", rb"a b\w+c-", rb"abc.*abc"]
+    for L in (64, 256, 100, 512):
+        rows = alpha[nrng.integers(0, len(alpha), size=(6000, L))].copy()
+        seeds = [b"abcqqxyz", b"id=42;", b"abcacba", b"x=1;", b"foobarbazz", b"a bzzc-", b"abcabc", b"abcxyzxyz", b"id=;", b"abab a"]
+        for i in range(0, 6000, 2):
+            sd = np.frombuffer(seeds[(i // 2) % len(seeds)], dtype=np.uint8)
+            off = int(nrng.integers(0, L - len(sd)))
+            rows[i, off:off + len(sd)] = sd
+        for pat in pats:
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            assert prog.last_path() != 2, (pat, L, prog.last_path())
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            assert np.array_equal(f, of), (pat, L)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
+            assert int(of.sum()) > 0, pat

@@ -64,6 +64,28 @@ def test_byte_level_tables_equal_oracle_on_utf8_fuzz(built, monkeypatch):
         assert info[0] == want and info[4] < 8192, (pat, list(info))
 
 
+def test_prefilter_equivalence_proof_holds_on_fuzz(built, monkeypatch):
+    """Programs that carry tile-kernel tables are searched by brute force on pure-ASCII rows although the reference would use
+    its candidate-list driver (prefix / suffix literals): the compile-time proof of that equivalence (compile.cpp, `brute_equiv`)
+    against the oracle, with the host harness forced onto the brute-force path (FX_HW_FAST=1)."""
+    import random
+    import fuzz_prefilter
+    monkeypatch.setenv("FX_HW_FAST", "1")
+    rng = random.Random(71)
+    cases = [fuzz_prefilter.gen_case(rng) for _ in range(6000)]
+    a = golden.run_protocol(HW, cases)
+    b = golden.run_protocol(golden.ORACLE_CLI, cases)
+    diffs = [(c, x, y) for c, x, y in zip(cases, a, b) if not x.startswith("U") and x != y]
+    assert not diffs, diffs[:5]
+    # `literal.*literal` shapes are among the programs the proof admits
+    lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
+    lib.hw_info.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    for pat, want in ((b"abc.*xyz", True), (b"id=\\d+;", True), (b"aa[bc]", False)):
+        info = (ctypes.c_int32 * 8)()
+        lib.hw_info(pat, len(pat), 0, info)
+        assert bool(info[1] & (8 | 256 | 0x2000)) == want, (pat, hex(info[1]))
+
+
 def test_config_rows_tables_vs_oracle(built):
     """Small slices of the five BASELINE configs through the host walker (one compile per batch) and the oracle."""
     import torch
