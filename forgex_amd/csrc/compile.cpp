@@ -1080,11 +1080,14 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    }
 
    // ---- 9. byte-level chain tables: A and R composed with the UTF-8 decoder (no decode pass on the device) ---------------------
-   // Only where the tile kernels' brute-force semantics hold for non-ASCII rows too: `.match.`, or a search without a
-   // prefilter literal (the candidate list is an INDEX over raw bytes, api_internal_m.F90:76-104).
+   // Only where the tile kernels' brute-force semantics hold: `.match.`, or a search proven equal to brute force.  With a
+   // prefilter literal that proof carries over from pure-ASCII rows to rows of valid canonical UTF-8 -- UTF-8 is
+   // self-synchronising, so the byte-level INDEX of the candidate list (api_internal_m.F90:76-104) finds exactly the
+   // character-aligned occurrences -- and every other row is an exception row anyway (for these programs they go to the general
+   // engine, which follows the candidate-list driver to the letter).
    {
       std::vector<uint16_t> bcm(256, 0), btr, bta;
-      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || (brute_equiv && !prefilter));
+      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || brute_equiv);
       std::vector<uint8_t> bwa, bwr;
       if (want) {
          Sig full;

@@ -489,10 +489,19 @@ def test_prefix_and_suffix_literal_patterns_on_tile_kernel(fx):
             sd = np.frombuffer(seeds[(i // 2) % len(seeds)], dtype=np.uint8)
             off = int(nrng.integers(0, L - len(sd)))
             rows[i, off:off + len(sd)] = sd
+        # the same rows with multi-byte characters (valid UTF-8: byte-level tables) and broken sequences (row-level fix-up) spliced in
+        mixed = rows[:3000].copy()
+        pieces = [np.frombuffer(x, dtype=np.uint8) for x in ("あ".encode(), "é".encode(), "ω".encode(), b"\x80", b"\xe3\x81", "\U0001F600".encode())]
+        for i in range(3000):
+            for _ in range(int(nrng.integers(0, 4))):
+                pc = pieces[int(nrng.integers(0, len(pieces)))] if i % 3 else pieces[int(nrng.integers(0, 3))]
+                off = int(nrng.integers(0, L - len(pc)))
+                mixed[i, off:off + len(pc)] = pc
         for pat in pats:
-            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() != 2, (pat, L, prog.last_path())
-            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
-            assert np.array_equal(f, of), (pat, L)
-            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
-            assert int(of.sum()) > 0, pat
+            for data in (rows, mixed):
+                prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, data)
+                assert prog.last_path() != 2, (pat, L, prog.last_path())
+                of, oa, ob = oracle_lib.batch(2, pat, data, NT)
+                assert np.array_equal(f, of), (pat, L)
+                assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
+                assert int(of.sum()) > 0, pat
