@@ -1000,6 +1000,29 @@ __global__ __launch_bounds__(256) void fx_general(const uint8_t* __restrict__ ro
    if (to) to[row] = res.to;
 }
 
+// Exception rows of a byte-level pass, gathered in a worklist: one lane = one listed row through the general procedure, tables
+// staged in LDS (programs whose class-level tables cannot decode, or whose prefilter needs the candidate-list driver).
+__global__ __launch_bounds__(256) void fx_fixup_list(const uint8_t* __restrict__ rows, int32_t L, const uint8_t* __restrict__ prog,
+                                                      uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
+                                                      const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ count_p,
+                                                      uint32_t prog_lds_bytes) {
+   extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
+   const uint32_t count = *count_p;
+   if ((uint64_t)blockIdx.x * blockDim.x >= count) return;   // (block-uniform: nothing listed for this block)
+   const uint8_t* pbase = stage_program(prog, reinterpret_cast<uint8_t*>(dyn_lds), prog_lds_bytes);
+   fxrow::ProgView pv(pbase);
+   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+      const int64_t row = worklist[i];
+      GlobalRow r{rows + row * (int64_t)L};
+      fxrow::Result res;
+      fxrow::DfaSim sim(pv);
+      fxrow::run_row(pv, sim, r, L, res);
+      flags[row] = (uint8_t)res.flag;
+      if (from) from[row] = res.from;
+      if (to) to[row] = res.to;
+   }
+}
+
 // Fix-up pass after the fast kernel: every thread inspects 16 flags with one 16-byte load and only rows marked
 // FX_NEEDS_GENERAL (bytes >= 0x80: on-device UTF-8 decode needed) are re-matched, with the tables read from global memory.
 __global__ __launch_bounds__(256) void fx_fixup(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
@@ -1593,7 +1616,14 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       // exception rows of a byte-level pass: the decode pass over the gathered worklist when the class-level tables can decode,
       // else the row-level fix-up through the general engine
       auto exceptions = [&]() -> int {
-         if (!utf8_tables) return fixup_rows(ctr + 1);
+         if (!utf8_tables) {   // the general engine over the worklist
+            int64_t lblocks = (n + 255) / 256;
+            if (lblocks > 4096) lblocks = 4096;
+            hipLaunchKernelGGL(fx_fixup_list, dim3((unsigned)lblocks), dim3(256), prog_lds, st, d_rows, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to,
+                               p->d_worklist, ctr + 1, prog_lds);
+            FX_HIP(hipGetLastError());
+            return FXAMD_OK;
+         }
          if (is_match) FX_HIP(match_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp));
          else FX_HIP(fast_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp));
          return FXAMD_OK;
