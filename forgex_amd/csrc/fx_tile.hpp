@@ -1,0 +1,1063 @@
+// Tile kernels of libforgex_amd.so (fx_search_fast, fx_match_fast) and their launchers; see fxamd.hip for the overview and
+// DESIGN.md section 4.  This header is compiled into several translation units: fxamd.hip only DECLARES the launcher
+// instantiations (extern template), fx_tile_inst.hip defines them for one chunk count per object file so that the few hundred
+// kernel variants build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <type_traits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/forgex_amd.h"
+#include "compile.hpp"
+#include "program.h"
+#include "row_engine.hpp"
+
+#define FX_NEEDS_GENERAL 0xFFu   // marker the fast kernel leaves in flags[] for rows with a byte >= 0x80
+
+// =========================================================================================================
+// tile staging: 64 rows x (16*CH) bytes, HBM -> LDS, transposed so each lane reads its own row conflict-free
+// cell(R, k) = k*64 + (R ^ (k & 7))   [16-byte cells]; chunk k of row R.  Only the low three bits are swizzled: that is all the
+// banking needs (a 16-byte cell spans 4 of the 32/64 banks, so 8 resp. 16 consecutive cells are conflict-free), and it leaves the
+// row's upper bits additive, so the staging stores of one tile differ only in their immediate offsets (store_tile).
+// =========================================================================================================
+__device__ __forceinline__ uint32_t tile_cell(uint32_t R, uint32_t k) { return (k << 6) + (R ^ (k & 7u)); }
+
+typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FX_PREFETCH_DEPTH
+#define FX_PREFETCH_DEPTH 1   // tiles of global loads in flight per wave in the first pass
+#endif
+#ifndef FX_LOAD_AUX
+#define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
+#endif
+template <int CH>
+__device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, bool enable = true) {
+   // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH.  row0 is wave-uniform:
+   // the tile is addressed through a buffer resource whose base is the tile and whose extent is the tile's valid bytes, so
+   // each piece is ONE buffer_load_dwordx4 (scalar base, lane offset, immediate piece offset) and the pieces of rows >= n
+   // come back as zero from the hardware range check instead of per-piece predication.
+   const int64_t rows_left = n - row0;
+   // enable == false (wave-uniform): a tile this pass skips -- zero valid bytes, the loads are issued and range-checked away
+   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * 16u * CH : (rows_left > 0 ? (uint32_t)rows_left * 16u * CH : 0u));
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)(16 * CH);
+   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + (uint32_t)q * 1024u, 0, FX_LOAD_AUX);
+      v[q] = make_uint4(t.x, t.y, t.z, t.w);
+   }
+}
+
+// Long rows (Lr a multiple of 16, > 256): the tile is walked in 256-byte SEGMENTS (one of them shorter when Lr % 256 != 0).  Piece q*64+lane of segment `seg` = row
+// 4q + lane/16, chunk lane%16 of that segment: 16 lanes read 256 contiguous bytes of one row.  Same buffer resource trick:
+// extent = the tile's valid bytes, the row / segment distance rides in the scalar offset (which the range check includes).
+__device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
+                                              uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable) {
+   // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
+   // (k_lo, k_hi) = (0, 15); the short one of a row whose length is not a multiple of 256 sits RIGHT-aligned (search: k_lo = 16 - c,
+   // the backward loop stops there) or LEFT-aligned (`.match.`: k_hi = c - 1) and its other chunks repeat a neighbour (never walked).
+   const int64_t rows_left = n - row0;
+   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u));
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)Lr;
+   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+   uint32_t kc = lane & 15u;
+   kc = kc < k_lo ? k_lo : (kc > k_hi ? k_hi : kc);
+   const uint32_t voff = (lane >> 4) * Lr + (kc - k_lo) * 16u;
+   const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_byte);
+#pragma unroll
+   for (int q = 0; q < 16; ++q) {
+      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)(4 * q) * Lr, FX_LOAD_AUX);
+      v[q] = make_uint4(t.x, t.y, t.z, t.w);
+   }
+}
+
+// Rows whose length Lr is not 16*CH (Lr % 4 == 0, 16 <= Lr <= 16*CH): the same 64-row tile, but piece (R, k) comes from byte
+// R*Lr + 16k of the tile (dword aligned, not 16-byte aligned) and the bytes behind the row end are delivered as ZERO.  The
+// last partial chunk is read as the row's LAST 16 bytes and shifted down, so nothing beyond the caller's buffer is touched.
+struct __attribute__((aligned(4))) U4a {
+   uint32_t x, y, z, w;
+};
+template <int CH>
+__device__ __forceinline__ void load_tile_ragged(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane,
+                                                 uint32_t Lr) {
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      const uint32_t p = q * 64 + lane, R = p / CH, k = p % CH;
+      const int64_t row = row0 + R;
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (row < n && 16u * k < Lr) {
+         const uint8_t* rp = rows + row * (int64_t)Lr;
+         if (16u * k + 16u <= Lr) {
+            const U4a t = *reinterpret_cast<const U4a*>(rp + 16u * k);
+            o = make_uint4(t.x, t.y, t.z, t.w);
+         } else {
+            const U4a t = *reinterpret_cast<const U4a*>(rp + Lr - 16u);   // bytes [Lr-16, Lr)
+            const uint32_t rem = Lr - 16u * k;                            // 4, 8 or 12 valid bytes
+            o = rem == 12u ? make_uint4(t.y, t.z, t.w, 0) : (rem == 8u ? make_uint4(t.z, t.w, 0, 0) : make_uint4(t.w, 0, 0, 0));
+         }
+      }
+      v[q] = o;
+   }
+}
+
+// symbol 255 (inert at the end of a row in every scheme) behind the row end, for lane r's own row.  Returns the OR of the row's
+// own bytes (the loader delivered zeros behind the row end), which the ragged kernels use for their ">= 0x80 anywhere" test.
+template <int CH>
+__device__ __forceinline__ uint32_t pad_rows(uint4* tile, uint32_t lane, uint32_t Lr) {
+   uint32_t na = 0;
+#pragma unroll 1
+   for (uint32_t k = 0; k < (uint32_t)CH; ++k) {
+      uint4 c = tile[tile_cell(lane, k)];
+      na |= c.x | c.y | c.z | c.w;
+      const uint32_t b = 16u * k;
+      if (b + 16u <= Lr) continue;   // wave-uniform
+      c.x = b + 0u < Lr ? c.x : 0xFFFFFFFFu;
+      c.y = b + 4u < Lr ? c.y : 0xFFFFFFFFu;
+      c.z = b + 8u < Lr ? c.z : 0xFFFFFFFFu;
+      c.w = b + 12u < Lr ? c.w : 0xFFFFFFFFu;
+      tile[tile_cell(lane, k)] = c;
+   }
+   return na;
+}
+
+template <int CH>
+__device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, uint32_t lane) {
+   if constexpr ((CH & (CH - 1)) == 0) {
+      // piece q*64+lane = row q*RPI + r, chunk k (r = lane / CH, k = lane % CH).  With B = max(RPI, 8) the row splits into a
+      // multiple of B, which the swizzle leaves alone (an immediate offset), and a rest < B: B/RPI base addresses in all.
+      constexpr uint32_t RPI = 64 / CH, B = RPI > 8 ? RPI : 8;
+      const uint32_t r = lane / CH, k = lane % CH;
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+         const uint32_t hi = ((uint32_t)q * RPI) & ~(B - 1u), lo = ((uint32_t)q * RPI) & (B - 1u);
+         tile[(k << 6) + hi + ((lo + r) ^ (k & 7u))] = v[q];
+      }
+   } else {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+         uint32_t p = q * 64 + lane;
+         tile[tile_cell(p / CH, p % CH)] = v[q];
+      }
+   }
+}
+
+// =========================================================================================================
+// fast search kernel
+// =========================================================================================================
+// every value is a state id replicated into all four bytes (id * 0x01010101): v_perm_b32 then advances four identical
+// copies of the automaton and `state >= hit_min` can compare whole registers without masking
+struct FastParams {
+   uint32_t R_start, A_init, hit_min, acc_min;
+   uint32_t inv;            // BYTES modes: the INVALID state (structurally invalid UTF-8): the row is left to the decode path
+   uint32_t defer_tiles;    // first pass: tiles holding a byte >= 0x80 are deferred whole (a later pass handles them)
+   uint32_t gate_word;      // marked-tile passes: which of the call's two words says whether there is anything to do
+   uint32_t lit_len;        // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
+};
+
+// 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
+// Two table schemes share the kernel (template parameter CHAIN):
+//   v_perm scheme  (<= 8 states): F = uint2 = the 8 next-state bytes of the symbol; step = ONE v_perm_b32.
+//   chain scheme   (larger automata): F = 2 * column of the symbol's class (uint16 map, state-independent, pipelined the same
+//                  way); the state is the byte offset of its row in a class-indexed uint16 table held in LDS and the step is a
+//                  dependent ds_read_u16 of T[state + F] (the destination's row offset).
+template <class F, class TabT>
+__device__ __forceinline__ void lookup8(F* __restrict__ f, uint32_t lo, uint32_t hi, const TabT* __restrict__ tab) {
+#pragma unroll
+   for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
+}
+__device__ __forceinline__ uint32_t fxstep(uint2 f, uint32_t st, const uint8_t*) { return __builtin_amdgcn_perm(f.y, f.x, st); }
+// wide scheme: F = 16 encoded next-state bytes (states 0..7 in x,y; 8..15 in z,w); the state byte is i (i < 8) or 0x80 + i - 8.
+// v_perm_b32 delivers 0xFF for a selector byte >= 13, so the half that does not hold the current state drops out of the AND.
+__device__ __forceinline__ uint32_t fxstep(uint4 f, uint32_t st, const uint8_t*) {
+   return __builtin_amdgcn_perm(f.y, f.x, st) & __builtin_amdgcn_perm(f.w, f.z, st ^ 0x80808080u);
+}
+__device__ __forceinline__ uint32_t fxstep(uint32_t f, uint32_t st, const uint8_t* T) {
+   return *reinterpret_cast<const uint16_t*>(T + st + f);
+}
+// table scheme SCH: 0 = v_perm (<= 8 states), 1 = LDS chain, 2 = wide v_perm (<= 16 states, two v_perm_b32 per byte)
+template <int SCH>
+struct FxF {
+   using type = uint2;
+};
+template <>
+struct FxF<1> {
+   using type = uint32_t;
+};
+template <>
+struct FxF<2> {
+   using type = uint4;
+};
+
+// Right-to-left state chain over 8 bytes.  All four bytes of `state` carry the same state id (v_perm_b32 advances four
+// identical copies), so whole registers compare like ids and no masking is needed.  Hit states have the LARGEST ids, so
+// the group's "any hit" is max(states) >= hit_min: one v_max3_u32 per two bytes instead of a compare+select per byte.
+template <class F>
+__device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state, const uint8_t* T) {
+   uint32_t st[8];
+#pragma unroll
+   for (int i = 7; i >= 0; --i) {
+      state = fxstep(f[i], state, T);
+      st[i] = state;
+   }
+   uint32_t m0 = max(max(st[0], st[1]), st[2]);
+   uint32_t m1 = max(max(st[3], st[4]), st[5]);
+   uint32_t m2 = max(st[6], st[7]);
+   return max(max(m0, m1), m2);
+}
+
+// ---- on-device UTF-8 decode for the fast kernel (FXP_F_FAST_UTF8) -------------------------------------------------------
+// A tile that holds any byte >= 0x80 is rewritten IN REGISTERS, before it is stored to LDS, into fast-path symbol ids:
+// ASCII bytes stay; the first byte of a structurally valid multi-byte character becomes 128 + class(code point); its
+// continuation bytes become 255 (SKIP); every byte of an invalid sequence becomes 128 + class(U+FFFF) -- the reference's
+// strict stepping (utf8_m.f90:44-140,168-246) and arithmetic decode (:338-430), decided per position from a +-3 byte
+// window (a lead byte is always a character start; a continuation byte is inside a character iff the nearest
+// non-continuation byte within 3 to its left is a lead whose whole sequence is continuation bytes).
+// Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
+// at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
+template <bool RAGGED, bool LONG = false>
+__device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
+   if (LONG) {
+      // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); L % 8 == 0
+      if (p < L) {
+         const uint2 r = *reinterpret_cast<const uint2*>(tb + p);
+         lo = r.x;
+         hi = r.y;
+      } else {
+         lo = p == L ? 0xFEFEFE00u : 0xFEFEFEFEu;
+         hi = 0xFEFEFEFEu;
+      }
+      return;
+   }
+   if (!RAGGED) {
+      // whole chunks: index L.. lives in the row's extra chunk column (NUL, then KILL symbols); anything further reads its KILL half
+      const uint32_t pc = p < L + 8u ? p : L + 8u;   // p and L are multiples of 8
+      const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 8u));
+      lo = r.x;
+      hi = r.y;
+      return;
+   }
+   const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8, L a multiple of 4
+   const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
+   // 0x00 at index L (the trailing NUL), 0xFE (the symbol id whose table row is all-dead) behind it
+   lo = p + 4u <= L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
+   hi = p + 8u <= L ? r.y : (p + 4u == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
+}
+template <bool RAGGED, bool LONG = false>
+__device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
+   const uint32_t base = j & ~7u, sh = j & 7u;
+   uint32_t d[10];
+#pragma unroll
+   for (int g = 0; g < 5; ++g) group_words<RAGGED, LONG>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
+   const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
+   uint32_t e[9];
+#pragma unroll
+   for (int k = 0; k < 9; ++k) e[k] = (up & d[k + 1]) | (~up & d[k]);
+#pragma unroll
+   for (int k = 0; k < 8; ++k) o[k] = __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u);
+}
+template <bool RAGGED, bool LONG = false>
+__device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
+   const uint32_t base = j & ~7u, sh = j & 7u;
+   uint32_t d[4];
+   group_words<RAGGED, LONG>(d[0], d[1], tb, lane, base, L);
+   group_words<RAGGED, LONG>(d[2], d[3], tb, lane, base + 8u, L);
+   const uint32_t up = 0u - ((sh >> 2) & 1u);
+   uint32_t e[3];
+#pragma unroll
+   for (int k = 0; k < 3; ++k) e[k] = (up & d[k + 1]) | (~up & d[k]);
+   o[0] = __builtin_amdgcn_alignbyte(e[1], e[0], sh & 3u);
+   o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
+}
+
+// ---- optional phase stamps (debug builds only: make stamp) --------------------------------------------------------------
+// -DFX_STAMP: lane 0 of every wave accumulates s_memtime deltas per phase of fx_search_fast and adds them to fx_stamp_acc[].
+#ifdef FX_STAMP
+__device__ unsigned long long fx_stamp_acc[16];
+#define STAMP_DECL unsigned long long _st_t = __builtin_amdgcn_s_memtime(), _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i)                                                     \
+   do {                                                              \
+      const unsigned long long _n = __builtin_amdgcn_s_memtime();    \
+      _st_acc[i] += _n - _st_t;                                      \
+      _st_t = _n;                                                    \
+   } while (0)
+#define STAMP_FLUSH                                                                      \
+   do {                                                                                  \
+      if (lane == 0)                                                                     \
+         for (int _i = 0; _i < 8; ++_i) atomicAdd(&fx_stamp_acc[_i], _st_acc[_i]);       \
+   } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+// aligned rows: fully coalesced 16-byte pieces; ragged rows (Lr != 16*CH): dword-aligned pieces, zero behind the row end
+#define LOAD_TILE(st, r0)                                              \
+   do {                                                                \
+      if (RAGGED) load_tile_ragged<CH>(st, rows, (r0), n, lane, Lr);   \
+      else load_tile<CH>(st, rows, (r0), n, lane);                     \
+   } while (0)
+// prefetch of a tile that may lie behind the last one: the aligned loader needs no guard (zero valid bytes -> every piece is
+// range-checked away), and an unguarded load keeps the staging registers free of control-flow merges
+#define PREFETCH_TILE(st, tn, en)                                      \
+   do {                                                                \
+      if (!RAGGED) load_tile<CH>(st, rows, (tn) << 6, n, lane, (en));  \
+      else if ((en) && (tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
+   } while (0)
+
+__device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr);
+// segment sg of a long row, search order (the SHORT segment is the leftmost one, sg = 0, right-aligned in the tile)
+#define PREFETCH_SEG(st, tn, sg, en) \
+   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, seg_byte_search((sg), Lr), ((sg) == 0u && (Lr & 255u)) ? 16u - ((Lr & 255u) >> 4) : 0u, 15u, (en))
+// `.match.` order (the SHORT segment is the rightmost one, left-aligned in the tile)
+#define PREFETCH_SEG_FWD(st, tn, sg, en) \
+   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? ((Lr & 255u) >> 4) - 1u : 15u, (en))
+// first byte of segment sg when the short segment (Lr % 256 bytes) comes first
+__device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr) {
+   const uint32_t rem = Lr & 255u;
+   return sg == 0u ? 0u : (rem ? rem + (sg - 1u) * 256u : sg * 256u);
+}
+
+// FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
+//                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
+//                 the offending rows are marked individually for the general kernel's fix-up.
+// FIXUP = true:  second pass: only marked tiles are loaded, decoded from UTF-8 to symbol ids in LDS, then scanned.
+// MODE 0: first pass (class-level tables), as above.            MODE 1: the decode second pass (FIXUP), marked tiles only.
+// MODE 2: byte-level tables (FXP_F_BYTE_DFA) over ALL tiles: raw bytes are the symbols, nothing is decoded or deferred; rows
+//         whose backward pass ends in the INVALID state keep FX_NEEDS_GENERAL for the row-level fix-up (fx_fixup).
+// MODE 3: the same over the tiles a MODE 0 pass deferred.
+// MODE 4: the decode pass over a WORKLIST of row indices (the exception rows a BYTES pass appended): each lane gathers its own
+//         row into its LDS cells, results are scattered back to the rows' own slots.
+// n_deferred points at this call's two words: [0] "a first pass deferred tiles", [1] number of exception rows in `worklist`.
+// LONG: rows longer than 256 bytes (a multiple of 256), CH = 16: the backward pass walks the row segment by segment through the
+// same LDS tile, the short forward pass reads its bytes straight from global memory.  First-pass and BYTES modes only.
+template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
+__global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+                                                        FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
+                                                        int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
+                                                        uint32_t Lr, uint32_t* __restrict__ clear_next, uint32_t* __restrict__ worklist) {
+   // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
+   // instantiation keeps the row length a compile-time constant (the hot path).
+   const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;
+   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;   // segments per row: 256 bytes each, the LEFTMOST one shorter when Lr % 256 != 0
+   constexpr bool ragged = RAGGED;
+   static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
+   constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
+   constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
+   static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
+   static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
+   if ((MARKED || LIST) && n_deferred[fp.gate_word] == 0) return;   // nothing was left for this pass
+   // the "something was deferred" words of consecutive calls alternate: this call's first pass zeroes the NEXT call's word (no
+   // memset node per call; nobody reads that word before the next call's second pass)
+   if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
+      clear_next[0] = 0u;
+      clear_next[1] = 0u;
+   }
+   using F = typename FxF<SCH>::type;
+   __shared__ uint2 permR[SCH == 0 ? 256 : 1];
+   __shared__ uint2 permA[SCH == 0 ? 256 : 1];
+   __shared__ uint4 wideR[WIDE ? 256 : 1];
+   __shared__ uint4 wideA[WIDE ? 256 : 1];
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * (CH + 1));
+   const uint32_t tr_bytes = BYTES ? h->byte_TR_bytes : h->chain_TR_bytes, ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
+   const uint32_t chain_bytes = CHAIN ? ((512u + tr_bytes + ta_bytes + 15u) & ~15u) : 0u;
+   const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cmap) + 512;
+   const uint8_t* TAp = TRp + (CHAIN ? tr_bytes : 0u);
+   if (CHAIN) {
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_cls : h->off_chain_cls));
+      const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TR : h->off_chain_TR));
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
+      const uint32_t nr = tr_bytes / 2, na = ta_bytes / 2;
+      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+   } else if (WIDE) {
+      const uint4* gR = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16R : h->off_w16R));
+      const uint4* gA = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16A : h->off_w16A));
+      wideR[threadIdx.x] = gR[threadIdx.x];
+      wideA[threadIdx.x] = gA[threadIdx.x];
+   } else {
+      const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
+      const uint2* gA = reinterpret_cast<const uint2*>(prog + h->off_fastA);
+      uint32_t t = threadIdx.x;   // 256 threads = 256 symbol ids (ids >= 128 are all-dead rows unless FXP_F_FAST_UTF8)
+      permR[t] = gR[t];
+      permA[t] = gA[t];
+   }
+   __syncthreads();
+   // symbol -> F tables of the two directions (the chain scheme shares one class map)
+   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+   const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideR) : reinterpret_cast<const TabT*>(permR));
+   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
+   const bool raw = BYTES || (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search, byte-level tables: bytes are symbols, nothing is decoded or deferred
+   const bool utf8 = !raw && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
+   // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
+   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
+   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
+   if (FIXUP && class_map_in_lds) {
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * (CH + 1)) + chain_bytes);
+      const uint32_t n16 = 1024u + h->n_pages * 64u;
+      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      __syncthreads();
+      page_p = l16;
+      pages_p = l16 + 1024;
+   }
+   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
+                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
+   const uint32_t sym_ffff = 128u + h->cls_ffff;
+   // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (0xFE, whose table
+   // row is all-dead), so the forward pass reads "past the end" like any other position.  Written once, never overwritten.
+   uint4* tile = tiles + wave * (64 * (CH + 1));
+   tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+
+   bool any_deferred = false;   // wave-uniform: this wave deferred at least one tile to the second pass
+   STAMP_DECL;
+   // One tile: `stage` holds its global loads (issued DEPTH tiles ago); once they are stored to LDS the same registers take the
+   // loads of tile t_next, which stay in flight while this and the following DEPTH-1 tiles are scanned.
+   // marked-tile passes: does tile t hold a row the pass before left behind (FX_NEEDS_GENERAL)?  wave-uniform
+   auto tile_marked = [&](const int64_t t) -> bool {
+      const int64_t rr = (t << 6) + lane;
+      return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
+   };
+   const uint32_t list_count = LIST ? n_deferred[1] : 0u;
+   // `live`: the tile in `stage` is to be scanned (always, except in the marked-tile passes); on return it says so for t_next
+   auto do_tile = [&](uint4 (&stage)[CH], bool& live, const int64_t t, const int64_t t_next) {
+      const int64_t row0 = t << 6;
+      STAMP(7);
+      int64_t row = row0 + lane;   // the row this lane owns and whether it exists
+      bool row_ok = row < n;
+      bool defer_early = false;
+      if (LIST) {
+         // worklist pass: lane r gathers row worklist[64 t + r] straight into its own cells (one row per lane: nothing to transpose)
+         const uint32_t slot = (uint32_t)row0 + lane;
+         row_ok = slot < list_count;
+         row = row_ok ? (int64_t)worklist[slot] : 0;
+         const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+#pragma unroll
+         for (int k = 0; k < CH; ++k) stage[k] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+         for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = stage[k];
+      }
+      uint32_t state = fp.R_start;
+      uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
+      uint32_t na = 0;
+      for (uint32_t seg = S - 1u;; --seg) {   // one pass unless LONG: the row's 256-byte segments, right to left
+         if (!LIST) {
+            const bool process = live;
+            // cheap sampled look at the staged bytes: a tile that shows a byte >= 0x80 here is deferred without being scanned
+            // (tiles whose only such bytes hide in the unsampled registers are caught after the backward pass below)
+            if (MODE == 0 && utf8 && seg == S - 1u) {
+               const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+               defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+            }
+            if (process) store_tile<CH>(stage, tile, lane);
+            STAMP(0);
+            // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
+            // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
+            // loop's back edge: copies behind a vmcnt(0)).  A tile the pass skips is "loaded" with zero valid bytes.
+            const bool last = !LONG || !process || defer_early || seg == 0u;   // nothing more of this tile is wanted
+            if (last) live = MARKED ? tile_marked(t_next) : true;
+            if constexpr (LONG) PREFETCH_SEG(stage, last ? t_next : t, last ? S - 1u : seg - 1u, last ? live : true);
+            else PREFETCH_TILE(stage, t_next, live);
+            if (!process) return;
+         }
+         if (defer_early) {
+            if (row_ok) flags[row] = FX_NEEDS_GENERAL;
+            any_deferred = true;
+            return;
+         }
+         if (FIXUP) {
+            // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
+            // (fxrow::translate_cell16).  The 4 bytes before / after a cell are taken from the ORIGINAL neighbours: the
+            // previous cell's last dword is kept in a register, the next cell is read before anything overwrites it.
+            uint32_t prev = 0;
+            uint4 cur = tile[tile_cell(lane, 0)];
+            for (int k = 0; k < CH; ++k) {
+               const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+               tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+               prev = cur.w;
+               cur = nxt;
+            }
+         }
+         if (ragged) na |= pad_rows<CH>(tile, lane, Lr);
+
+         // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
+         // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
+         // expressible) while the state chain of the current group runs.  Per group only "did any state hit" and the
+         // group's entry state are kept; the exact byte is recovered afterwards by re-walking ONE group per row.
+         STAMP(1);
+#ifdef FX_EXP_NOCOMPUTE
+         {   // experiment: memory path only (loads, LDS staging, outputs), no automaton work
+            uint32_t acc = na;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+               const uint4 c = tile[tile_cell(lane, k)];
+               acc |= c.x | c.y | c.z | c.w;
+            }
+            if (row0 + lane < n) {
+               flags[row0 + lane] = (uint8_t)(acc & 1u);
+               if (SPANS) {
+                  from[row0 + lane] = (int32_t)acc;
+                  to[row0 + lane] = (int32_t)(acc >> 1);
+               }
+            }
+            return;
+         }
+#endif
+         // 8-byte groups to the left of this segment's chunk 0 (the short segment sits right-aligned: its first chunks are not walked)
+         const uint32_t kmin = (LONG && seg == 0u && (Lr & 255u)) ? 16u - ((Lr & 255u) >> 4) : 0u;
+         const uint32_t gbase = LONG ? (seg_byte_search(seg, Lr) >> 3) - 2u * kmin : 0u;
+         F fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
+         if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+         lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll
+         for (int k = CH - 1; k >= 0; --k) {
+            if (LONG && (uint32_t)k < kmin) break;   // wave-uniform: the short segment ends here (the lookups already issued for this chunk are dropped)
+            if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
+            lookup8(fb, wk.x, wk.y, tabR);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fa, state, TRp);
+               gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k + 1) : gsel;
+               esel = mx >= fp.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 1) {
+               wk = wn;
+               lookup8(fa, wk.z, wk.w, tabR);
+               if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fb, state, TRp);
+               gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k) : gsel;
+               esel = mx >= fp.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+         }
+         if (!LONG || seg == 0u) break;
+      }
+      STAMP(2);
+      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
+      {
+         // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
+         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
+         uint2 rw;
+         if (LONG) rw = row_ok ? *reinterpret_cast<const uint2*>(rows + row * (int64_t)L + (int64_t)g * 8) : make_uint2(0, 0);   // (its segment left the tile)
+         else rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+         F f[8];
+         lookup8(f, rw.x, rw.y, tabR);
+         uint32_t st = esel, loc = 8;
+#pragma unroll
+         for (int i = 7; i >= 0; --i) {
+            st = fxstep(f[i], st, TRp);
+            loc = st >= fp.hit_min ? (uint32_t)i : loc;
+         }
+         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
+         const F fz = tabR[0];   // leading NUL
+         state = fxstep(fz, state, TRp);
+         s = state >= fp.hit_min ? 1u : s;
+         if (LONG && !row_ok) s = 0;   // (no row: the forward pass would read global memory)
+      }
+      const uint8_t* fsrc = LONG ? rows + row * (int64_t)L : tb;   // where the forward pass finds the row's bytes
+      // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
+      // TILE is deferred to the second pass (wave-uniform; the raw-byte scan above is discarded and the
+      // forward walk below is skipped).
+      const bool row_hi = MODE == 0 && !raw && (na & 0x80808080u) != 0;
+      const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
+      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8, the row-level fix-up redoes it
+      const bool exception = BYTES && state == fp.inv;
+      const bool nonascii = (row_hi && !utf8) || defer_tile || exception;
+      if (BYTES) {
+         // exception rows are appended to the worklist of the decode pass: one atomic per tile that has any
+         const uint64_t em = __builtin_amdgcn_ballot_w64(exception && row_ok);
+         if (em != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (exception && row_ok) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+         }
+      }
+
+      // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
+      // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk.
+      // The row is extended virtually: position L holds the trailing NUL (byte 0 -> F[0]), later positions kill the state;
+      // an accept after consuming position `pos` gives max_match = pos + 3 for text bytes and for the trailing NUL alike.
+      uint32_t cur = (s != 0 && !nonascii && (SPANS || s == 1) && fp.lit_len == 0) ? fp.A_init : 0u;
+      uint32_t mm = (fp.lit_len != 0 && s != 0) ? s + fp.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
+      uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
+      if (s == 1) {
+         const F f = tabA[0];
+         cur = fxstep(f, cur, TAp);
+         mm = cur >= fp.acc_min ? 2u : 0u;
+      }
+      STAMP(3);
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         // First 32 symbols from j, straight-line: five aligned 8-byte row reads, a byte shift to start exactly at j,
+         // all 32 table lookups issued before the chain; per 8-byte group only "any accept" (v_max3) + entry state
+         // are kept and the last accepting group is re-walked for the exact byte.
+         uint32_t o[8];
+         fetch32<RAGGED, LONG>(o, fsrc, lane, j, (uint32_t)L);
+         constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
+         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
+#pragma unroll
+         for (int gb = 0; gb < 4; gb += GB) {
+            F f[8 * GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+               const uint32_t entry = cur;
+               uint32_t st[8];
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f[8 * g + q], cur, TAp);
+                  st[q] = cur;
+               }
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool hit = mx >= fp.acc_min;
+               gl = hit ? (uint32_t)(gb + g) : gl;
+               el = hit ? entry : el;
+               blo = hit ? o[2 * (gb + g)] : blo;
+               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
+            }
+         }
+         {
+            F fr8[8];
+            lookup8(fr8, blo, bhi, tabA);
+            uint32_t st = el, loc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               st = fxstep(fr8[q], st, TAp);
+               loc = st >= fp.acc_min ? (uint32_t)q : loc;
+            }
+            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+         }
+         j += 32u;
+         STAMP(4);
+         // matches longer than the window: 8 symbols per round trip
+         while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+            if (cur != 0) {
+               uint32_t o8[2];
+               fetch8<RAGGED, LONG>(o8, fsrc, lane, j, (uint32_t)L);
+               F f8[8];
+               lookup8(f8, o8[0], o8[1], tabA);
+               uint32_t loc = 8;
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f8[q], cur, TAp);
+                  loc = cur >= fp.acc_min ? (uint32_t)q : loc;
+               }
+               mm = loc != 8u ? j + loc + 3u : mm;
+               j += 8u;
+            }
+         }
+      }
+      STAMP(5);
+      uint32_t flag = 0;
+      int32_t fr = 0, tt = 0;
+      if (SPANS) {
+         if (s != 0 && mm != 0) {   // api_internal_m.F90:140-148
+            fr = (int32_t)(s - 1);
+            if (fr == 0) fr = 1;
+            tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
+            if (fr > 0 && tt > 0) flag = 1;
+            else { fr = 0; tt = 0; }
+         }
+      } else {
+         flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
+      }
+      if (nonascii) flag = FX_NEEDS_GENERAL;
+      any_deferred = any_deferred || defer_tile;
+      if (row_ok) {
+         flags[row] = (uint8_t)flag;
+         if (SPANS) {
+            from[row] = fr;
+            to[row] = tt;
+         }
+      }
+   };
+   if (LIST) {
+      uint4 stage[CH];
+      bool live = true;
+      for (int64_t t = wave_global; (uint64_t)(t << 6) < list_count; t += wave_stride) do_tile(stage, live, t, t);
+   } else {
+      // DEPTH tiles of global loads in flight per wave (HBM latency under load is several microseconds).  The marked-tile passes
+      // run the same pipeline: a tile they skip costs one read of its flags and 16 loads that are range-checked away.
+      constexpr int DEPTH = FX_PREFETCH_DEPTH;
+      uint4 stage[DEPTH][CH];
+      bool live[DEPTH];
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+         live[d] = MARKED ? tile_marked(wave_global + d * wave_stride) : true;
+         if constexpr (LONG) PREFETCH_SEG(stage[d], wave_global + d * wave_stride, S - 1u, live[d]);
+         else PREFETCH_TILE(stage[d], wave_global + d * wave_stride, live[d]);
+      }
+      for (int64_t t = wave_global;;) {   // (leaving the loop from the middle keeps the staging registers free of merges)
+         bool done = false;
+#pragma unroll
+         for (int d = 0; d < DEPTH; ++d) {
+            if (done || t >= n_tiles) {
+               done = true;
+               continue;
+            }
+            do_tile(stage[d], live[d], t, t + DEPTH * wave_stride);
+            t += wave_stride;
+         }
+         if (done) break;
+      }
+   }
+   STAMP(6);
+   STAMP_FLUSH;
+   // one plain store per wave (not an atomic per tile: 16k same-address atomics cost ~0.2 ms); the value only gates the second pass
+   if (MODE == 0 && any_deferred && lane == 0) n_deferred[0] = 1u;
+}
+
+// =========================================================================================================
+// fx_match_fast: `.match.` on the tile kernel.  One forward pass of the anchored automaton over every byte of the row from
+// M_start (the state after the optional leading NUL, api_internal_m.F90:280-289), verdict = the state's FINAL bit (accept at
+// ci = n+2 or after the trailing NUL, :296-302), behind the reference's literal / prefix / suffix gate (forgex.F90:207-213,
+// api_internal_m.F90:199-233) which is evaluated on the raw row bytes.  Same staging, schemes and UTF-8 second pass as the
+// search kernel.
+// =========================================================================================================
+template <class F>
+__device__ __forceinline__ void chain8_fwd(const F (&f)[8], uint32_t& state, const uint8_t* T) {
+#pragma unroll
+   for (int i = 0; i < 8; ++i) state = fxstep(f[i], state, T);
+}
+
+// 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides (fxrow::match_gate on the row's bytes in the LDS tile)
+__device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t* __restrict__ prog, const uint8_t* tb, uint32_t lane, uint32_t L) {
+   auto row = [&](uint32_t j) -> uint32_t { return tb[(tile_cell(lane, j >> 4) << 4) + (j & 15u)]; };
+   return fxrow::match_gate(h, prog, row, L);
+}
+
+// MODE as in fx_search_fast (BYTES modes: a row whose walk ends inside a character or in the INVALID state -- FINAL column 2 -- is
+// left to the row-level fix-up)
+template <int CH, int MODE, int SCH, bool RAGGED, bool LONG = false>
+__global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+                                                       FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
+                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
+                                                       uint32_t* __restrict__ worklist) {
+   const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
+   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;       // LONG: 256-byte segments per row (the last one shorter when Lr % 256 != 0), left to right
+   constexpr bool ragged = RAGGED;
+   static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
+   constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
+   constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
+   static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
+   static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
+   if ((MARKED || LIST) && n_deferred[fp.gate_word] == 0) return;
+   if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
+      clear_next[0] = 0u;
+      clear_next[1] = 0u;
+   }
+   using F = typename FxF<SCH>::type;
+   __shared__ uint2 permA[SCH == 0 ? 256 : 1];
+   __shared__ uint4 wideA[WIDE ? 256 : 1];
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
+   const uint32_t ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
+   const uint32_t chain_bytes = CHAIN ? ((512u + ta_bytes + 15u) & ~15u) : 0u;
+   const uint8_t* TAp = reinterpret_cast<const uint8_t*>(cmap) + 512;
+   if (CHAIN) {
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_cls : h->off_chain_cls));
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
+      const uint32_t na = ta_bytes / 2;
+      for (uint32_t i = threadIdx.x; i < 256u + na; i += 256u) cmap[i] = i < 256u ? g[i] : ga[i - 256u];
+   } else if (WIDE) {
+      wideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16A : h->off_w16A))[threadIdx.x];
+   } else {
+      permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
+   }
+   __syncthreads();
+   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+   const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const bool utf8 = !BYTES && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
+   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
+   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
+   if (FIXUP && class_map_in_lds) {
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * CH) + chain_bytes);
+      const uint32_t n16 = 1024u + h->n_pages * 64u;
+      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      __syncthreads();
+      page_p = l16;
+      pages_p = l16 + 1024;
+   }
+   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
+                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
+   const uint32_t sym_ffff = 128u + h->cls_ffff;
+   uint4* tile = tiles + wave * (64 * CH);
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   bool any_deferred = false;
+   auto tile_marked = [&](const int64_t t) -> bool {
+      const int64_t rr = (t << 6) + lane;
+      return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
+   };
+   const uint32_t list_count = LIST ? n_deferred[1] : 0u;
+   uint4 stage[CH];
+   bool live = true;   // the tile in `stage` is to be scanned (always, except in the marked-tile passes)
+   if (!LIST) {
+      live = MARKED ? tile_marked(wave_global) : true;
+      if constexpr (LONG) PREFETCH_SEG_FWD(stage, wave_global, 0u, live);
+      else PREFETCH_TILE(stage, wave_global, live);
+   }
+   for (int64_t t = wave_global; LIST ? (uint64_t)(t << 6) < list_count : t < n_tiles; t += wave_stride) {
+      const int64_t row0 = t << 6;
+      int64_t row = row0 + lane;   // the row this lane owns and whether it exists
+      bool row_ok = row < n;
+      bool defer_early = false;
+      if (LIST) {
+         // worklist pass: lane r gathers row worklist[64 t + r] straight into its own cells
+         const uint32_t slot = (uint32_t)row0 + lane;
+         row_ok = slot < list_count;
+         row = row_ok ? (int64_t)worklist[slot] : 0;
+         const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+#pragma unroll
+         for (int k = 0; k < CH; ++k) stage[k] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+         for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = stage[k];
+      }
+      uint32_t st = fp.A_init;   // = M_start
+      uint32_t na = 0;
+      uint32_t gate = 1u;
+      bool skip = false;
+      for (uint32_t seg = 0;; ++seg) {   // one pass unless LONG: the row's 256-byte segments, left to right
+         if (!LIST) {
+            const bool process = live;
+            if (MODE == 0 && utf8 && seg == 0u) {
+               const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+               defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+            }
+            if (process) store_tile<CH>(stage, tile, lane);
+            const bool last = !LONG || !process || defer_early || seg + 1u == S;   // nothing more of this tile is wanted
+            if (last) live = MARKED ? tile_marked(t + wave_stride) : true;
+            // the one reload site of the staging registers
+            if constexpr (LONG) PREFETCH_SEG_FWD(stage, last ? t + wave_stride : t, last ? 0u : seg + 1u, last ? live : true);
+            else PREFETCH_TILE(stage, t + wave_stride, live);
+            if (!process) {
+               skip = true;
+               break;
+            }
+         }
+         if (defer_early) {
+            if (row_ok) flags[row] = FX_NEEDS_GENERAL;
+            any_deferred = true;
+            skip = true;
+            break;
+         }
+         if (seg == 0u) {   // on the raw bytes, before any decode (long rows: straight from global memory)
+            if (LONG) {
+               const uint8_t* rp = rows + row * (int64_t)L;
+               auto rowb = [&](uint32_t j) -> uint32_t { return rp[j]; };
+               gate = row_ok ? fxrow::match_gate(h, prog, rowb, L) : 0u;
+            } else {
+               gate = match_gate(h, prog, tb, lane, L);
+            }
+         }
+         if (FIXUP) {
+            uint32_t prev = 0;
+            uint4 cur = tile[tile_cell(lane, 0)];
+            for (int k = 0; k < CH; ++k) {
+               const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+               tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+               prev = cur.w;
+               cur = nxt;
+            }
+         }
+         if (ragged) na |= pad_rows<CH>(tile, lane, Lr);
+         // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
+         F fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
+         if (CH >= 2) wn = tile[tile_cell(lane, 1)];
+         lookup8(fa, wk.x, wk.y, tabA);
+         const int nch = (LONG && (seg + 1u) * 256u > Lr) ? (int)((Lr & 255u) >> 4) : CH;   // chunks of this segment
+#pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
+         for (int k = 0; k < nch; ++k) {
+            if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
+            lookup8(fb, wk.z, wk.w, tabA);
+            __builtin_amdgcn_sched_barrier(0);
+            chain8_fwd(fa, st, TAp);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < CH) {
+               wk = wn;
+               lookup8(fa, wk.x, wk.y, tabA);
+               if (k + 2 < CH) wn = tile[tile_cell(lane, k + 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            chain8_fwd(fb, st, TAp);
+            __builtin_amdgcn_sched_barrier(0);
+         }
+         if (!LONG || seg + 1u == S) break;
+      }
+      if (skip) continue;
+      uint32_t fin;
+      if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * ((BYTES ? h->byte_n_classes : h->n_classes) + 2u));   // FINAL column
+      else if (WIDE) {
+         const uint32_t* fm = BYTES ? h->bw16_finalM : h->w16_finalM;
+         fin = fxstep(make_uint4(fm[0], fm[1], fm[2], fm[3]), st, nullptr) & 3u;
+      } else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
+      uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin == 1u ? 1u : 0u));
+      const bool row_hi = MODE == 0 && (na & 0x80808080u) != 0;
+      const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
+      const bool exception = BYTES && gate == 1u && st != 0 && fin == 2u;   // inside a character / INVALID at the end of the row
+      if (BYTES) {   // exception rows are appended to the worklist of the decode pass
+         const uint64_t em = __builtin_amdgcn_ballot_w64(exception && row_ok);
+         if (em != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (exception && row_ok) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+         }
+      }
+      if ((row_hi && !utf8) || defer_tile || exception) flag = FX_NEEDS_GENERAL;
+      any_deferred = any_deferred || defer_tile;
+      if (row_ok) flags[row] = (uint8_t)flag;
+   }
+   if (MODE == 0 && any_deferred && lane == 0) n_deferred[0] = 1u;
+}
+
+// MODE: 0 first pass, 1 decode second pass, 2 byte-level tables over all tiles, 3 byte-level tables over marked tiles
+// n_deferred: this call's two words ([0] tiles deferred, [1] exception rows left); the other call parity's pair is 8 bytes away
+template <int CH, int MODE, int SCH>
+hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
+                              int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);   // the other parity's pair (16-byte aligned block)
+   const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;   // (worklist pass: the host only knows an upper bound)
+   int64_t blocks = (n_tiles + 3) / 4;
+   const int64_t cap = MODE == 4 ? 256 : 256 * 8;   // grid-stride beyond this (guide §6 G11)
+   if (blocks > cap) blocks = cap;
+   // decode passes: the BMP class map rides behind the tiles when it fits
+   const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column
+   const bool ragged = Lr != 16u * CH;
+   const bool spans = from && to;
+   if (Lr > 256u) {   // long rows (a multiple of 256 bytes): segment-walking instantiation, CH = 16, first-pass / byte-level modes only
+      if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
+         constexpr int CHN = SCH;
+         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<16, true, MODE, CHN, false, true>)
+                                : reinterpret_cast<const void*>(&fx_search_fast<16, false, MODE, CHN, false, true>);
+         if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+         }
+         if (spans) hipLaunchKernelGGL((fx_search_fast<16, true, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<16, false, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         return hipGetLastError();
+      } else {
+         return hipErrorInvalidValue;   // (never dispatched)
+      }
+   }
+   if constexpr (MODE >= 2) {   // whole-chunk rows only: byte-level tables (2, 3: chain scheme) and the worklist decode pass (4)
+      constexpr int CHN = SCH;
+      if (ragged) return hipErrorInvalidValue;   // (never dispatched)
+      const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false>)
+                             : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false>);
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      return hipGetLastError();
+   } else {
+      const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, true>)
+                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, true>))
+                              : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, false>)
+                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, false>));
+      if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      if (ragged) {
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      } else {
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+      }
+      return hipGetLastError();
+   }
+}
+
+template <int CH, int MODE, int SCH>
+hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
+                               uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);
+   const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;
+   int64_t blocks = (n_tiles + 3) / 4;
+   if (blocks > (MODE == 4 ? 256 : 256 * 8)) blocks = MODE == 4 ? 256 : 256 * 8;
+   const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
+   const bool ragged = Lr != 16u * CH;
+   if (Lr > 256u) {   // long rows
+      if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
+         constexpr int CHN = SCH;
+         const void* fn = reinterpret_cast<const void*>(&fx_match_fast<16, MODE, CHN, false, true>);
+         if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+         }
+         hipLaunchKernelGGL((fx_match_fast<16, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+         return hipGetLastError();
+      } else {
+         return hipErrorInvalidValue;
+      }
+   }
+   if constexpr (MODE >= 2) {
+      constexpr int CHN = SCH;
+      if (ragged) return hipErrorInvalidValue;
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      return hipGetLastError();
+   } else {
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, true>)
+                                                   : reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      else hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      return hipGetLastError();
+   }
+}
+
+
+// every (CH, MODE, SCH) the dispatch code of fxamd.hip can ask for
+#define FX_TILE_COMBOS(X, CH) \
+   X(CH, 0, 0) X(CH, 0, 1) X(CH, 0, 2) X(CH, 1, 0) X(CH, 1, 1) X(CH, 1, 2) X(CH, 4, 0) X(CH, 4, 1) X(CH, 4, 2) X(CH, 2, 1) X(CH, 2, 2) X(CH, 3, 1) X(CH, 3, 2)
+#define FX_TILE_ALL(X) \
+   FX_TILE_COMBOS(X, 1) FX_TILE_COMBOS(X, 2) FX_TILE_COMBOS(X, 3) FX_TILE_COMBOS(X, 4) FX_TILE_COMBOS(X, 6) FX_TILE_COMBOS(X, 8) FX_TILE_COMBOS(X, 12) FX_TILE_COMBOS(X, 16)
+#define FX_TILE_SIG_FAST \
+   (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t*, int64_t)
+#define FX_TILE_SIG_MATCH (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, uint32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t*, int64_t)
