@@ -211,6 +211,26 @@ def main():
                 "frac": (alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms else None,
                 "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
 
+    # ---- the pure `.in.` verdict (flags only, no spans) on the same rows: an extra, separately timed leg ---------------------------
+    flags_only = None
+    if spans:
+        try:
+            out_f = (flags, None, None)
+            for _ in range(2):
+                prog.match_device(rows, spans=False, out=out_f)
+            barrier()
+            f0 = time.perf_counter()
+            for _ in range(args.steps):
+                prog.match_device(rows, spans=False, out=out_f)
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - f0
+            flags_only = {"value": world * rows_per_gpu * row_len * args.steps / fdt / 1e9, "unit": "GB/s (this rank's time, all ranks' bytes)",
+                          "ms_per_step": fdt / args.steps * 1e3}
+            step()   # restore flags + spans for the checks below
+            torch.cuda.synchronize()
+        except Exception:
+            flags_only = None
+
     # ---- measured device-copy ceiling in the same run: rows -> scratch, read + write bytes per second ----
     copy_gbs = None
     try:
@@ -256,7 +276,7 @@ def main():
                 "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches},
             "frac_of_hbm_peak": total_bytes / dt / 1e9 / (HBM_PEAK_GBS * world),
             "frac_of_one_eighth_gpu": total_bytes / dt / 1e9 / (HBM_PEAK_GBS / 8 * world),
-            "roofline": roofline, "gather_ms": gather_ms,
+            "roofline": roofline, "gather_ms": gather_ms, "flags_only": flags_only,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, pattern, row_len)
