@@ -85,12 +85,14 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __r
 // Rows whose length Lr is not 16*CH (Lr % 4 == 0, 16 <= Lr <= 16*CH): the same 64-row tile, but piece (R, k) comes from byte
 // R*Lr + 16k of the tile (dword aligned, not 16-byte aligned) and the bytes behind the row end are delivered as ZERO.  The
 // last partial chunk is read as the row's LAST 16 bytes and shifted down, so nothing beyond the caller's buffer is touched.
-struct __attribute__((aligned(4))) U4a {
+struct __attribute__((packed, aligned(1))) U4a {   // rows of any length start at any byte: the 16-byte pieces are unaligned loads
    uint32_t x, y, z, w;
 };
 template <int CH>
 __device__ __forceinline__ void load_tile_ragged(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane,
                                                  uint32_t Lr) {
+   // the row's last, partial chunk: its rem = Lr % 16 bytes are the tail of the row's LAST 16 bytes, shifted down (wave-uniform shift)
+   const uint32_t rem = Lr & 15u, sh = 16u - rem, sw = sh >> 2, sb = sh & 3u;
 #pragma unroll
    for (int q = 0; q < CH; ++q) {
       const uint32_t p = q * 64 + lane, R = p / CH, k = p % CH;
@@ -103,8 +105,12 @@ __device__ __forceinline__ void load_tile_ragged(uint4 (&v)[CH], const uint8_t* 
             o = make_uint4(t.x, t.y, t.z, t.w);
          } else {
             const U4a t = *reinterpret_cast<const U4a*>(rp + Lr - 16u);   // bytes [Lr-16, Lr)
-            const uint32_t rem = Lr - 16u * k;                            // 4, 8 or 12 valid bytes
-            o = rem == 12u ? make_uint4(t.y, t.z, t.w, 0) : (rem == 8u ? make_uint4(t.z, t.w, 0, 0) : make_uint4(t.w, 0, 0, 0));
+            const uint32_t w[8] = {t.x, t.y, t.z, t.w, 0u, 0u, 0u, 0u};
+            uint32_t m[5];   // the four words from word sw on, and the one behind them
+#pragma unroll
+            for (int i = 0; i < 5; ++i) m[i] = sw == 0u ? w[i] : (sw == 1u ? w[i + 1] : (sw == 2u ? w[i + 2] : w[i + 3]));
+            o = make_uint4(fxrow::fx_alignbyte(m[1], m[0], sb), fxrow::fx_alignbyte(m[2], m[1], sb), fxrow::fx_alignbyte(m[3], m[2], sb),
+                           fxrow::fx_alignbyte(m[4], m[3], sb));
          }
       }
       v[q] = o;
@@ -122,10 +128,15 @@ __device__ __forceinline__ uint32_t pad_rows(uint4* tile, uint32_t lane, uint32_
       na |= c.x | c.y | c.z | c.w;
       const uint32_t b = 16u * k;
       if (b + 16u <= Lr) continue;   // wave-uniform
-      c.x = b + 0u < Lr ? c.x : 0xFFFFFFFFu;
-      c.y = b + 4u < Lr ? c.y : 0xFFFFFFFFu;
-      c.z = b + 8u < Lr ? c.z : 0xFFFFFFFFu;
-      c.w = b + 12u < Lr ? c.w : 0xFFFFFFFFu;
+      auto pad = [&](uint32_t wv, uint32_t at) -> uint32_t {   // bytes of the word at row offset `at` that lie behind the row end -> 0xFF
+         if (at + 4u <= Lr) return wv;
+         if (at >= Lr) return 0xFFFFFFFFu;
+         return wv | (0xFFFFFFFFu << (8u * (Lr - at)));
+      };
+      c.x = pad(c.x, b + 0u);
+      c.y = pad(c.y, b + 4u);
+      c.z = pad(c.z, b + 8u);
+      c.w = pad(c.w, b + 12u);
       tile[tile_cell(lane, k)] = c;
    }
    return na;
@@ -247,11 +258,17 @@ __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const ui
       hi = r.y;
       return;
    }
-   const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8, L a multiple of 4
+   const uint32_t pc = p < L ? p : 0u;   // p is a multiple of 8, L is any length
    const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 15u));
-   // 0x00 at index L (the trailing NUL), 0xFE (the symbol id whose table row is all-dead) behind it
-   lo = p + 4u <= L ? r.x : (p == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
-   hi = p + 8u <= L ? r.y : (p + 4u == L ? 0xFEFEFE00u : 0xFEFEFEFEu);
+   // 0x00 at index L (the trailing NUL), 0xFE (the symbol id whose table row is all-dead) behind it -- at byte granularity
+   auto word = [&](uint32_t wv, uint32_t at) -> uint32_t {
+      if (at + 4u <= L) return wv;
+      if (at >= L) return at == L ? 0xFEFEFE00u : 0xFEFEFEFEu;
+      const uint32_t sh = 8u * (L - at);   // 8, 16 or 24: that many low bits are text
+      return (wv & ~(0xFFFFFFFFu << sh)) | (0xFEFEFE00u << sh);
+   };
+   lo = word(r.x, p);
+   hi = word(r.y, p + 4u);
 }
 template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {

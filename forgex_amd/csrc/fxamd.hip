@@ -256,7 +256,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
 static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
    if ((reinterpret_cast<uintptr_t>(d_rows) & 15u) != 0) return false;
    if (long_row(row_len)) return true;
-   if (row_len < 16 || row_len > 256 || (row_len & 3) != 0) return false;
+   if (row_len < 16 || row_len > 256) return false;   // (any length in between: rows that are not whole chunks are padded in LDS)
    if (row_len == 16 * tile_chunks(row_len)) return true;       // whole chunks: fully coalesced tile loads
    return (h.flags & FXP_F_RAGGED_OK) != 0;                        // padded in LDS with the inert symbol 255
 }

@@ -279,7 +279,8 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
         if p.status != 0 or not (p.info()["flags"] & (8 | 256)):   # v_perm tables or class-indexed chain tables
             continue
         n_fast += 1
-        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252, 272, 512, 784])   # incl. ragged (not a multiple of 16) and long rows
+        L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252, 272, 512, 784,
+                        17, 30, 50, 75, 99, 250, 255])   # incl. ragged (any length that is not a multiple of 16) and long rows
         n = 192
         rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
         mixed = []
@@ -378,8 +379,9 @@ def test_match_operator_on_tile_kernel(fx):
     nrng = np.random.default_rng(23)
     cases = [(rb"\d{3}-\d{4}", b"0123456789-", 16), (rb"[a-z]+\d+", b"abcxyz0189 ", 32), (rb"ab[cd]e*f", b"abcdef", 16),
              (rb"foo(bar|baz)x*", b"fobarzx", 16), (rb"^abc.*xyz$", b"abcxyz.\n", 32), ("[ぁ-ん]+[0-9]*".encode(), None, 48),
-             # ragged row lengths (L % 4 == 0, not a multiple of 16): padded with the inert symbol in LDS
+             # ragged row lengths (any length that is not a multiple of 16): padded with the inert symbol in LDS
              (rb"[a-z]+\d+", b"abcxyz0189 ", 20), (rb"ab[cd]e*f", b"abcdef", 36), (rb"^abc.*xyz$", b"abcxyz.\n", 100),
+             (rb"[a-z]+\d+", b"abcxyz0189 ", 29), (rb"^abc.*xyz$", b"abcxyz.\n", 101), (rb"(ab|cd)+\d", b"abcd01", 255),
              (rb"(ab|cd|ef|gh|ij|kl)+\d{2}", b"abcdefghijkl01", 52), ("[ぁ-ん]+[0-9]*".encode(), None, 60)]
     for pat, alpha, L in cases:
         if alpha is None:
@@ -415,7 +417,7 @@ def test_literal_index_search_on_tile_kernel(fx):
     """Whole-pattern literals (`.in.` = raw-byte INDEX, forgex.F90:111-130): reverse-KMP tables on the tile kernel, raw bytes
     (no UTF-8 decode), short (v_perm) and long (chain) literals, overlapping occurrences, occurrences at both row ends."""
     nrng = np.random.default_rng(31)
-    for lit, L in ((b"ab", 20), (b"abcab", 100), (b"needle in a hay", 252), ("あいう".encode(), 84), (b"ab", 16), (b"aa", 32), (b"abcab", 64), (b"fooba", 64), (b"abcabcabx", 128), ("あいう".encode(), 96), (b"needle in a hay", 256),
+    for lit, L in ((b"ab", 20), (b"abcab", 100), (b"needle in a hay", 252), (b"ab", 17), (b"abcab", 99), (b"needle in a hay", 255), ("あいう".encode(), 77), ("あいう".encode(), 84), (b"ab", 16), (b"aa", 32), (b"abcab", 64), (b"fooba", 64), (b"abcabcabx", 128), ("あいう".encode(), 96), (b"needle in a hay", 256),
                    (b"a", 16), (b"zzzzzzz", 48)):
         p = fx.Program(lit, fx.OP_SEARCH)
         assert p.status == 0 and p.info()["mode"] == 2 and (p.info()["flags"] & (8 | 256)), lit
