@@ -103,7 +103,17 @@ __device__ __forceinline__ void load_tile_ragged(uint4 (&v)[CH], const uint8_t* 
          if (16u * k + 16u <= Lr) {
             const U4a t = *reinterpret_cast<const U4a*>(rp + 16u * k);
             o = make_uint4(t.x, t.y, t.z, t.w);
+         } else if (Lr < 16u && (row + 1) * (int64_t)Lr + 16 <= n * (int64_t)Lr) {
+            // rows shorter than one chunk: the 16 bytes FROM the row start (they run into the following rows, still inside the
+            // buffer), cut off behind the row's own bytes
+            const U4a t = *reinterpret_cast<const U4a*>(rp);
+            const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+            uint32_t c4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c4[i] = 4u * i + 4u <= Lr ? w4[i] : (4u * i >= Lr ? 0u : (w4[i] & ~(0xFFFFFFFFu << (8u * (Lr - 4u * i)))));
+            o = make_uint4(c4[0], c4[1], c4[2], c4[3]);
          } else {
+            // (rows shorter than one chunk at the very end of the buffer come here too: their last 16 bytes start in earlier rows)
             const U4a t = *reinterpret_cast<const U4a*>(rp + Lr - 16u);   // bytes [Lr-16, Lr)
             const uint32_t w[8] = {t.x, t.y, t.z, t.w, 0u, 0u, 0u, 0u};
             uint32_t m[5];   // the four words from word sw on, and the one behind them

@@ -256,7 +256,8 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
 static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
    if ((reinterpret_cast<uintptr_t>(d_rows) & 15u) != 0) return false;
    if (long_row(row_len)) return true;
-   if (row_len < 16 || row_len > 256) return false;   // (any length in between: rows that are not whole chunks are padded in LDS)
+   if (row_len < 2 || row_len > 256) return false;   // (any length in between: rows that are not whole chunks are padded in LDS;
+                                                      //  a one-byte row can be the single blank of api_internal_m.F90:68-74)
    if (row_len == 16 * tile_chunks(row_len)) return true;       // whole chunks: fully coalesced tile loads
    return (h.flags & FXP_F_RAGGED_OK) != 0;                        // padded in LDS with the inert symbol 255
 }
@@ -474,7 +475,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (p->prog.status != 0) return FXAMD_E_ARG;
    const FxpHeader& h = p->prog.hdr();
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme < 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
+   if (scheme < 0 || h.mode == FXP_MODE_MATCH_ENGINE || (row_len < 16 && n * row_len < 32)) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);
@@ -539,7 +540,8 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       d_from = nullptr;
       d_to = nullptr;
    }
-   const int scheme = fast_scheme(h, d_rows, row_len);
+   int scheme = fast_scheme(h, d_rows, row_len);
+   if (row_len < 16 && n * row_len < 32) scheme = -1;   // (the ragged loader of sub-chunk rows wants 16 readable bytes around every row)
    if (scheme >= 0) {
       const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
       uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);   // this call's words: [0] tiles deferred, [1] exception rows left

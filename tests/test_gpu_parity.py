@@ -280,7 +280,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
             continue
         n_fast += 1
         L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252, 272, 512, 784,
-                        17, 30, 50, 75, 99, 250, 255])   # incl. ragged (any length that is not a multiple of 16) and long rows
+                        17, 30, 50, 75, 99, 250, 255, 2, 3, 5, 8, 11, 15])   # incl. ragged (any length that is not a multiple of 16), tiny and long rows
         n = 192
         rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
         mixed = []
@@ -404,13 +404,13 @@ def test_match_operator_on_tile_kernel(fx):
         assert prog.last_path() in (1, 3, 5, 6, 7, 8), (pat, prog.last_path())
         of, _, _ = oracle_lib.batch(1, pat, rows, NT)
         assert np.array_equal(f, of), pat
-    # 8-byte rows of BASELINE config 1 go through the general kernel (row length not a multiple of 16): still bit-exact
+    # the 8-byte rows of BASELINE config 1: shorter than one chunk, still on the tile kernel (ragged instantiation)
     import torch
     from forgex_amd import synth
     rows = synth.batch("cfg1", 0, 1000, torch.device("cpu")).numpy()
     prog, f, _, _ = _device_run(fx, synth.PATTERNS["cfg1"].encode(), fx.OP_MATCH, rows, spans=False)
     of, _, _ = oracle_lib.batch(1, synth.PATTERNS["cfg1"].encode(), rows, NT)
-    assert np.array_equal(f, of) and prog.last_path() == 2
+    assert np.array_equal(f, of) and prog.last_path() in (5, 6, 7), prog.last_path()
 
 
 def test_literal_index_search_on_tile_kernel(fx):
