@@ -73,7 +73,11 @@ int fxamd_program_upload(fxamd_program* p);
 /* Device-resident batch: d_rows, d_flags (n bytes: 0/1), d_from, d_to (n int32 each, may both be NULL) are
  * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
  * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
- * `.match.`: flags = verdict, from/to untouched.  Invalid pattern: all flags 0, from/to 0. */
+ * `.match.`: flags = verdict, from/to untouched.  Invalid pattern: all flags 0, from/to 0.
+ * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2..256 bytes and rows
+ * whose length is a multiple of 16 up to 64 KiB when d_rows is 16-byte aligned, other shapes run on the general kernel
+ * (one lane per row, roughly 20x slower).  Calls on ONE handle must not overlap in time (per-handle device scratch);
+ * distinct handles are independent. */
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream);
 
