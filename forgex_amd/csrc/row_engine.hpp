@@ -344,6 +344,10 @@ FX_HD Cell16 translate_cell16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3
       const uint32_t ff_hi = (hi >> 7) * 0xFFu, ff_cov = (cov >> 7) * 0xFFu, ff_inv = (inval >> 7) * 0xFFu;
       out[d - 1] = (w[d] & ~ff_hi) | ff_cov | (ff_inv & ffff_rep);   // valid lead bytes are patched below
    }
+   // no valid lead byte in this cell (ASCII plus broken bytes, e.g. Latin-1 text): nothing to classify -- on the device the whole
+   // wave skips the code point assembly when that holds for all of its rows
+   if (((V2[1] | V3[1] | V4[1]) | (V2[2] | V3[2] | V4[2]) | (V2[3] | V3[3] | V4[3]) | (V2[4] | V3[4] | V4[4])) == 0)
+      return Cell16{out[0], out[1], out[2], out[3]};
    // classes of the valid lead bytes: code point assembly + BMP page lookup, all 16 positions independent
    uint32_t code[16];
 #pragma unroll
