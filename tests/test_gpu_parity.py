@@ -265,14 +265,16 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
     import fuzz_diff
     if not byte_tables:
         monkeypatch.setenv("FXAMD_NO_BYTE_DFA", "1")
-    rng = random.Random(99 if byte_tables else 100)
-    nrng = np.random.default_rng(99)
+    seed = int(os.environ.get("FX_FUZZ_SEED", "0"))   # (FX_FUZZ_SEED / FX_FUZZ_PATTERNS: longer soak runs than the default suite)
+    want = int(os.environ.get("FX_FUZZ_PATTERNS", "60"))
+    rng = random.Random((99 if byte_tables else 100) + 1000 * seed)
+    nrng = np.random.default_rng(99 + seed)
     ascii_alpha = np.frombuffer(b"abcxyz019 .-\n\tAZ_@", dtype=np.uint8)
     pieces = [b"a", b"b", b"c", b"x", b"0", b"9", b" ", b".", "あ".encode(), "ん".encode(), "α".encode(), "ω".encode(), "é".encode(),
               b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
     n_fast = 0
     tried = 0
-    while n_fast < 60 and tried < 1200:
+    while n_fast < want and tried < 20 * want:
         tried += 1
         pat = fuzz_diff.gen_pattern(rng).encode()
         p = fx.Program(pat, fx.OP_SEARCH)
