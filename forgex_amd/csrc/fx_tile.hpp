@@ -186,10 +186,10 @@ struct FastParams {
    uint32_t lit_len;        // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
 };
 
-// 8 independent table lookups for 8 bytes: F[b] = 8 next-state bytes (one per current state)
-// Two table schemes share the kernel (template parameter CHAIN):
-//   v_perm scheme  (<= 8 states): F = uint2 = the 8 next-state bytes of the symbol; step = ONE v_perm_b32.
-//   chain scheme   (larger automata): F = 2 * column of the symbol's class (uint16 map, state-independent, pipelined the same
+// 8 independent table lookups for 8 bytes.  Three table schemes share the kernels (template parameter SCH):
+//   0 v_perm       (<= 8 states): F = uint2 = the 8 next-state bytes of the symbol; step = ONE v_perm_b32.
+//   2 wide v_perm  (<= 16 states): F = uint4 = 16 encoded next-state bytes; step = two v_perm_b32 and an AND (see fxstep below).
+//   1 chain        (larger automata): F = 2 * column of the symbol's class (uint16 map, state-independent, pipelined the same
 //                  way); the state is the byte offset of its row in a class-indexed uint16 table held in LDS and the step is a
 //                  dependent ds_read_u16 of T[state + F] (the destination's row offset).
 template <class F, class TabT>

@@ -1,8 +1,8 @@
 // libforgex_amd.so: HIP kernels (gfx950 / CDNA4) + the C ABI of include/forgex_amd.h.
 //
 // Two kernel families:
-//   fx_search_fast<CH>   the hot kernel.  One wavefront owns a tile of 64 consecutive rows (64 x 16*CH bytes,
-//                        contiguous in HBM): 16-byte/lane coalesced global loads -> XOR-swizzled ds_write_b128
+//   fx_search_fast<CH>   (fx_tile.hpp, with fx_match_fast) the hot kernel.  One wavefront owns a tile of 64 consecutive rows
+//                        (64 x 16*CH bytes, contiguous in HBM): 16-byte/lane coalesced buffer loads -> swizzled ds_write_b128
 //                        -> transposed ds_read_b128 so that lane r holds row r.  The per-byte state advance is
 //                        ONE ds_read_b64 of the fused byte table F[byte] (8 next-state bytes, independent of the
 //                        state, so lookups pipeline) + ONE v_perm_b32 (state selects its byte).  Right-to-left
