@@ -133,6 +133,26 @@ class Program:
         return flags, frm, to
 
 
+def match_many(programs, rows, spans=True):
+    """m compiled programs against the same device-resident rows (torch uint8 CUDA tensor [n, L]): flags [m, n] (and from / to)."""
+    import torch
+    if not rows.is_cuda or rows.dtype != torch.uint8 or rows.dim() != 2 or not rows.is_contiguous():
+        raise ValueError("rows must be a contiguous uint8 CUDA tensor of shape [n, row_len]")
+    n, rl = rows.shape
+    m = len(programs)
+    flags = torch.empty((m, n), dtype=torch.uint8, device=rows.device)
+    frm = torch.zeros((m, n), dtype=torch.int32, device=rows.device) if spans else None
+    to = torch.zeros((m, n), dtype=torch.int32, device=rows.device) if spans else None
+    handles = (ctypes.c_void_p * m)(*[p._h for p in programs])
+    stream = torch.cuda.current_stream(rows.device).cuda_stream
+    with torch.cuda.device(rows.device):
+        rc = _lib.lib().fxamd_match_multi_device(handles, m, rows.data_ptr() if n else None, n, rl, flags.data_ptr(),
+                                                 frm.data_ptr() if spans else None, to.data_ptr() if spans else None, stream)
+    if rc != 0:
+        raise RuntimeError("fxamd_match_multi_device failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
+    return flags, frm, to
+
+
 def _as_batches(strs):
     """-> list of (indices, ndarray[n, L]) with uniform L, plus scalar flag."""
     if isinstance(strs, (bytes, bytearray, str)):

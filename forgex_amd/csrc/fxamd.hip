@@ -636,6 +636,20 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    return FXAMD_OK;
 }
 
+// m patterns over the same device-resident rows: results pattern-major ([m][n]).  One pass of the pipeline per pattern, enqueued
+// back to back on the stream (the elemental operators with an ARRAY of patterns, forgex.F90:74 / :163, against one batch).
+int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
+                             int32_t* d_from, int32_t* d_to, void* hip_stream) {
+   if (!progs || m < 0 || n < 0 || !d_flags || (d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
+   for (int32_t i = 0; i < m; ++i) {
+      if (!progs[i]) return FXAMD_E_ARG;
+      const int rc = fxamd_match_batch_device(progs[i], d_rows, n, row_len, d_flags + (int64_t)i * n, d_from ? d_from + (int64_t)i * n : nullptr,
+                                              d_to ? d_to + (int64_t)i * n : nullptr, hip_stream);
+      if (rc != FXAMD_OK) return rc;
+   }
+   return FXAMD_OK;
+}
+
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags, int32_t* h_from,
                            int32_t* h_to) {
    if (!p || n < 0 || row_len < 0 || !h_flags || (n > 0 && row_len > 0 && !h_rows)) return FXAMD_E_ARG;

@@ -81,6 +81,12 @@ int fxamd_program_upload(fxamd_program* p);
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream);
 
+/* m patterns against the same device-resident rows (the reference's elemental operators accept an ARRAY of patterns,
+ * src/forgex.F90:74, :163): progs[i] fills d_flags[i*n .. i*n+n) (and d_from / d_to likewise).  One pass of the pipeline per
+ * pattern, enqueued back to back on the stream; rows are re-read per pattern. */
+int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                             uint8_t* d_flags, int32_t* d_from, int32_t* d_to, void* hip_stream);
+
 /* Host-buffer convenience used by the Fortran module: H2D copy, match, D2H copy, synchronous. */
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
                            int32_t* h_from, int32_t* h_to);

@@ -509,3 +509,19 @@ def test_prefix_and_suffix_literal_patterns_on_tile_kernel(fx):
                 assert np.array_equal(f, of), (pat, L)
                 assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
                 assert int(of.sum()) > 0, pat
+
+
+def test_many_patterns_over_one_batch(fx):
+    """fxamd_match_multi_device: an array of patterns against the same rows, results pattern-major."""
+    import torch
+    from forgex_amd import synth
+    rows = synth.batch("cfg3", 0, 20000, torch.device("cuda"))
+    pats = [rb"[a-z]+\d+", rb"\d{3}-\d{4}", rb"zz+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d"]
+    progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+    f, a, b = fx.match_many(progs, rows)
+    torch.cuda.synchronize()
+    host = rows.cpu().numpy()
+    for i, p in enumerate(pats):
+        of, oa, ob = oracle_lib.batch(2, p, host, NT)
+        assert np.array_equal(f[i].cpu().numpy(), of), p
+        assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), p
