@@ -525,3 +525,27 @@ def test_many_patterns_over_one_batch(fx):
         of, oa, ob = oracle_lib.batch(2, p, host, NT)
         assert np.array_equal(f[i].cpu().numpy(), of), p
         assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), p
+
+
+def test_batch_shapes_and_handle_reuse(fx):
+    """ONE program handle across calls of different batch sizes, row lengths and output sets (the per-handle counter words
+    alternate between calls, the worklist grows on demand): tile boundaries (n = 1, 63, 64, 65, ...), ASCII and UTF-8 rows mixed."""
+    import random
+    rng = random.Random(77)
+    pieces = [b"a", b"b", b"z", b"0", b"7", b" ", b"-", "あ".encode(), "ω".encode(), "é".encode(), b"\x80", b"\xe3\x81", b"ab12", b"555-1234"]
+    for pat in (rb"[a-z]+\d+", rb"\d{3}-\d{4}", "[ぁ-ん]+[0-9]*".encode(), rb"id=\d+"):
+        ps = fx.Program(pat, fx.OP_SEARCH)
+        pm = fx.Program(pat, fx.OP_MATCH)
+        for n, L in ((1, 64), (63, 256), (64, 64), (65, 100), (4097, 32), (130, 512), (7, 8), (1000, 255), (64, 64), (5, 272), (2049, 256)):
+            rows = np.stack([np.frombuffer((b"".join(rng.choice(pieces) for _ in range(L)))[:L].ljust(L, b"x"), dtype=np.uint8) for _ in range(n)])
+            if n > 3:
+                rows[::3] = np.frombuffer((b"abc123 " * L)[:L], dtype=np.uint8)   # pure-ASCII rows with matches in between
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            om, _, _ = oracle_lib.batch(1, pat, rows, NT)
+            for spans in (True, False, True):
+                f, a, b = ps.match_host(rows, spans=spans)
+                assert np.array_equal(f, of), (pat, n, L, spans)
+                if spans:
+                    assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, n, L)
+            fm, _, _ = pm.match_host(rows, spans=False)
+            assert np.array_equal(fm, om), (pat, n, L, "match")
