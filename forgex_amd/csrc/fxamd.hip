@@ -467,6 +467,21 @@ int fxamd_program_upload(fxamd_program* p) {
    return FXAMD_OK;
 }
 
+int fxamd_program_reserve(fxamd_program* p, int64_t max_rows) {
+   if (!p || max_rows < 0) return FXAMD_E_ARG;
+   int rc = fxamd_program_upload(p);
+   if (rc != FXAMD_OK) return rc;
+   std::lock_guard<std::mutex> g(p->mu);
+   if (p->worklist_rows < max_rows) {
+      if (p->d_worklist) (void)hipFree(p->d_worklist);
+      p->d_worklist = nullptr;
+      p->worklist_rows = 0;
+      FX_HIP(hipMalloc((void**)&p->d_worklist, (size_t)max_rows * 4));
+      p->worklist_rows = max_rows;
+   }
+   return FXAMD_OK;
+}
+
 int fxamd_last_path(const fxamd_program* p) { return p ? p->last_path : FXAMD_E_ARG; }
 
 int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,

@@ -70,6 +70,11 @@ const char* fxamd_strerror(int32_t status);
 /* Upload the tables to the current HIP device (idempotent; done lazily by the match calls otherwise). */
 int fxamd_program_upload(fxamd_program* p);
 
+/* Upload the tables and allocate the handle's device scratch for batches of up to max_rows rows now (4 bytes per row), so that
+ * later fxamd_match_batch_device calls only enqueue kernels (stream capture, latency-sensitive callers).  Optional: the match
+ * calls do both lazily. */
+int fxamd_program_reserve(fxamd_program* p, int64_t max_rows);
+
 /* Device-resident batch: d_rows, d_flags (n bytes: 0/1), d_from, d_to (n int32 each, may both be NULL) are
  * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
  * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
