@@ -38,15 +38,18 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
 #endif
 template <int CH>
-__device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, bool enable = true) {
+__device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, bool enable = true,
+                                          uint32_t row_bytes = 16u * CH) {
    // the tile's bytes are contiguous: 64*CH 16-byte pieces; piece p = q*64+lane -> row p/CH, chunk p%CH.  row0 is wave-uniform:
    // the tile is addressed through a buffer resource whose base is the tile and whose extent is the tile's valid bytes, so
    // each piece is ONE buffer_load_dwordx4 (scalar base, lane offset, immediate piece offset) and the pieces of rows >= n
    // come back as zero from the hardware range check instead of per-piece predication.
    const int64_t rows_left = n - row0;
    // enable == false (wave-uniform): a tile this pass skips -- zero valid bytes, the loads are issued and range-checked away
-   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * 16u * CH : (rows_left > 0 ? (uint32_t)rows_left * 16u * CH : 0u));
-   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)(16 * CH);
+   // (row_bytes < 16*CH: rows of fewer whole chunks than the instantiation has -- the tile is still one contiguous run of
+   //  64*row_bytes bytes, the pieces behind it are range-checked away; store_tile_rt sorts the pieces into rows)
+   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * row_bytes : (rows_left > 0 ? (uint32_t)rows_left * row_bytes : 0u));
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)row_bytes;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
                                                                          __builtin_amdgcn_readfirstlane(valid), 0x00020000);
@@ -170,6 +173,19 @@ __device__ __forceinline__ void store_tile(const uint4 (&v)[CH], uint4* tile, ui
          uint32_t p = q * 64 + lane;
          tile[tile_cell(p / CH, p % CH)] = v[q];
       }
+   }
+}
+
+// rows of c < CH whole chunks (c = row length / 16, wave-uniform at run time): piece q*64+lane = row p / c, chunk p % c; the chunk
+// columns c..CH-1 are never written here (they hold the inert pad symbol, put there once per kernel)
+template <int CH>
+__device__ __forceinline__ void store_tile_rt(const uint4 (&v)[CH], uint4* tile, uint32_t lane, uint32_t c) {
+   const uint32_t inv = 0xFFFFFFFFu / c + 1u;   // p / c == (p * inv) >> 32 for p < 2^16
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      const uint32_t p = q * 64 + lane;
+      const uint32_t R = (uint32_t)(((uint64_t)p * inv) >> 32), k = p - R * c;
+      if (p < 64u * c) tile[tile_cell(R, k)] = v[q];
    }
 }
 
@@ -332,14 +348,22 @@ __device__ unsigned long long fx_stamp_acc[16];
 // aligned rows: fully coalesced 16-byte pieces; ragged rows (Lr != 16*CH): dword-aligned pieces, zero behind the row end
 #define LOAD_TILE(st, r0)                                              \
    do {                                                                \
-      if (RAGGED) load_tile_ragged<CH>(st, rows, (r0), n, lane, Lr);   \
+      if (RAGGED && (Lr & 15u) == 0u) load_tile<CH>(st, rows, (r0), n, lane, true, Lr); \
+      else if (RAGGED) load_tile_ragged<CH>(st, rows, (r0), n, lane, Lr);   \
       else load_tile<CH>(st, rows, (r0), n, lane);                     \
+   } while (0)
+// staged pieces -> LDS tile (RAGGED with whole chunks: run-time piece-to-row map)
+#define STORE_TILE(st)                                                                      \
+   do {                                                                                     \
+      if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(st, tile, lane, Lr >> 4);           \
+      else store_tile<CH>(st, tile, lane);                                                  \
    } while (0)
 // prefetch of a tile that may lie behind the last one: the aligned loader needs no guard (zero valid bytes -> every piece is
 // range-checked away), and an unguarded load keeps the staging registers free of control-flow merges
 #define PREFETCH_TILE(st, tn, en)                                      \
    do {                                                                \
       if (!RAGGED) load_tile<CH>(st, rows, (tn) << 6, n, lane, (en));  \
+      else if ((Lr & 15u) == 0u) load_tile<CH>(st, rows, (tn) << 6, n, lane, (en), Lr); \
       else if ((en) && (tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
    } while (0)
 
@@ -448,6 +472,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    // row is all-dead), so the forward pass reads "past the end" like any other position.  Written once, never overwritten.
    uint4* tile = tiles + wave * (64 * (CH + 1));
    tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   // rows of fewer WHOLE chunks than the instantiation has: their unused chunk columns hold the inert symbol 255 from here on
+   // (the staging stores never touch them; the decode passes re-pad per tile because they rewrite the cells)
+   const bool whole = RAGGED && (Lr & 15u) == 0u;
+   if (whole)
+      for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
@@ -492,7 +521,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
                const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
                defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
             }
-            if (process) store_tile<CH>(stage, tile, lane);
+            if (process) STORE_TILE(stage);
             STAMP(0);
             // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
             // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
@@ -522,7 +551,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
                cur = nxt;
             }
          }
-         if (ragged) na |= pad_rows<CH>(tile, lane, Lr);
+         if (ragged && (!whole || FIXUP)) na |= pad_rows<CH>(tile, lane, Lr);
 
          // ---- right-to-left pass: reverse unanchored DFA; the LAST hit seen is the leftmost start ----
          // software pipeline in 8-byte groups: the 8 lookups of the next group are in flight (lgkmcnt <= 15 stays
@@ -557,7 +586,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
 #pragma unroll
          for (int k = CH - 1; k >= 0; --k) {
             if (LONG && (uint32_t)k < kmin) break;   // wave-uniform: the short segment ends here (the lookups already issued for this chunk are dropped)
-            if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
+            if (!ragged || (whole && !FIXUP && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
             lookup8(fb, wk.x, wk.y, tabR);
             __builtin_amdgcn_sched_barrier(0);
             {
@@ -839,6 +868,9 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    const uint32_t sym_ffff = 128u + h->cls_ffff;
    uint4* tile = tiles + wave * (64 * CH);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const bool whole = RAGGED && (Lr & 15u) == 0u;   // fewer WHOLE chunks than the instantiation: pad columns written once (see fx_search_fast)
+   if (whole)
+      for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    bool any_deferred = false;
@@ -881,7 +913,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
                const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
                defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
             }
-            if (process) store_tile<CH>(stage, tile, lane);
+            if (process) STORE_TILE(stage);
             const bool last = !LONG || !process || defer_early || seg + 1u == S;   // nothing more of this tile is wanted
             if (last) live = MARKED ? tile_marked(t + wave_stride) : true;
             // the one reload site of the staging registers
@@ -918,7 +950,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
                cur = nxt;
             }
          }
-         if (ragged) na |= pad_rows<CH>(tile, lane, Lr);
+         if (ragged && (!whole || FIXUP)) na |= pad_rows<CH>(tile, lane, Lr);
          // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
          F fa[8], fb[8];
          uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
@@ -927,7 +959,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          const int nch = (LONG && (seg + 1u) * 256u > Lr) ? (int)((Lr & 255u) >> 4) : CH;   // chunks of this segment
 #pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
          for (int k = 0; k < nch; ++k) {
-            if (!ragged) na |= wk.x | wk.y | wk.z | wk.w;
+            if (!ragged || (whole && !FIXUP && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
             lookup8(fb, wk.z, wk.w, tabA);
             __builtin_amdgcn_sched_barrier(0);
             chain8_fwd(fa, st, TAp);
