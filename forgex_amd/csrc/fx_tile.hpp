@@ -48,7 +48,9 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
    // enable == false (wave-uniform): a tile this pass skips -- zero valid bytes, the loads are issued and range-checked away
    // (row_bytes < 16*CH: rows of fewer whole chunks than the instantiation has -- the tile is still one contiguous run of
    //  64*row_bytes bytes, the pieces behind it are range-checked away; store_tile_rt sorts the pieces into rows)
-   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * row_bytes : (rows_left > 0 ? (uint32_t)rows_left * row_bytes : 0u));
+   // (the extent is rounded up to whole dwords: the range check drops a dword that straddles it, and with rows of odd length the
+   //  batch may end inside one -- at most 3 bytes behind the caller's last row are read, never used)
+   const uint32_t valid = !enable ? 0u : ((rows_left >= 64 ? 64u * row_bytes : (rows_left > 0 ? (uint32_t)rows_left * row_bytes : 0u)) + 3u) & ~3u;
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)row_bytes;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
@@ -82,51 +84,6 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __r
    for (int q = 0; q < 16; ++q) {
       const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)(4 * q) * Lr, FX_LOAD_AUX);
       v[q] = make_uint4(t.x, t.y, t.z, t.w);
-   }
-}
-
-// Rows whose length Lr is not 16*CH (Lr % 4 == 0, 16 <= Lr <= 16*CH): the same 64-row tile, but piece (R, k) comes from byte
-// R*Lr + 16k of the tile (dword aligned, not 16-byte aligned) and the bytes behind the row end are delivered as ZERO.  The
-// last partial chunk is read as the row's LAST 16 bytes and shifted down, so nothing beyond the caller's buffer is touched.
-struct __attribute__((packed, aligned(1))) U4a {   // rows of any length start at any byte: the 16-byte pieces are unaligned loads
-   uint32_t x, y, z, w;
-};
-template <int CH>
-__device__ __forceinline__ void load_tile_ragged(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane,
-                                                 uint32_t Lr) {
-   // the row's last, partial chunk: its rem = Lr % 16 bytes are the tail of the row's LAST 16 bytes, shifted down (wave-uniform shift)
-   const uint32_t rem = Lr & 15u, sh = 16u - rem, sw = sh >> 2, sb = sh & 3u;
-#pragma unroll
-   for (int q = 0; q < CH; ++q) {
-      const uint32_t p = q * 64 + lane, R = p / CH, k = p % CH;
-      const int64_t row = row0 + R;
-      uint4 o = make_uint4(0, 0, 0, 0);
-      if (row < n && 16u * k < Lr) {
-         const uint8_t* rp = rows + row * (int64_t)Lr;
-         if (16u * k + 16u <= Lr) {
-            const U4a t = *reinterpret_cast<const U4a*>(rp + 16u * k);
-            o = make_uint4(t.x, t.y, t.z, t.w);
-         } else if (Lr < 16u && (row + 1) * (int64_t)Lr + 16 <= n * (int64_t)Lr) {
-            // rows shorter than one chunk: the 16 bytes FROM the row start (they run into the following rows, still inside the
-            // buffer), cut off behind the row's own bytes
-            const U4a t = *reinterpret_cast<const U4a*>(rp);
-            const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
-            uint32_t c4[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c4[i] = 4u * i + 4u <= Lr ? w4[i] : (4u * i >= Lr ? 0u : (w4[i] & ~(0xFFFFFFFFu << (8u * (Lr - 4u * i)))));
-            o = make_uint4(c4[0], c4[1], c4[2], c4[3]);
-         } else {
-            // (rows shorter than one chunk at the very end of the buffer come here too: their last 16 bytes start in earlier rows)
-            const U4a t = *reinterpret_cast<const U4a*>(rp + Lr - 16u);   // bytes [Lr-16, Lr)
-            const uint32_t w[8] = {t.x, t.y, t.z, t.w, 0u, 0u, 0u, 0u};
-            uint32_t m[5];   // the four words from word sw on, and the one behind them
-#pragma unroll
-            for (int i = 0; i < 5; ++i) m[i] = sw == 0u ? w[i] : (sw == 1u ? w[i + 1] : (sw == 2u ? w[i + 2] : w[i + 3]));
-            o = make_uint4(fxrow::fx_alignbyte(m[1], m[0], sb), fxrow::fx_alignbyte(m[2], m[1], sb), fxrow::fx_alignbyte(m[3], m[2], sb),
-                           fxrow::fx_alignbyte(m[4], m[3], sb));
-         }
-      }
-      v[q] = o;
    }
 }
 
@@ -187,6 +144,41 @@ __device__ __forceinline__ void store_tile_rt(const uint4 (&v)[CH], uint4* tile,
       const uint32_t R = (uint32_t)(((uint64_t)p * inv) >> 32), k = p - R * c;
       if (p < 64u * c) tile[tile_cell(R, k)] = v[q];
    }
+}
+
+// rows of ANY other length (Lr % 16 != 0): the tile is still one contiguous run of 64*Lr bytes, loaded with the coalesced
+// loader; the pieces go to LDS as a LINEAR image first, then lane r pulls its own row out of it -- bytes r*Lr .. r*Lr+Lr-1, at
+// any alignment: aligned dword reads and a per-lane v_alignbyte -- and writes it back in the transposed cell layout every
+// other part of the kernel expects (in place: a wave's LDS operations complete in order, all rows are in registers before the
+// first cell is overwritten).  Bytes behind the row end come out as zero (pad_rows turns them into the inert symbol).
+template <int CH>
+__device__ __forceinline__ void store_tile_relayout(uint4 (&v)[CH], uint4* tile, uint32_t lane, uint32_t Lr) {
+#pragma unroll
+   for (int q = 0; q < CH; ++q) tile[q * 64 + lane] = v[q];
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const uint32_t base = lane * Lr, sh = base & 3u;   // (16k keeps the byte phase)
+   const uint32_t* dw = reinterpret_cast<const uint32_t*>(tb + (base & ~3u));
+#pragma unroll
+   for (int k = 0; k < CH; ++k) {
+      if (16u * k < Lr) {   // wave-uniform
+         uint32_t d[5];
+#pragma unroll
+         for (int i = 0; i < 5; ++i) d[i] = dw[4 * k + i];
+         uint32_t w[4];
+#pragma unroll
+         for (int i = 0; i < 4; ++i) {
+            w[i] = fxrow::fx_alignbyte(d[i + 1], d[i], sh);
+            const uint32_t at = 16u * k + 4u * i;   // bytes of this word that lie behind the row end -> 0
+            if (at >= Lr) w[i] = 0u;
+            else if (at + 4u > Lr) w[i] &= ~(0xFFFFFFFFu << (8u * (Lr - at)));
+         }
+         v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+      } else {
+         v[k] = make_uint4(0, 0, 0, 0);
+      }
+   }
+#pragma unroll
+   for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = v[k];
 }
 
 // =========================================================================================================
@@ -345,17 +337,17 @@ __device__ unsigned long long fx_stamp_acc[16];
 #define STAMP_FLUSH
 #endif
 
-// aligned rows: fully coalesced 16-byte pieces; ragged rows (Lr != 16*CH): dword-aligned pieces, zero behind the row end
+// the tile of 64 rows is ONE contiguous run of 64*Lr bytes whatever the row length: fully coalesced 16-byte pieces
 #define LOAD_TILE(st, r0)                                              \
    do {                                                                \
-      if (RAGGED && (Lr & 15u) == 0u) load_tile<CH>(st, rows, (r0), n, lane, true, Lr); \
-      else if (RAGGED) load_tile_ragged<CH>(st, rows, (r0), n, lane, Lr);   \
+      if (RAGGED) load_tile<CH>(st, rows, (r0), n, lane, true, Lr);    \
       else load_tile<CH>(st, rows, (r0), n, lane);                     \
    } while (0)
 // staged pieces -> LDS tile (RAGGED with whole chunks: run-time piece-to-row map)
 #define STORE_TILE(st)                                                                      \
    do {                                                                                     \
       if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(st, tile, lane, Lr >> 4);           \
+      else if (RAGGED) store_tile_relayout<CH>(st, tile, lane, Lr);                         \
       else store_tile<CH>(st, tile, lane);                                                  \
    } while (0)
 // prefetch of a tile that may lie behind the last one: the aligned loader needs no guard (zero valid bytes -> every piece is
@@ -363,8 +355,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 #define PREFETCH_TILE(st, tn, en)                                      \
    do {                                                                \
       if (!RAGGED) load_tile<CH>(st, rows, (tn) << 6, n, lane, (en));  \
-      else if ((Lr & 15u) == 0u) load_tile<CH>(st, rows, (tn) << 6, n, lane, (en), Lr); \
-      else if ((en) && (tn) < n_tiles) load_tile_ragged<CH>(st, rows, (tn) << 6, n, lane, Lr); \
+      else load_tile<CH>(st, rows, (tn) << 6, n, lane, (en), Lr);      \
    } while (0)
 
 __device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr);

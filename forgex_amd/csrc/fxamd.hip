@@ -490,7 +490,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (p->prog.status != 0) return FXAMD_E_ARG;
    const FxpHeader& h = p->prog.hdr();
    const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme < 0 || h.mode == FXP_MODE_MATCH_ENGINE || (row_len < 16 && n * row_len < 32)) return FXAMD_E_ARG;
+   if (scheme < 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
    int rc = fxamd_program_upload(p);
    if (rc != FXAMD_OK) return rc;
    uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);
@@ -555,8 +555,7 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       d_from = nullptr;
       d_to = nullptr;
    }
-   int scheme = fast_scheme(h, d_rows, row_len);
-   if (row_len < 16 && n * row_len < 32) scheme = -1;   // (the ragged loader of sub-chunk rows wants 16 readable bytes around every row)
+   const int scheme = fast_scheme(h, d_rows, row_len);
    if (scheme >= 0) {
       const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
       uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);   // this call's words: [0] tiles deferred, [1] exception rows left
