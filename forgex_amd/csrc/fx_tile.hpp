@@ -62,16 +62,17 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
    }
 }
 
-// Long rows (Lr a multiple of 16, > 256): the tile is walked in 256-byte SEGMENTS (one of them shorter when Lr % 256 != 0).  Piece q*64+lane of segment `seg` = row
+// Long rows (ANY Lr > 256): the tile is walked in 256-byte SEGMENTS (the last one shorter when Lr % 256 != 0).  Piece q*64+lane of segment `seg` = row
 // 4q + lane/16, chunk lane%16 of that segment: 16 lanes read 256 contiguous bytes of one row.  Same buffer resource trick:
 // extent = the tile's valid bytes, the row / segment distance rides in the scalar offset (which the range check includes).
 __device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
                                               uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable) {
    // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
-   // (k_lo, k_hi) = (0, 15); the short one of a row whose length is not a multiple of 256 sits RIGHT-aligned (search: k_lo = 16 - c,
-   // the backward loop stops there) or LEFT-aligned (`.match.`: k_hi = c - 1) and its other chunks repeat a neighbour (never walked).
+   // (k_lo, k_hi) = (0, 15); the short last one has k_hi = its last (possibly partial) chunk and the chunks behind it repeat that
+   // one (never walked).  Rows start at any byte: the pieces are unaligned buffer loads.
    const int64_t rows_left = n - row0;
-   const uint32_t valid = !enable ? 0u : (rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u));
+   // (extent rounded up to whole dwords, as in load_tile)
+   const uint32_t valid = !enable ? 0u : ((rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u)) + 3u) & ~3u;
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)Lr;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
@@ -245,6 +246,19 @@ __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state
    return max(max(m0, m1), m2);
 }
 
+// the same over only the first nv (1..7, wave-uniform) bytes of the group -- the end of a long row's last segment
+template <class F>
+__device__ __forceinline__ uint32_t chain8_back_n(const F (&f)[8], uint32_t& state, const uint8_t* T, uint32_t nv) {
+   uint32_t mx = 0;
+#pragma unroll
+   for (int i = 7; i >= 0; --i)
+      if ((uint32_t)i < nv) {
+         state = fxstep(f[i], state, T);
+         mx = max(mx, state);
+      }
+   return mx;
+}
+
 // ---- on-device UTF-8 decode for the fast kernel (FXP_F_FAST_UTF8) -------------------------------------------------------
 // A tile that holds any byte >= 0x80 is rewritten IN REGISTERS, before it is stored to LDS, into fast-path symbol ids:
 // ASCII bytes stay; the first byte of a structurally valid multi-byte character becomes 128 + class(code point); its
@@ -257,14 +271,21 @@ __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state
 template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
    if (LONG) {
-      // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); L % 8 == 0
-      if (p < L) {
-         const uint2 r = *reinterpret_cast<const uint2*>(tb + p);
+      // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); any L >= 8
+      if (p + 8u <= L) {
+         const uint2 r = *reinterpret_cast<const uint2*>(tb + p);   // (rows start at any byte: an unaligned 8-byte load)
          lo = r.x;
          hi = r.y;
-      } else {
+      } else if (p >= L) {
          lo = p == L ? 0xFEFEFE00u : 0xFEFEFEFEu;
          hi = 0xFEFEFEFEu;
+      } else {
+         // the row ends inside this group: its last 8 bytes, shifted down to position p; then the NUL, then KILL symbols
+         const uint2 r = *reinterpret_cast<const uint2*>(tb + L - 8u);
+         const uint32_t nb = 8u * (L - p);   // bits of text: 8 .. 56
+         const uint64_t v = ((((uint64_t)r.y << 32) | r.x) >> (64u - nb)) | (0xFEFEFEFEFEFEFE00ull << nb);
+         lo = (uint32_t)v;
+         hi = (uint32_t)(v >> 32);
       }
       return;
    }
@@ -358,18 +379,11 @@ __device__ unsigned long long fx_stamp_acc[16];
       else load_tile<CH>(st, rows, (tn) << 6, n, lane, (en), Lr);      \
    } while (0)
 
-__device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr);
-// segment sg of a long row, search order (the SHORT segment is the leftmost one, sg = 0, right-aligned in the tile)
+// segment sg of a long row: bytes [256 sg, 256 sg + 256) of every row; the LAST segment is shorter when Lr % 256 != 0 and sits
+// left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, seg_byte_search((sg), Lr), ((sg) == 0u && (Lr & 255u)) ? 16u - ((Lr & 255u) >> 4) : 0u, 15u, (en))
-// `.match.` order (the SHORT segment is the rightmost one, left-aligned in the tile)
-#define PREFETCH_SEG_FWD(st, tn, sg, en) \
-   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? ((Lr & 255u) >> 4) - 1u : 15u, (en))
-// first byte of segment sg when the short segment (Lr % 256 bytes) comes first
-__device__ __forceinline__ uint32_t seg_byte_search(uint32_t sg, uint32_t Lr) {
-   const uint32_t rem = Lr & 255u;
-   return sg == 0u ? 0u : (rem ? rem + (sg - 1u) * 256u : sg * 256u);
-}
+   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en))
+#define PREFETCH_SEG_FWD(st, tn, sg, en) PREFETCH_SEG(st, tn, sg, en)
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
    // instantiation keeps the row length a compile-time constant (the hot path).
    const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;
-   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;   // segments per row: 256 bytes each, the LEFTMOST one shorter when Lr % 256 != 0
+   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;   // segments per row: 256 bytes each, the last one shorter when Lr % 256 != 0
    constexpr bool ragged = RAGGED;
    static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
@@ -567,41 +581,66 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             return;
          }
 #endif
-         // 8-byte groups to the left of this segment's chunk 0 (the short segment sits right-aligned: its first chunks are not walked)
-         const uint32_t kmin = (LONG && seg == 0u && (Lr & 255u)) ? 16u - ((Lr & 255u) >> 4) : 0u;
-         const uint32_t gbase = LONG ? (seg_byte_search(seg, Lr) >> 3) - 2u * kmin : 0u;
-         F fa[8], fb[8];
-         uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
-         if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
-         lookup8(fa, wk.z, wk.w, tabR);
+         // LONG: bytes of this segment (256, or what is left of the row in its last segment): groups behind the row end are not
+         // walked, the group the row ends in is walked over its valid bytes only -- no pad symbol is needed, so the byte-level
+         // tables work on rows of any length
+         const uint32_t seg_len = LONG ? (Lr - seg * 256u < 256u ? Lr - seg * 256u : 256u) : 16u * CH;
+         const uint32_t gbase = LONG ? seg * 32u : 0u;   // 8-byte groups to the left of this segment
+         // the chunk loop in two instantiations: every group whole (always, unless LONG and this is a row's short last segment) or
+         // with the per-group byte counts
+         auto walk = [&](auto whole_groups) {
+            constexpr bool WG = decltype(whole_groups)::value;
+            F fa[8], fb[8];
+            uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
+            if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+            lookup8(fa, wk.z, wk.w, tabR);
 #pragma unroll
-         for (int k = CH - 1; k >= 0; --k) {
-            if (LONG && (uint32_t)k < kmin) break;   // wave-uniform: the short segment ends here (the lookups already issued for this chunk are dropped)
-            if (!ragged || (whole && !FIXUP && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
-            lookup8(fb, wk.x, wk.y, tabR);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-               const uint32_t entry = state;
-               const uint32_t mx = chain8_back(fa, state, TRp);
-               gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k + 1) : gsel;
-               esel = mx >= fp.hit_min ? entry : esel;
-               asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+            for (int k = CH - 1; k >= 0; --k) {
+               // valid bytes of this chunk's upper / lower group (8 unless LONG and the row ends here)
+               const uint32_t nhi = WG ? 8u : (seg_len >= 16u * k + 16u ? 8u : (seg_len > 16u * k + 8u ? seg_len - (16u * k + 8u) : 0u));
+               const uint32_t nlo = WG ? 8u : (seg_len >= 16u * k + 8u ? 8u : (seg_len > 16u * k ? seg_len - 16u * k : 0u));
+               if (LONG) {
+                  if (nhi == 8u) na |= wk.x | wk.y | wk.z | wk.w;
+                  else {   // (wave-uniform) only the row's own bytes count
+                     const uint32_t w4[4] = {wk.x, wk.y, wk.z, wk.w};
+#pragma unroll
+                     for (int i = 0; i < 4; ++i) {
+                        const uint32_t at = 16u * k + 4u * i;
+                        if (at + 4u <= seg_len) na |= w4[i];
+                        else if (at < seg_len) na |= w4[i] & ~(0xFFFFFFFFu << (8u * (seg_len - at)));
+                     }
+                  }
+               } else if (!ragged || (whole && !FIXUP && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
+               lookup8(fb, wk.x, wk.y, tabR);
+               __builtin_amdgcn_sched_barrier(0);
+               if (nhi != 0u) {
+                  const uint32_t entry = state;
+                  const uint32_t mx = nhi == 8u ? chain8_back(fa, state, TRp) : chain8_back_n(fa, state, TRp, nhi);
+                  gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k + 1) : gsel;
+                  esel = mx >= fp.hit_min ? entry : esel;
+                  asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               if (k >= 1) {
+                  wk = wn;
+                  lookup8(fa, wk.z, wk.w, tabR);
+                  if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               if (nlo != 0u) {
+                  const uint32_t entry = state;
+                  const uint32_t mx = nlo == 8u ? chain8_back(fb, state, TRp) : chain8_back_n(fb, state, TRp, nlo);
+                  gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k) : gsel;
+                  esel = mx >= fp.hit_min ? entry : esel;
+                  asm volatile("" : "+v"(esel));
+               }
+               __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (k >= 1) {
-               wk = wn;
-               lookup8(fa, wk.z, wk.w, tabR);
-               if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-               const uint32_t entry = state;
-               const uint32_t mx = chain8_back(fb, state, TRp);
-               gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k) : gsel;
-               esel = mx >= fp.hit_min ? entry : esel;
-               asm volatile("" : "+v"(esel));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+         };
+         if constexpr (!LONG) walk(std::true_type{});
+         else {
+            if (seg_len == 256u) walk(std::true_type{});
+            else walk(std::false_type{});
          }
          if (!LONG || seg == 0u) break;
       }
@@ -611,15 +650,29 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
          const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
          uint2 rw;
-         if (LONG) rw = row_ok ? *reinterpret_cast<const uint2*>(rows + row * (int64_t)L + (int64_t)g * 8) : make_uint2(0, 0);   // (its segment left the tile)
-         else rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+         uint32_t nv = 8;   // LONG: valid bytes of the group (the row may end inside it)
+         if (LONG) {   // (its segment left the tile: from global memory)
+            rw = make_uint2(0, 0);
+            if (row_ok) {
+               const uint8_t* rp = rows + row * (int64_t)L;
+               if (g * 8u + 8u <= L) rw = *reinterpret_cast<const uint2*>(rp + g * 8u);
+               else {   // the row's last 8 bytes, shifted down to the group's place (nothing behind the row is read)
+                  const uint2 r = *reinterpret_cast<const uint2*>(rp + L - 8u);
+                  nv = L - g * 8u;
+                  const uint64_t v = (((uint64_t)r.y << 32) | r.x) >> (64u - 8u * nv);
+                  rw = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+               }
+            }
+         } else rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
          F f[8];
          lookup8(f, rw.x, rw.y, tabR);
          uint32_t st = esel, loc = 8;
 #pragma unroll
          for (int i = 7; i >= 0; --i) {
-            st = fxstep(f[i], st, TRp);
-            loc = st >= fp.hit_min ? (uint32_t)i : loc;
+            const uint32_t nx = fxstep(f[i], st, TRp);
+            const bool on = !LONG || (uint32_t)i < nv;   // (per lane)
+            st = on ? nx : st;
+            loc = on && nx >= fp.hit_min ? (uint32_t)i : loc;
          }
          s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
          const F fz = tabR[0];   // leading NUL
@@ -793,6 +846,13 @@ __device__ __forceinline__ void chain8_fwd(const F (&f)[8], uint32_t& state, con
 #pragma unroll
    for (int i = 0; i < 8; ++i) state = fxstep(f[i], state, T);
 }
+// only the first nv (wave-uniform) bytes of the group: a long row ends inside it
+template <class F>
+__device__ __forceinline__ void chain8_fwd_n(const F (&f)[8], uint32_t& state, const uint8_t* T, uint32_t nv) {
+#pragma unroll
+   for (int i = 0; i < 8; ++i)
+      if ((uint32_t)i < nv) state = fxstep(f[i], state, T);
+}
 
 // 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides (fxrow::match_gate on the row's bytes in the LDS tile)
 __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t* __restrict__ prog, const uint8_t* tb, uint32_t lane, uint32_t L) {
@@ -808,7 +868,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
                                                        uint32_t* __restrict__ worklist) {
    const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
-   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;       // LONG: 256-byte segments per row (the last one shorter when Lr % 256 != 0), left to right
+   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;       // LONG: 256-byte segments per row (the last one shorter when Lr % 256 != 0, at any byte), left to right
    constexpr bool ragged = RAGGED;
    static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
@@ -947,13 +1007,29 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
          if (CH >= 2) wn = tile[tile_cell(lane, 1)];
          lookup8(fa, wk.x, wk.y, tabA);
-         const int nch = (LONG && (seg + 1u) * 256u > Lr) ? (int)((Lr & 255u) >> 4) : CH;   // chunks of this segment
+         // LONG: bytes of this segment (the row may end inside its last one, at any byte: the groups are walked over their valid bytes)
+         const uint32_t seg_len = LONG ? (Lr - seg * 256u < 256u ? Lr - seg * 256u : 256u) : 16u * CH;
+         const int nch = LONG ? (int)((seg_len + 15u) >> 4) : CH;   // chunks of this segment
 #pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
          for (int k = 0; k < nch; ++k) {
-            if (!ragged || (whole && !FIXUP && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
+            const uint32_t nlo = !LONG ? 8u : (seg_len >= 16u * k + 8u ? 8u : seg_len - 16u * k);   // (>= 1: k < nch)
+            const uint32_t nhi = !LONG ? 8u : (seg_len >= 16u * k + 16u ? 8u : (seg_len > 16u * k + 8u ? seg_len - (16u * k + 8u) : 0u));
+            if (LONG) {
+               if (nhi == 8u) na |= wk.x | wk.y | wk.z | wk.w;
+               else {
+                  const uint32_t w4[4] = {wk.x, wk.y, wk.z, wk.w};
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                     const uint32_t at = 16u * k + 4u * i;
+                     if (at + 4u <= seg_len) na |= w4[i];
+                     else if (at < seg_len) na |= w4[i] & ~(0xFFFFFFFFu << (8u * (seg_len - at)));
+                  }
+               }
+            } else if (!ragged || (whole && !FIXUP && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
             lookup8(fb, wk.z, wk.w, tabA);
             __builtin_amdgcn_sched_barrier(0);
-            chain8_fwd(fa, st, TAp);
+            if (nlo == 8u) chain8_fwd(fa, st, TAp);
+            else chain8_fwd_n(fa, st, TAp, nlo);
             __builtin_amdgcn_sched_barrier(0);
             if (k + 1 < CH) {
                wk = wn;
@@ -961,7 +1037,8 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
                if (k + 2 < CH) wn = tile[tile_cell(lane, k + 2)];
             }
             __builtin_amdgcn_sched_barrier(0);
-            chain8_fwd(fb, st, TAp);
+            if (nhi == 8u) chain8_fwd(fb, st, TAp);
+            else if (nhi != 0u) chain8_fwd_n(fb, st, TAp, nhi);
             __builtin_amdgcn_sched_barrier(0);
          }
          if (!LONG || seg + 1u == S) break;

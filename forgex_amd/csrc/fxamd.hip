@@ -219,8 +219,8 @@ static int tile_chunks(int64_t row_len) {
       if (row_len <= 16 * c) return c;
    return 0;
 }
-// long rows: a multiple of 16 bytes, walked in 256-byte segments by the CH = 16 instantiations
-static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536 && (row_len & 15) == 0; }
+// long rows (any length): walked in 256-byte segments by the CH = 16 instantiations
+static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536; }
 static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : tile_chunks(row_len); }
 // what a pass needs to know beyond the tables: deferral policy of a first pass, gate word of a marked-tile pass
 struct PassOpts {

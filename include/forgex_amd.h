@@ -79,9 +79,8 @@ int fxamd_program_reserve(fxamd_program* p, int64_t max_rows);
  * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
  * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
  * `.match.`: flags = verdict, from/to untouched.  Invalid pattern: all flags 0, from/to 0.
- * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2..256 bytes and rows
- * whose length is a multiple of 16 up to 64 KiB when d_rows is 16-byte aligned, other shapes run on the general kernel
- * (one lane per row, roughly 20x slower).  Calls on ONE handle must not overlap in time (per-handle device scratch);
+ * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2 bytes .. 64 KiB when
+ * d_rows is 16-byte aligned, other shapes run on the general kernel (one lane per row, roughly 20x slower).  Calls on ONE handle must not overlap in time (per-handle device scratch);
  * distinct handles are independent. */
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream);

@@ -88,7 +88,7 @@ def test_config_rows_vs_oracle(fx, cfg, n):
 
 
 def test_fast_and_general_kernels_agree(fx):
-    """The same rows through the fast kernel (aligned [n,256]) and through the general kernel (an odd row length forces it)."""
+    """The same rows through the fast kernel (aligned [n,256]) and through the general kernel (a misaligned base address forces it)."""
     import torch
     from forgex_amd import synth
     rows = synth.batch("cfg3", 5000, 8192, torch.device("cuda"))
@@ -96,7 +96,10 @@ def test_fast_and_general_kernels_agree(fx):
     p = fx.Program(pat, fx.OP_SEARCH)
     f1, a1, b1 = p.match_device(rows)
     assert p.last_path() in (1, 3, 8)
-    wide = torch.cat([rows, torch.full((rows.shape[0], 1), 33, dtype=torch.uint8, device=rows.device)], dim=1).contiguous()  # '!' appended
+    # the same rows at a base address that is not 16-byte aligned: the tile kernels decline, the general kernel takes them
+    buf = torch.empty(rows.numel() + 1, dtype=torch.uint8, device=rows.device)
+    wide = buf[1:].view(rows.shape)
+    wide.copy_(rows)
     f2, a2, b2 = p.match_device(wide)
     assert p.last_path() == 2
     torch.cuda.synchronize()
@@ -282,7 +285,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
             continue
         n_fast += 1
         L = rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 20, 36, 52, 80, 100, 132, 200, 252, 272, 512, 784,
-                        17, 30, 50, 75, 99, 250, 255, 2, 3, 5, 8, 11, 15])   # incl. ragged (any length that is not a multiple of 16), tiny and long rows
+                        17, 30, 50, 75, 99, 250, 255, 2, 3, 5, 8, 11, 15, 257, 300, 1000])   # incl. ragged (any length that is not a multiple of 16), tiny and long rows
         n = 192
         rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
         mixed = []
@@ -447,14 +450,14 @@ def test_long_rows_on_tile_kernels(fx):
     nrng = np.random.default_rng(41)
     alpha = np.frombuffer(b"abcxyz .-_@\n", dtype=np.uint8)
     pieces = [s.encode() for s in "あいうえおかんアイウαβγω"] + [b"a", b"z", b"0", b"7", b" ", b".", b"\x80", b"\xe3\x81", b"\xff", b"\xc3"]
-    for L in (512, 1024, 2048, 272, 400, 1008, 784):   # multiples of 256 and of 16 (one shorter segment)
+    for L in (512, 1024, 2048, 272, 400, 1008, 784, 257, 300, 1000, 515):   # multiples of 256, of 16, and any other length (a shorter last segment)
         n = 1500
         rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
         seeds = [b"abc123", b"555-1234", b"needle in a hay", b"bob@mail.org", "あいう".encode(), b"zz9"]
         for i in range(0, n, 3):
             sd = np.frombuffer(seeds[(i // 3) % len(seeds)], dtype=np.uint8)
             # around the segment borders as well as anywhere
-            border = (L % 256) + 256 * int(nrng.integers(0, L // 256)) if L % 256 else 256 * int(nrng.integers(1, L // 256))   # a segment border
+            border = 256 * int(nrng.integers(1, L // 256 + 1)) if L >= 512 else 256   # a segment border
             off = int(nrng.integers(0, L - len(sd))) if i % 2 else max(0, min(L - len(sd), border - int(nrng.integers(0, len(sd) + 1))))
             rows[i, off:off + len(sd)] = sd
         mixed = np.stack([np.frombuffer((b"".join(rng.choice(pieces) for _ in range(L)))[:L], dtype=np.uint8) for _ in range(300)])
@@ -470,14 +473,14 @@ def test_long_rows_on_tile_kernels(fx):
                 assert np.array_equal(f2, of), (pat, L, "flags-only")
         # `.match.`: whole-row patterns
         full = rows.copy()
-        full[::4] = np.frombuffer((b"ab" * (L // 2)), dtype=np.uint8)
+        full[::4] = np.frombuffer((b"ab" * L)[:2 * (L // 2)].ljust(L, b"a"), dtype=np.uint8)
         for pat in (rb"(ab)+", rb"[a-z .@_\n-]+", rb"(ab)*a?", "[^あ]+".encode()):
             for data in (full, np.concatenate([full[:200], mixed, full[200:400]])):
                 pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, data, spans=False)
                 assert pm.last_path() != 2, (pat, L, pm.last_path())
                 om, _, _ = oracle_lib.batch(1, pat, data, NT)
                 assert np.array_equal(fm, om), (pat, L, "match", pm.last_path())
-                assert int(om.sum()) > 0 or pat != rb"(ab)+"
+                assert int(om.sum()) > 0 or pat != rb"(ab)+" or L % 2 == 1
 
 
 def test_prefix_and_suffix_literal_patterns_on_tile_kernel(fx):
