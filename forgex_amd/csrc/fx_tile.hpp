@@ -396,7 +396,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 // MODE 4: the decode pass over a WORKLIST of row indices (the exception rows a BYTES pass appended): each lane gathers its own
 //         row into its LDS cells, results are scattered back to the rows' own slots.
 // n_deferred points at this call's two words: [0] "a first pass deferred tiles", [1] number of exception rows in `worklist`.
-// LONG: rows longer than 256 bytes (a multiple of 256), CH = 16: the backward pass walks the row segment by segment through the
+// LONG: rows longer than 256 bytes (any length up to 64 KiB), CH = 16: the backward pass walks the row segment by segment through the
 // same LDS tile, the short forward pass reads its bytes straight from global memory.  First-pass and BYTES modes only.
 template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
 __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
@@ -1085,7 +1085,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
-   if (Lr > 256u) {   // long rows (a multiple of 256 bytes): segment-walking instantiation, CH = 16, first-pass / byte-level modes only
+   if (Lr > 256u) {   // long rows: segment-walking instantiation, CH = 16, first-pass / byte-level modes only
       if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
          constexpr int CHN = SCH;
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<16, true, MODE, CHN, false, true>)

@@ -271,7 +271,7 @@ FX_HD int find_wrapped(const Row& r, int L, PatFn pat, int m, int lo) {
    return 0;
 }
 
-// ---- UTF-8 -> fast-path symbol ids (fx_translate kernel; also compiled by the test-only host harness) ---------------
+// ---- UTF-8 -> fast-path symbol ids (the decode passes of the tile kernels; also compiled by the test-only host harness) ---
 FX_HD uint32_t u8_is_cont(uint32_t b) { return (b & 0xC0u) == 0x80u; }
 FX_HD uint32_t u8_lead_len(uint32_t b) { return b >= 0xF8u ? 0u : (b >= 0xF0u ? 4u : (b >= 0xE0u ? 3u : (b >= 0xC0u ? 2u : 0u))); }
 
