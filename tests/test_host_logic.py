@@ -157,3 +157,31 @@ def test_match_path_fails_loudly_without_gpu(built):
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError):
         fx.in_("abc", [b"xabc"])
+
+
+def test_host_compiler_under_address_and_ub_sanitizers(built, tmp_path):
+    """The host side of the product (front end, table compiler, byte-level automata builders) and the row procedure, compiled with
+    -fsanitize=address,undefined (CPU build only; the GPU pool has no sanitizer support) and driven with fuzzed patterns and texts."""
+    import random
+    import subprocess
+    import fuzz_bytes
+    import fuzz_prefilter
+    exe = str(tmp_path / "host_walk_asan")
+    src = [os.path.join(golden.ROOT, "tests", "support", "host_walk.cpp"), os.path.join(golden.ROOT, "forgex_amd", "csrc", "frontend.cpp"),
+           os.path.join(golden.ROOT, "forgex_amd", "csrc", "compile.cpp")]
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-DHW_MAIN"] + src + ["-o", exe],
+                        capture_output=True)
+    if cc.returncode != 0:
+        pytest.skip("sanitizer build not available: " + cc.stderr.decode()[:200])
+    rng = random.Random(3)
+    cases = [fuzz_prefilter.gen_case(rng) for _ in range(250)]
+    for _ in range(250):
+        pat = rng.choice(fuzz_bytes.EXTRA_PATTERNS) if rng.random() < 0.4 else fuzz_diff.gen_pattern(rng)
+        cases.append((rng.choice(["I", "M", "R"]), pat.encode(), fuzz_bytes.gen_text(rng)))
+    cases += fuzz_diff.gen_cases(5, 300)
+    inp = "".join("%s %s %s\n" % (c[0], golden.hx(c[1]), golden.hx(c[2])) for c in cases)
+    env = dict(os.environ, FX_HW_BYTES="1", FX_HW_FAST="1", ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe], input=inp.encode(), capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
+    assert len(r.stdout.decode().splitlines()) == len(cases)
