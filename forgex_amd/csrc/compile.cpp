@@ -917,8 +917,12 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       }
       brute_equiv = ok;
    }
-   if (brute_equiv && prefilter) {
-      bool ok = border_free(lit.prefix) && lit.prefix.find('\0') == std::string::npos;
+   // the prefix literal is a NECESSARY beginning of every non-empty match (walking A along it, each state is non-accepting and only
+   // the next prefix symbol -- a singleton class -- is live): with it the general engine may skip the reference's brute-force
+   // fallback on pure-ASCII rows that do not contain the prefix at all; with border-freeness on top, the tile kernels apply
+   bool prefix_necessary = false;
+   if (op == OP_SEARCH && prefilter) {
+      bool ok = lit.prefix.find('\0') == std::string::npos;
       int q = A.init;
       std::vector<int32_t> codes = decode_chars(lit.prefix);
       for (size_t i = 0; ok && i < codes.size(); ++i) {
@@ -935,8 +939,10 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
             if (q == 0) ok = false;
          }
       }
-      brute_equiv = ok;
+      prefix_necessary = ok;
    }
+   if (prefix_necessary) h.flags |= FXP_F_PREFIX_NECESSARY;
+   if (brute_equiv && prefilter) brute_equiv = prefix_necessary && border_free(lit.prefix);
    // ---- 7. fast path: <= 8 states per automaton, fused byte tables (one v_perm_b32 per input byte) ---------------------
    // `.match.` runs one forward pass of A over the whole row (api_internal_m.F90:258-302): no R, no candidate list, so the
    // tile kernel applies whenever the tables fit; its prefix/suffix gate is evaluated on the row bytes by the kernel.

@@ -441,6 +441,14 @@ FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Resu
          }
       }
       if (idx > 0 && (suf_idx < 0 || idx <= suf_idx)) first = idx;
+      if (idx == 0 && (h.flags & FXP_F_PREFIX_NECESSARY)) {
+         // the prefix occurs nowhere: the reference falls back to brute force here (api_internal_m.F90:79-81), which on a pure-ASCII
+         // row cannot find anything either (every match begins with the prefix) -- skip it.  (Rows with bytes >= 0x80 may spell
+         // the prefix in an overlong form that only the automaton sees: they take the fallback.)
+         bool ascii = true;
+         for (int j = 0; j < L; ++j) ascii = ascii && r[j] < 0x80u;
+         if (ascii) return;
+      }
       if (first == 0) brute = true;   // api_internal_m.F90:79-81
    }
    if (brute) {
