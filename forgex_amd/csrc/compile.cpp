@@ -776,6 +776,123 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       }
    }
 
+   // ---- 4b. prefix literal with a BORDER (`--x`, `aa[bc]`, `abab.*`): the reference's candidate list holds NON-overlapping
+   // occurrences of the prefix (utility_m.f90:94-116), so it differs from brute force exactly on rows where two occurrences
+   // overlap -- rows that contain a WITNESS p + p[b..] for a border length b.  R is composed with an Aho-Corasick detector of the
+   // (reversed) witnesses whose hit is one absorbing state: the tile kernels search by brute force and hand rows that end there
+   // to the general engine.  Only with a necessary prefix (checked here on the intervals) and without a suffix literal (the
+   // general engine's own brute-force fallback then only ever runs on rows without the prefix, where the detector stays idle).
+   bool overlap_sink = false;
+   int R_inv_state = -1;
+   if (op == OP_SEARCH && R.ok && !f_eq(lit.prefix, "") && f_eq(lit.suffix, "") && !border_free(lit.prefix) &&
+       lit.prefix.find('\0') == std::string::npos) {
+      const std::vector<int32_t> pc = decode_chars(lit.prefix);
+      const int lp = static_cast<int>(pc.size());
+      std::vector<int> piv(static_cast<size_t>(lp));
+      bool ok = lp >= 2;
+      int q = A.init;
+      for (int i = 0; ok && i < lp; ++i) {
+         if (i > 0 && A.out[static_cast<size_t>(q)]) ok = false;
+         const int iv = interval_of(pc[static_cast<size_t>(i)]);
+         piv[static_cast<size_t>(i)] = iv;
+         if (!(bounds[static_cast<size_t>(iv)] == pc[static_cast<size_t>(i)] && bounds[static_cast<size_t>(iv) + 1] == pc[static_cast<size_t>(i)] + 1)) ok = false;
+         for (int k = 0; ok && k < nI; ++k)
+            if (k != iv && A.T[static_cast<size_t>(q) * nI + k] != 0) ok = false;
+         if (ok) {
+            q = A.T[static_cast<size_t>(q) * nI + iv];
+            if (q == 0) ok = false;
+         }
+      }
+      if (ok) {
+         // reversed witnesses (R reads right to left)
+         std::vector<std::vector<int>> wit;
+         for (int b = 1; b < lp; ++b) {
+            bool border = true;
+            for (int i = 0; border && i < b; ++i) border = pc[static_cast<size_t>(i)] == pc[static_cast<size_t>(lp - b + i)];
+            if (!border) continue;
+            std::vector<int> w(piv.begin(), piv.end());
+            w.insert(w.end(), piv.begin() + b, piv.end());
+            std::reverse(w.begin(), w.end());
+            wit.push_back(std::move(w));
+         }
+         // Aho-Corasick states = the prefixes of the witnesses; node 0 = empty
+         std::vector<std::vector<int>> node{std::vector<int>{}};
+         std::map<std::vector<int>, int> node_id{{node[0], 0}};
+         for (const auto& w : wit)
+            for (size_t len = 1; len <= w.size(); ++len) {
+               std::vector<int> u(w.begin(), w.begin() + static_cast<long>(len));
+               if (node_id.emplace(u, static_cast<int>(node.size())).second) node.push_back(u);
+            }
+         std::vector<uint8_t> terminal(node.size(), 0);
+         for (const auto& w : wit) terminal[static_cast<size_t>(node_id[w])] = 1;
+         auto ac_step = [&](int nd, int iv) -> int {   // longest suffix of node + iv that is a node; -1 = a witness is complete
+            std::vector<int> u = node[static_cast<size_t>(nd)];
+            u.push_back(iv);
+            for (size_t cut = 0; cut <= u.size(); ++cut) {
+               auto it = node_id.find(std::vector<int>(u.begin() + static_cast<long>(cut), u.end()));
+               if (it != node_id.end()) {
+                  // a witness that ends here (this node or a suffix of it) completes the detection
+                  for (size_t c2 = cut; c2 < u.size(); ++c2) {
+                     auto it2 = node_id.find(std::vector<int>(u.begin() + static_cast<long>(c2), u.end()));
+                     if (it2 != node_id.end() && terminal[static_cast<size_t>(it2->second)]) return -1;
+                  }
+                  return it->second;
+               }
+            }
+            return 0;
+         };
+         const int nC = R.ncol;
+         std::vector<std::pair<int, int>> keys;   // (r, ac node); (-1, 0) = the sink
+         std::map<std::pair<int, int>, int> ids;
+         auto state_of = [&](int r, int nd) {
+            auto key = std::make_pair(r, nd);
+            auto it = ids.find(key);
+            if (it != ids.end()) return it->second;
+            keys.push_back(key);
+            ids.emplace(key, static_cast<int>(keys.size()) - 1);
+            return static_cast<int>(keys.size()) - 1;
+         };
+         const int init = state_of(R.init, 0);
+         const int sink = state_of(-1, 0);
+         std::vector<int> T2;
+         bool fits = true;
+         for (size_t s2 = 0; s2 < keys.size() && fits; ++s2) {
+            if (keys.size() > 4096) fits = false;
+            const int r = keys[s2].first, nd = keys[s2].second;
+            T2.resize((s2 + 1) * static_cast<size_t>(nC));
+            for (int k = 0; k < nC; ++k) {
+               int dst;
+               if (r < 0) dst = sink;
+               else if (k >= nI) dst = state_of(R.T[static_cast<size_t>(r) * nC + k], nd);   // SKIP column: not a text symbol
+               else {
+                  const int nn = ac_step(nd, k);
+                  dst = nn < 0 ? sink : state_of(R.T[static_cast<size_t>(r) * nC + k], nn);
+               }
+               T2[s2 * static_cast<size_t>(nC) + static_cast<size_t>(k)] = dst;
+            }
+         }
+         if (fits) {
+            Dfa R2;
+            R2.n = static_cast<int>(keys.size());
+            R2.ncol = nC;
+            R2.T = std::move(T2);
+            R2.init = init;
+            R2.ok = true;
+            R2.out.assign(static_cast<size_t>(R2.n), 0);
+            std::vector<int> labels(static_cast<size_t>(R2.n), 0);
+            for (int s2 = 0; s2 < R2.n; ++s2) {
+               if (keys[static_cast<size_t>(s2)].first >= 0) R2.out[static_cast<size_t>(s2)] = R.out[static_cast<size_t>(keys[static_cast<size_t>(s2)].first)];
+               else labels[static_cast<size_t>(s2)] = 1;
+            }
+            std::vector<int> o2n;
+            minimise(R2, -1, &labels, &o2n);
+            R = R2;
+            R_inv_state = o2n[static_cast<size_t>(sink)];
+            overlap_sink = true;
+         }
+      }
+   }
+
    // ---- 5. merge intervals with identical columns into classes -----------------------------------------------
    std::vector<int> cls_of(static_cast<size_t>(nI));
    int ncls = 0;
@@ -942,7 +1059,11 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       prefix_necessary = ok;
    }
    if (prefix_necessary) h.flags |= FXP_F_PREFIX_NECESSARY;
-   if (brute_equiv && prefilter) brute_equiv = prefix_necessary && border_free(lit.prefix);
+   if (brute_equiv && prefilter) brute_equiv = prefix_necessary && (border_free(lit.prefix) || overlap_sink);
+   if (overlap_sink) {
+      h.flags |= FXP_F_OVERLAP_SINK;
+      h.R_inv = static_cast<uint32_t>(R_inv_state);
+   }
    // ---- 7. fast path: <= 8 states per automaton, fused byte tables (one v_perm_b32 per input byte) ---------------------
    // `.match.` runs one forward pass of A over the whole row (api_internal_m.F90:258-302): no R, no candidate list, so the
    // tile kernel applies whenever the tables fit; its prefix/suffix gate is evaluated on the row bytes by the kernel.
@@ -1093,7 +1214,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    // engine, which follows the candidate-list driver to the letter).
    {
       std::vector<uint16_t> bcm(256, 0), btr, bta;
-      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || brute_equiv);
+      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || (brute_equiv && !overlap_sink));
       std::vector<uint8_t> bwa, bwr;
       if (want) {
          Sig full;

@@ -189,7 +189,9 @@ __device__ __forceinline__ void store_tile_relayout(uint4 (&v)[CH], uint4* tile,
 // copies of the automaton and `state >= hit_min` can compare whole registers without masking
 struct FastParams {
    uint32_t R_start, A_init, hit_min, acc_min;
-   uint32_t inv;            // BYTES modes: the INVALID state (structurally invalid UTF-8): the row is left to the decode path
+   uint32_t inv;            // BYTES modes: the INVALID state (structurally invalid UTF-8): the row is left to the decode path;
+                            // inv_on: the overlap state of R (FXP_F_OVERLAP_SINK): the row is left to the general engine
+   uint32_t inv_on;
    uint32_t defer_tiles;    // first pass: tiles holding a byte >= 0x80 are deferred whole (a later pass handles them)
    uint32_t gate_word;      // marked-tile passes: which of the call's two words says whether there is anything to do
    uint32_t lit_len;        // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       const bool row_hi = MODE == 0 && !raw && (na & 0x80808080u) != 0;
       const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
       // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8, the row-level fix-up redoes it
-      const bool exception = BYTES && state == fp.inv;
+      const bool exception = (BYTES || (MODE == 0 && fp.inv_on != 0)) && state == fp.inv;
       const bool nonascii = (row_hi && !utf8) || defer_tile || exception;
       if (BYTES) {
          // exception rows are appended to the worklist of the decode pass: one atomic per tile that has any

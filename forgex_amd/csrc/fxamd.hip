@@ -236,7 +236,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
-   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, po.defer_tiles, po.gate_word, 0};
+   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, 0u, po.defer_tiles, po.gate_word, 0};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.A_init = (BYTES ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
       fp.inv = BYTES ? h.bw16_inv_A * 0x01010101u : 0u;
@@ -290,7 +290,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TR_bytes + h.byte_TA_bytes : h.chain_TR_bytes + h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
+                 0u, 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.R_start = (BYTES ? h.bw16_R_start : h.w16_R_start) * 0x01010101u;
       fp.A_init = (BYTES ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
@@ -308,6 +308,10 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.A_init = h.chain_A_init;
       fp.hit_min = h.chain_hit_min;
       fp.acc_min = h.chain_acc_min;
+   }
+   if (MODE == 0 && (h.flags & FXP_F_OVERLAP_SINK)) {   // bordered prefix literal: rows whose backward pass ends in R's overlap state
+      fp.inv_on = 1u;
+      fp.inv = WIDE ? (h.R_inv < 8u ? h.R_inv : 0x80u + h.R_inv - 8u) * 0x01010101u : (CHAIN ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
    switch (chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);

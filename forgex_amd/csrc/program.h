@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 10u
+#define FXP_VERSION 11u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -38,6 +38,7 @@ enum FxpFlags {
    FXP_F_W16_OK = 1u << 13,         // 16-state v_perm tables present (automata with 9..16 states: two v_perm_b32 per byte instead of the LDS chain)
    FXP_F_W16_UTF8 = 1u << 14,       // ... and they hold the 128+class / SKIP rows (the decode pass may use them)
    FXP_F_BYTE_W16 = 1u << 15,       // the byte-level automata also exist in the 16-state v_perm format
+   FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match
    FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it
    FXP_F_RAW_BYTES = 1u << 10,      // literal INDEX search: symbols are raw bytes (no UTF-8 decode, no deferral), hit = occurrence start      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
@@ -100,7 +101,8 @@ struct FxpHeader {
    uint32_t off_w16A, off_w16R;     // uint8 [256][16]
    uint32_t off_bw16A, off_bw16R;   // uint8 [256][16]
    uint32_t w16_finalM[4], bw16_finalM[4];   // `.match.`: byte j = verdict of state j after the last text byte (byte-level: 2 = redo by the decode path)
-   uint32_t reserved[2];
+   uint32_t R_inv;        // FXP_F_OVERLAP_SINK: that state of R (a row that ends its backward pass there is left to the general engine)
+   uint32_t reserved[1];
 };
 
 #define FXP_STATE_MASK 0x7FFFu

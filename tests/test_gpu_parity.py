@@ -552,3 +552,31 @@ def test_batch_shapes_and_handle_reuse(fx):
                     assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, n, L)
             fm, _, _ = pm.match_host(rows, spans=False)
             assert np.array_equal(fm, om), (pat, n, L, "match")
+
+
+def test_bordered_prefix_literals_on_tile_kernel(fx):
+    """Prefix literals with a border (`--x`, `aa[bc]`, `abab\\d`): the reference collects NON-overlapping occurrences, so rows where
+    two occurrences overlap (`---x`, `aaab`) differ from brute force; R carries an absorbing state for exactly those rows and
+    the tile kernels hand them to the general engine (`aa[bc]` .in. `aaab` is F in the reference)."""
+    nrng = np.random.default_rng(73)
+    alpha = np.frombuffer(b"ab-cxz01 ", dtype=np.uint8)
+    for L in (64, 256, 100, 512):
+        rows = alpha[nrng.integers(0, len(alpha), size=(8000, L))].copy()
+        seeds = [b"--ab", b"---ab", b"aab", b"aaab", b"aaaac", b"abab1", b"ababab2", b"zz9", b"zzz9", b"abaxy", b"ababa"]
+        for i in range(0, 8000, 2):
+            sd = np.frombuffer(seeds[(i // 2) % len(seeds)], dtype=np.uint8)
+            off = int(nrng.integers(0, L - len(sd)))
+            rows[i, off:off + len(sd)] = sd
+        for pat in (rb"--[a-z]+", rb"aa[bc]", rb"abab\d", rb"zz\d+", rb"aba[a-z]+"):
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            assert prog.info()["flags"] & 0x20000, pat
+            assert prog.last_path() in (3, 6), (pat, L, prog.last_path())
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            assert np.array_equal(f, of), (pat, L)
+            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
+            _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+            assert np.array_equal(f2, of), (pat, L, "flags-only")
+            assert int(of.sum()) > 0, pat
+    # the quirk itself
+    prog, f, a, b = _device_run(fx, rb"aa[bc]", fx.OP_SEARCH, np.frombuffer(b"aaab".ljust(16) + b"xaab".ljust(16), dtype=np.uint8).reshape(2, 16))
+    assert list(f) == [0, 1]
