@@ -389,11 +389,11 @@ __device__ unsigned long long fx_stamp_acc[16];
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
-//                 the offending rows are marked individually for the general kernel's fix-up.
+//                 the offending rows are appended one by one to the worklist of the general engine's fix-up.
 // FIXUP = true:  second pass: only marked tiles are loaded, decoded from UTF-8 to symbol ids in LDS, then scanned.
 // MODE 0: first pass (class-level tables), as above.            MODE 1: the decode second pass (FIXUP), marked tiles only.
 // MODE 2: byte-level tables (FXP_F_BYTE_DFA) over ALL tiles: raw bytes are the symbols, nothing is decoded or deferred; rows
-//         whose backward pass ends in the INVALID state keep FX_NEEDS_GENERAL for the row-level fix-up (fx_fixup).
+//         whose backward pass ends in the INVALID state go to the worklist (decode pass or fx_fixup_list).
 // MODE 3: the same over the tiles a MODE 0 pass deferred.
 // MODE 4: the decode pass over a WORKLIST of row indices (the exception rows a BYTES pass appended): each lane gathers its own
 //         row into its LDS cells, results are scattered back to the rows' own slots.
@@ -691,14 +691,16 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8, the row-level fix-up redoes it
       const bool exception = (BYTES || (MODE == 0 && fp.inv_on != 0)) && state == fp.inv;
       const bool nonascii = (row_hi && !utf8) || defer_tile || exception;
-      if (BYTES) {
-         // exception rows are appended to the worklist of the decode pass: one atomic per tile that has any
-         const uint64_t em = __builtin_amdgcn_ballot_w64(exception && row_ok);
+      if (BYTES || MODE == 0) {
+         // exception rows are appended to the worklist of the decode pass: one atomic per tile that has any.  A first pass
+         // without decode tables lists its own leftovers (rows with bytes >= 0x80, overlap rows) for the row-level fix-up.
+         const bool listed = (BYTES ? exception : (worklist != nullptr && (exception || (row_hi && !utf8)))) && row_ok;
+         const uint64_t em = __builtin_amdgcn_ballot_w64(listed);
          if (em != 0) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (exception && row_ok) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+            if (listed) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
          }
       }
 
@@ -1056,13 +1058,14 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
       const bool row_hi = MODE == 0 && (na & 0x80808080u) != 0;
       const bool defer_tile = MODE == 0 && utf8 && __builtin_amdgcn_ballot_w64(row_hi) != 0;
       const bool exception = BYTES && gate == 1u && st != 0 && fin == 2u;   // inside a character / INVALID at the end of the row
-      if (BYTES) {   // exception rows are appended to the worklist of the decode pass
-         const uint64_t em = __builtin_amdgcn_ballot_w64(exception && row_ok);
+      if (BYTES || MODE == 0) {   // exception rows are appended to the worklist of the decode pass / of the row-level fix-up
+         const bool listed = (BYTES ? exception : (worklist != nullptr && row_hi && !utf8)) && row_ok;
+         const uint64_t em = __builtin_amdgcn_ballot_w64(listed);
          if (em != 0) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (exception && row_ok) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+            if (listed) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
          }
       }
       if ((row_hi && !utf8) || defer_tile || exception) flag = FX_NEEDS_GENERAL;

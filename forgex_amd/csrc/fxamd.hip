@@ -93,39 +93,6 @@ __global__ __launch_bounds__(256) void fx_fixup_list(const uint8_t* __restrict__
    }
 }
 
-// Fix-up pass after the fast kernel: every thread inspects 16 flags with one 16-byte load and only rows marked
-// FX_NEEDS_GENERAL (bytes >= 0x80: on-device UTF-8 decode needed) are re-matched, with the tables read from global memory.
-__global__ __launch_bounds__(256) void fx_fixup(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
-                                                 uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
-                                                 const uint32_t* __restrict__ gate) {
-   if (gate && *gate == 0) return;   // the pass before left no row behind
-   const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-   if (base >= n) return;
-   uint32_t marks = 0;
-   if (base + 16 <= n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(flags + base);   // cudaMalloc'ed / torch buffers are 256-byte aligned
-      if (((v.x | v.y | v.z | v.w) & 0x80808080u) == 0) return;
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 16; ++k) marks |= (((w[k >> 2] >> ((k & 3) * 8)) & 0xFFu) == FX_NEEDS_GENERAL ? 1u : 0u) << k;
-   } else {
-      for (int k = 0; base + k < n; ++k) marks |= (flags[base + k] == FX_NEEDS_GENERAL ? 1u : 0u) << k;
-   }
-   if (marks == 0) return;
-   fxrow::ProgView pv(prog);
-   for (int k = 0; k < 16; ++k) {
-      if (!((marks >> k) & 1u)) continue;
-      const int64_t row = base + k;
-      GlobalRow r{rows + row * (int64_t)L};
-      fxrow::Result res;
-      fxrow::DfaSim sim(pv);
-      fxrow::run_row(pv, sim, r, L, res);
-      flags[row] = (uint8_t)res.flag;
-      if (from) from[row] = res.from;
-      if (to) to[row] = res.to;
-   }
-}
-
 // LDS-staged variant for 16-byte-multiple rows: one wave per block, dynamic LDS = 64*L bytes (L <= 1024)
 __global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict__ rows, int64_t n, int32_t L, const uint8_t* __restrict__ prog,
                                                         uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
@@ -155,6 +122,45 @@ __global__ __launch_bounds__(64) void fx_general_tiled(const uint8_t* __restrict
    flags[row] = (uint8_t)res.flag;
    if (from) from[row] = res.from;
    if (to) to[row] = res.to;
+}
+
+// fx_fixup_list with the listed rows gathered into LDS first (16-byte-multiple rows, L <= 1024): one wave per block takes 64 list
+// entries at a time.  A listed row costs a serial walk of its bytes; from LDS that walk is several times shorter than from global
+// memory, and a short list is all latency.
+__global__ __launch_bounds__(64) void fx_fixup_list_tiled(const uint8_t* __restrict__ rows, int32_t L, const uint8_t* __restrict__ prog,
+                                                           uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
+                                                           const uint32_t* __restrict__ worklist, const uint32_t* __restrict__ count_p,
+                                                           uint32_t prog_lds_bytes) {
+   extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
+   const uint32_t count = *count_p;
+   if ((uint64_t)blockIdx.x * 64u >= count) return;
+   uint4* tiles = dyn_lds + prog_lds_bytes / 16;
+   const uint8_t* pbase = stage_program(prog, reinterpret_cast<uint8_t*>(dyn_lds), prog_lds_bytes);
+   fxrow::ProgView pv(pbase);
+   const uint32_t lane = threadIdx.x;
+   const uint32_t CH = (uint32_t)L >> 4;
+   for (uint64_t i0 = (uint64_t)blockIdx.x * 64u; i0 < count; i0 += (uint64_t)gridDim.x * 64u) {
+      const uint32_t listed = count - i0 >= 64u ? 64u : (uint32_t)(count - i0);
+      const uint32_t my_row = lane < listed ? worklist[i0 + lane] : 0u;
+      for (uint32_t q = 0; q < CH; ++q) {
+         const uint32_t p = q * 64u + lane, R = p / CH, k = p - R * CH;
+         const uint32_t src_row = __shfl(my_row, (int)R);
+         uint4 v = make_uint4(0, 0, 0, 0);
+         if (R < listed) v = *reinterpret_cast<const uint4*>(rows + (int64_t)src_row * L + (k << 4));
+         tiles[tile_cell(R, k)] = v;
+      }
+      __syncthreads();
+      if (lane < listed) {
+         TileRow r{reinterpret_cast<const uint8_t*>(tiles), lane};
+         fxrow::Result res;
+         fxrow::DfaSim sim(pv);
+         fxrow::run_row(pv, sim, r, L, res);
+         flags[my_row] = (uint8_t)res.flag;
+         if (from) from[my_row] = res.from;
+         if (to) to[my_row] = res.to;
+      }
+      __syncthreads();
+   }
 }
 
 // FXP_F_NFA_SIM programs (DFA too large to build): one lane = one row, NFA state sets as bitsets in `scratch`
@@ -568,20 +574,11 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
       const int bsch = bytes_scheme(h);
       const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
-      // row-level fix-up through the general engine: rows still marked FX_NEEDS_GENERAL (gate: skip when the word says none are)
-      auto fixup_rows = [&](const uint32_t* gate) -> int {
-         if ((reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0) {
-            const unsigned fblocks = (unsigned)((n + 4095) / 4096);
-            hipLaunchKernelGGL(fx_fixup, dim3(fblocks), dim3(256), 0, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, gate);
-         } else {
-            hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 1, prog_lds);
-         }
-         FX_HIP(hipGetLastError());
-         return FXAMD_OK;
-      };
       PassOpts first, marked, listp;
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
-      if (bytes) {   // worklist of the rows the byte-level tables cannot answer (structurally invalid or non-canonical UTF-8)
+      // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
+      // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
+      if (bytes || !utf8_tables) {
          std::lock_guard<std::mutex> g(p->mu);
          if (p->worklist_rows < n) {
             if (p->d_worklist) (void)hipFree(p->d_worklist);
@@ -596,15 +593,23 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
       }
       // exception rows of a byte-level pass: the decode pass over the gathered worklist when the class-level tables can decode,
       // else the row-level fix-up through the general engine
-      auto exceptions = [&]() -> int {
-         if (!utf8_tables) {   // the general engine over the worklist
+      auto list_fixup = [&]() -> int {   // the general engine over the worklist
+         if (aligned16 && (size_t)64 * row_len + prog_lds <= 65536u) {
+            int64_t tb = (n + 63) / 64;
+            if (tb > 16384) tb = 16384;
+            hipLaunchKernelGGL(fx_fixup_list_tiled, dim3((unsigned)tb), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, (int32_t)row_len, p->d_blob,
+                               d_flags, d_from, d_to, p->d_worklist, ctr + 1, prog_lds);
+         } else {
             int64_t lblocks = (n + 255) / 256;
             if (lblocks > 4096) lblocks = 4096;
             hipLaunchKernelGGL(fx_fixup_list, dim3((unsigned)lblocks), dim3(256), prog_lds, st, d_rows, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to,
                                p->d_worklist, ctr + 1, prog_lds);
-            FX_HIP(hipGetLastError());
-            return FXAMD_OK;
          }
+         FX_HIP(hipGetLastError());
+         return FXAMD_OK;
+      };
+      auto exceptions = [&]() -> int {
+         if (!utf8_tables) return list_fixup();
          if (is_match) FX_HIP(match_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp));
          else FX_HIP(fast_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp));
          return FXAMD_OK;
@@ -638,11 +643,11 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
          p->last_path = 1 + big;
          return FXAMD_OK;
       }
-      // rows holding bytes >= 0x80 were marked one by one: row-level fix-up (a cheap read of the flags otherwise)
+      // rows holding bytes >= 0x80 (and overlap rows) were listed one by one: row-level fix-up over that list
       p->last_path = 3 + big - (big ? 1 : 0);
-      return fixup_rows(nullptr);
+      return list_fixup();
    }
-   if (aligned16 && row_len <= 1024) {
+   if (aligned16 && (size_t)64 * row_len + prog_lds <= 65536u) {   // (64 KB: the dynamic LDS a launch gets without opting in to more)
       const unsigned tblocks = (unsigned)((n + 63) / 64);
       hipLaunchKernelGGL(fx_general_tiled, dim3(tblocks), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob,
                          d_flags, d_from, d_to, prog_lds);
