@@ -104,8 +104,9 @@ def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30,
+                    help="untimed steps first; the clocks settle over the first ~20 back-to-back launches after an idle gap (DESIGN.md 4.1)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's size; cfg5: 12.5M)")
     ap.add_argument("--flags-only", action="store_true", help="time the flags-only `.in.` entry instead of flags+spans")
@@ -171,11 +172,14 @@ def main():
     # ---- roofline leg: the dominant kernel alone, HIP events on its launch stream --------------------------
     L = forgex_amd.lib()
     stream = torch.cuda.current_stream(dev)
-    reps = max(5, min(args.steps, 50))
+    reps = max(5, min(args.steps, 200))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     kernel_ms = None
     fast = prog.last_path() in (1, 3, 5, 6, 7, 8)
     whole_step = cfg == "cfg4"   # non-ASCII rows: the work is in the SECOND pass (on-device UTF-8 decode + scan) -> time the whole step
+    if fast:   # the CPU-side work since the timed region left the GPU idle: settle the clocks again, as the warm-up steps did
+        for _ in range(args.warmup):
+            step()
     if fast and whole_step:
         for a, b in evs:
             a.record(stream)
@@ -216,7 +220,7 @@ def main():
     if spans:
         try:
             out_f = (flags, None, None)
-            for _ in range(2):
+            for _ in range(max(2, args.warmup)):
                 prog.match_device(rows, spans=False, out=out_f)
             barrier()
             f0 = time.perf_counter()
@@ -235,15 +239,16 @@ def main():
     copy_gbs = None
     try:
         scratch = torch.empty_like(rows)
-        for _ in range(2):
+        for _ in range(max(2, args.warmup)):
             scratch.copy_(rows)
+        ncopy = max(5, min(args.steps, 50))
         ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ca.record(stream)
-        for _ in range(5):
+        for _ in range(ncopy):
             scratch.copy_(rows)
         cb.record(stream)
         torch.cuda.synchronize()
-        copy_gbs = 2.0 * rows.numel() * 5 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+        copy_gbs = 2.0 * rows.numel() * ncopy / (ca.elapsed_time(cb) * 1e-3) / 1e9
         del scratch
     except Exception:
         copy_gbs = None
