@@ -27,7 +27,11 @@ for spans in (True, False):
     prog.match_device(rows, spans=spans)
     torch.cuda.synchronize()
     lib.fxamd_debug_stamps(buf)
-    for _ in range(5):
+    for _ in range(60):   # (the clocks settle over the first ~30 back-to-back launches)
+        prog.match_device(rows, spans=spans)
+    torch.cuda.synchronize()
+    lib.fxamd_debug_stamps(buf)
+    for _ in range(20):
         prog.match_device(rows, spans=spans)
     torch.cuda.synchronize()
     lib.fxamd_debug_stamps(buf)
@@ -37,4 +41,4 @@ for spans in (True, False):
              "output + loop end", "loop head"]
     print("spans" if spans else "flags only")
     for nm, x in zip(names, v):
-        print("  %-30s %6.2f %%" % (nm, 100.0 * x / tot))
+        print("  %-30s %6.2f %%   %8.0f cycles per tile" % (nm, 100.0 * x / tot, x / (20.0 * ((n + 63) // 64))))
