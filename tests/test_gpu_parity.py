@@ -580,3 +580,14 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
     # the quirk itself
     prog, f, a, b = _device_run(fx, rb"aa[bc]", fx.OP_SEARCH, np.frombuffer(b"aaab".ljust(16) + b"xaab".ljust(16), dtype=np.uint8).reshape(2, 16))
     assert list(f) == [0, 1]
+    # a worklist longer than one grid of the list fix-up (16384 blocks x 64 rows): every row holds an overlap witness or a byte >= 0x80
+    n = 16384 * 64 + 4321
+    rows = alpha[nrng.integers(0, len(alpha), size=(n, 32))].copy()
+    rows[0::2, 5:8] = np.frombuffer(b"aaa", dtype=np.uint8)
+    rows[1::2, 9] = 0xE9
+    rows[1::4, 20:23] = np.frombuffer(b"aab", dtype=np.uint8)
+    prog, f, a, b = _device_run(fx, rb"aa[bc]", fx.OP_SEARCH, rows)
+    assert prog.last_path() == 3
+    of, oa, ob = oracle_lib.batch(2, rb"aa[bc]", rows, NT)
+    assert np.array_equal(f, of) and np.array_equal(a, oa) and np.array_equal(b, ob)
+    assert 0 < int(of.sum()) < n
