@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SETTLE = 30              # untimed launches before any timed leg, so that the clocks have settled (see the warm-up comment below)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
@@ -153,6 +154,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # clock settling: after an idle gap the first ~20 back-to-back launches run at drifting clocks (0.53 -> 0.67 -> 0.50 ms per
+    # launch on config 3); when fewer than SETTLE warm-up steps were asked for, the difference is run first, untimed,
+    # and reported as config.clock_settle_steps
+    settle = max(0, SETTLE - args.warmup)
+    for _ in range(settle):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -178,7 +185,7 @@ def main():
     fast = prog.last_path() in (1, 3, 5, 6, 7, 8)
     whole_step = cfg == "cfg4"   # non-ASCII rows: the work is in the SECOND pass (on-device UTF-8 decode + scan) -> time the whole step
     if fast:   # the CPU-side work since the timed region left the GPU idle: settle the clocks again, as the warm-up steps did
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, SETTLE)):
             step()
     if fast and whole_step:
         for a, b in evs:
@@ -220,7 +227,7 @@ def main():
     if spans:
         try:
             out_f = (flags, None, None)
-            for _ in range(max(2, args.warmup)):
+            for _ in range(max(SETTLE, args.warmup)):
                 prog.match_device(rows, spans=False, out=out_f)
             barrier()
             f0 = time.perf_counter()
@@ -239,7 +246,7 @@ def main():
     copy_gbs = None
     try:
         scratch = torch.empty_like(rows)
-        for _ in range(max(2, args.warmup)):
+        for _ in range(max(SETTLE, args.warmup)):
             scratch.copy_(rows)
         ncopy = max(5, min(args.steps, 50))
         ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -278,7 +285,8 @@ def main():
             "config": {"workload": "%s: `%s` .in. (flags%s) over %d x %d B rows per GPU, counter-based PRNG rows resident in HBM" % (
                 cfg, pattern, " + (from,to) spans" if spans else " only", rows_per_gpu, row_len),
                 "rows_per_gpu": rows_per_gpu, "row_len": row_len, "pattern": pattern, "parallelism": "shard%d" % world,
-                "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches},
+                "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches,
+                "clock_settle_steps": settle},
             "frac_of_hbm_peak": total_bytes / dt / 1e9 / (HBM_PEAK_GBS * world),
             "frac_of_one_eighth_gpu": total_bytes / dt / 1e9 / (HBM_PEAK_GBS / 8 * world),
             "roofline": roofline, "gather_ms": gather_ms, "flags_only": flags_only,
