@@ -776,16 +776,68 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       }
    }
 
+   // (used by 4b and by section 7, where the argument is written out)
+   auto suffix_is_necessary_ending = [&]() -> bool {
+      bool ok = lit.suffix.find('\0') == std::string::npos;
+      const std::vector<int32_t> sc = decode_chars(lit.suffix), pc = decode_chars(lit.prefix);
+      for (int32_t c : sc) ok = ok && c < 128;
+      for (int32_t c : pc) ok = ok && c < 128;
+      Bits Wb = rclos[static_cast<size_t>(nfa.exit)];
+      for (size_t i = sc.size(); ok && i-- > 0;) {
+         if (bt(Wb, nfa.entry)) ok = false;
+         const int iv = interval_of(sc[i]);
+         if (!(bounds[static_cast<size_t>(iv)] == sc[i] && bounds[static_cast<size_t>(iv) + 1] == sc[i] + 1)) ok = false;
+         Bits nxt(W, 0);
+         for (int z = 1; ok && z <= N; ++z) {
+            if (!bt(Wb, z)) continue;
+            for (int ti : inc[static_cast<size_t>(z)]) {
+               const FlatTra& ft = tras[static_cast<size_t>(ti)];
+               for (int k : ft.acc) {
+                  if (k != iv) ok = false;   // some other symbol can stand at this distance from the end of a match
+                  else bor(nxt, rclos[static_cast<size_t>(ft.src)]);
+               }
+            }
+         }
+         Wb = nxt;
+         if (!bany(Wb)) ok = false;
+      }
+      // shortest accepted string (in symbols) >= prefix + suffix: breadth-first over A
+      if (ok) {
+         std::vector<int> dist(static_cast<size_t>(A.n), -1);
+         std::vector<int> queue{A.init};
+         dist[static_cast<size_t>(A.init)] = 0;
+         int shortest = -1;
+         for (size_t qi = 0; qi < queue.size() && shortest < 0; ++qi) {
+            const int st = queue[qi];
+            if (A.out[static_cast<size_t>(st)] && st != A.init) {
+               shortest = dist[static_cast<size_t>(st)];
+               break;
+            }
+            for (int k = 0; k < nI; ++k) {
+               const int t = A.T[static_cast<size_t>(st) * nI + k];
+               if (t != 0 && dist[static_cast<size_t>(t)] < 0) {
+                  dist[static_cast<size_t>(t)] = dist[static_cast<size_t>(st)] + 1;
+                  queue.push_back(t);
+               }
+            }
+         }
+         if (shortest < 0 || static_cast<size_t>(shortest) < pc.size() + sc.size()) ok = false;
+      }
+      return ok;
+   };
    // ---- 4b. prefix literal with a BORDER (`--x`, `aa[bc]`, `abab.*`): the reference's candidate list holds NON-overlapping
    // occurrences of the prefix (utility_m.f90:94-116), so it differs from brute force exactly on rows where two occurrences
    // overlap -- rows that contain a WITNESS p + p[b..] for a border length b.  R is composed with an Aho-Corasick detector of the
    // (reversed) witnesses whose hit is one absorbing state: the tile kernels search by brute force and hand rows that end there
-   // to the general engine.  Only with a necessary prefix (checked here on the intervals) and without a suffix literal (the
-   // general engine's own brute-force fallback then only ever runs on rows without the prefix, where the detector stays idle).
+   // to the general engine.  Only with a necessary prefix (checked here on the intervals).  The general engine's own brute-force
+   // fallback (api_internal_m.F90:79-81) walks this same R: without a suffix literal it only runs on rows without the prefix, where
+   // the detector stays idle; with one it also runs when the first prefix occurrence lies behind the last suffix occurrence, and
+   // then -- the suffix being a necessary ending, no match shorter than prefix + suffix -- the row holds no match at all, which is
+   // what R reports whether or not it falls into the absorbing state on the way.
    bool overlap_sink = false;
    int R_inv_state = -1;
-   if (op == OP_SEARCH && R.ok && !f_eq(lit.prefix, "") && f_eq(lit.suffix, "") && !border_free(lit.prefix) &&
-       lit.prefix.find('\0') == std::string::npos) {
+   if (op == OP_SEARCH && R.ok && !f_eq(lit.prefix, "") && !border_free(lit.prefix) && lit.prefix.find('\0') == std::string::npos &&
+       (f_eq(lit.suffix, "") || suffix_is_necessary_ending())) {
       const std::vector<int32_t> pc = decode_chars(lit.prefix);
       const int lp = static_cast<int>(pc.size());
       std::vector<int> piv(static_cast<size_t>(lp));
@@ -987,52 +1039,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       // suffix of the match found starts at least one byte behind the match start, which is all the off-by-one needs).
       // Necessity is checked on the NFA walked BACKWARDS from the exit: at each of the last ls positions only the suffix's own
       // symbol -- a singleton class -- leads anywhere, and the entry state (a complete, shorter match) is not met on the way.
-      bool ok = lit.suffix.find('\0') == std::string::npos;
-      const std::vector<int32_t> sc = decode_chars(lit.suffix), pc = decode_chars(lit.prefix);
-      for (int32_t c : sc) ok = ok && c < 128;
-      for (int32_t c : pc) ok = ok && c < 128;
-      Bits Wb = rclos[static_cast<size_t>(nfa.exit)];
-      for (size_t i = sc.size(); ok && i-- > 0;) {
-         if (bt(Wb, nfa.entry)) ok = false;
-         const int iv = interval_of(sc[i]);
-         if (!(bounds[static_cast<size_t>(iv)] == sc[i] && bounds[static_cast<size_t>(iv) + 1] == sc[i] + 1)) ok = false;
-         Bits nxt(W, 0);
-         for (int z = 1; ok && z <= N; ++z) {
-            if (!bt(Wb, z)) continue;
-            for (int ti : inc[static_cast<size_t>(z)]) {
-               const FlatTra& ft = tras[static_cast<size_t>(ti)];
-               for (int k : ft.acc) {
-                  if (k != iv) ok = false;   // some other symbol can stand at this distance from the end of a match
-                  else bor(nxt, rclos[static_cast<size_t>(ft.src)]);
-               }
-            }
-         }
-         Wb = nxt;
-         if (!bany(Wb)) ok = false;
-      }
-      // shortest accepted string (in symbols) >= prefix + suffix: breadth-first over A
-      if (ok) {
-         std::vector<int> dist(static_cast<size_t>(A.n), -1);
-         std::vector<int> queue{A.init};
-         dist[static_cast<size_t>(A.init)] = 0;
-         int shortest = -1;
-         for (size_t qi = 0; qi < queue.size() && shortest < 0; ++qi) {
-            const int st = queue[qi];
-            if (A.out[static_cast<size_t>(st)] && st != A.init) {
-               shortest = dist[static_cast<size_t>(st)];
-               break;
-            }
-            for (int k = 0; k < nI; ++k) {
-               const int t = A.T[static_cast<size_t>(st) * nI + k];
-               if (t != 0 && dist[static_cast<size_t>(t)] < 0) {
-                  dist[static_cast<size_t>(t)] = dist[static_cast<size_t>(st)] + 1;
-                  queue.push_back(t);
-               }
-            }
-         }
-         if (shortest < 0 || static_cast<size_t>(shortest) < pc.size() + sc.size()) ok = false;
-      }
-      brute_equiv = ok;
+      brute_equiv = suffix_is_necessary_ending();
    }
    // the prefix literal is a NECESSARY beginning of every non-empty match (walking A along it, each state is non-accepting and only
    // the next prefix symbol -- a singleton class -- is live): with it the general engine may skip the reference's brute-force

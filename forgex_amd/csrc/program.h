@@ -29,11 +29,11 @@ enum FxpFlags {
    FXP_F_HAS_SUFFIX = 1u << 2,      // suffix literal is not blank
    FXP_F_FAST_OK = 1u << 3,         // <=8-state byte tables present and brute-force semantics proven equivalent
    FXP_F_HAS_R = 1u << 4,           // reverse DFA present (else: bounded restart loop)
-   FXP_F_MATCH_LITERAL = 1u << 5,
-   FXP_F_FAST_UTF8 = 1u << 6,
-   FXP_F_NFA_SIM = 1u << 7,
+   FXP_F_MATCH_LITERAL = 1u << 5,   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
+   FXP_F_FAST_UTF8 = 1u << 6,       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place
+   FXP_F_NFA_SIM = 1u << 7,         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions
    FXP_F_CHAIN_OK = 1u << 8,        // class-indexed LDS chain tables present (automata too large for the v_perm tables)
-   FXP_F_CHAIN_UTF8 = 1u << 9,
+   FXP_F_CHAIN_UTF8 = 1u << 9,      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8
    FXP_F_BYTE_DFA = 1u << 12,       // byte-level chain tables present (UTF-8 composed into the automata)
    FXP_F_W16_OK = 1u << 13,         // 16-state v_perm tables present (automata with 9..16 states: two v_perm_b32 per byte instead of the LDS chain)
    FXP_F_W16_UTF8 = 1u << 14,       // ... and they hold the 128+class / SKIP rows (the decode pass may use them)
@@ -41,7 +41,7 @@ enum FxpFlags {
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match
    FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it
-   FXP_F_RAW_BYTES = 1u << 10,      // literal INDEX search: symbols are raw bytes (no UTF-8 decode, no deferral), hit = occurrence start      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8         // DFA too large: NFA state sets are simulated on the device (bitsets), both directions       // fast tables also hold 128+class and SKIP rows: the fast kernel decodes UTF-8 in place   // .match.: `all` literal present -> byte equality when lengths agree (forgex.F90:207-213)
+   FXP_F_RAW_BYTES = 1u << 10,      // literal INDEX search: symbols are raw bytes (no UTF-8 decode, no deferral), hit = occurrence start
 };
 
 struct FxpHeader {

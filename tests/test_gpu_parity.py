@@ -562,12 +562,13 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
     alpha = np.frombuffer(b"ab-cxz01 ", dtype=np.uint8)
     for L in (64, 256, 100, 512):
         rows = alpha[nrng.integers(0, len(alpha), size=(8000, L))].copy()
-        seeds = [b"--ab", b"---ab", b"aab", b"aaab", b"aaaac", b"abab1", b"ababab2", b"zz9", b"zzz9", b"abaxy", b"ababa"]
+        seeds = [b"--ab", b"---ab", b"aab", b"aaab", b"aaaac", b"abab1", b"ababab2", b"zz9", b"zzz9", b"abaxy", b"ababa", b"--x--", b"---x---",
+                 b"b0aaxb0", b"aaab0b0", b"abay", b"ababacy"]
         for i in range(0, 8000, 2):
             sd = np.frombuffer(seeds[(i // 2) % len(seeds)], dtype=np.uint8)
             off = int(nrng.integers(0, L - len(sd)))
             rows[i, off:off + len(sd)] = sd
-        for pat in (rb"--[a-z]+", rb"aa[bc]", rb"abab\d", rb"zz\d+", rb"aba[a-z]+"):
+        for pat in (rb"--[a-z]+", rb"aa[bc]", rb"abab\d", rb"zz\d+", rb"aba[a-z]+", rb"aba[a-z]*y", rb"aa.*b0", rb"--[a-z ]+--"):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             assert prog.info()["flags"] & 0x20000, pat
             assert prog.last_path() in (3, 6), (pat, L, prog.last_path())
