@@ -101,7 +101,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
                            int32_t* d_from, int32_t* d_to, void* hip_stream);
 
 /* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ second fast pass with
- * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up of non-ASCII rows,
+ * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up (over a worklist) of non-ASCII rows and of rows where two occurrences of a bordered prefix literal overlap,
  * 4 = NFA state-set simulation (DFA too large to build), 5 / 6 = like 1 / 3 for automata with more than 8 states (wide v_perm
  * tables up to 16 states, class-indexed LDS chain tables beyond), 7 = byte-level chain tables (UTF-8 composed into the automata) over every tile + row-level
  * fix-up of structurally invalid rows, 8 = fast kernel on the pure-ASCII tiles, byte-level chain tables on the others, same fix-up.
