@@ -682,7 +682,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          s = state >= fp.hit_min ? 1u : s;
          if (LONG && !row_ok) s = 0;   // (no row: the forward pass would read global memory)
       }
-      const uint8_t* fsrc = LONG ? rows + row * (int64_t)L : tb;   // where the forward pass finds the row's bytes
+      // where the forward pass finds the row's bytes (lanes past the last row of a long-row batch read row 0: every lane fetches)
+      const uint8_t* fsrc = LONG ? rows + (row_ok ? row : 0) * (int64_t)L : tb;
       // Bytes >= 0x80 in the first pass: without UTF-8 tables the ROW goes to the general kernel's fix-up; with them the whole
       // TILE is deferred to the second pass (wave-uniform; the raw-byte scan above is discarded and the
       // forward walk below is skipped).
@@ -760,13 +761,22 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          }
          j += 32u;
          STAMP(4);
-         // matches longer than the window: 8 symbols per round trip
-         while (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-            if (cur != 0) {
-               uint32_t o8[2];
-               fetch8<RAGGED, LONG>(o8, fsrc, lane, j, (uint32_t)L);
+         // matches longer than the window: 8 symbols per round trip.  The stream is a rolling window of two aligned 8-byte groups
+         // (t0, t1); the group after them is read one round ahead, so a round waits for its table lookups only.  Wave-uniform: dead
+         // lanes (state 0 is absorbing and below acc_min) ride along.
+         if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+            const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
+            uint32_t gb = j & ~7u;
+            uint32_t t0[2], t1[2];
+            group_words<RAGGED, LONG>(t0[0], t0[1], fsrc, lane, gb, (uint32_t)L);
+            group_words<RAGGED, LONG>(t1[0], t1[1], fsrc, lane, gb + 8u, (uint32_t)L);
+            do {
+               uint32_t t2[2];
+               group_words<RAGGED, LONG>(t2[0], t2[1], fsrc, lane, gb + 16u, (uint32_t)L);
+               const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
+               const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
                F f8[8];
-               lookup8(f8, o8[0], o8[1], tabA);
+               lookup8(f8, o0, o1, tabA);
                uint32_t loc = 8;
 #pragma unroll
                for (int q = 0; q < 8; ++q) {
@@ -775,7 +785,10 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
                }
                mm = loc != 8u ? j + loc + 3u : mm;
                j += 8u;
-            }
+               gb += 8u;
+               t0[0] = t1[0]; t0[1] = t1[1];
+               t1[0] = t2[0]; t1[1] = t2[1];
+            } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
          }
       }
       STAMP(5);
