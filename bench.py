@@ -3,21 +3,31 @@
 
 A "step" is ONE pass of the hot path over the resident batch: fxamd_match_batch_device (flags + (from,to) spans
 for every row) on BASELINE.json config 3 -- `[a-z]+\\d+` over 10M x 256 B synthetic rows, inputs already in HBM.
-With --gpus N each rank owns its own 10M-row shard of an N*10M-row batch (weak scaling, no data-path collective);
+With --gpus N each rank owns its own shard of an N-times larger batch (weak scaling, no data-path collective);
 the packed-result gather over RCCL is timed separately and reported as `gather_ms`.
 
+Launch: `python bench.py --gpus N` starts the N rank processes itself (one per GPU, RCCL rendezvous on 127.0.0.1) when no
+launcher did; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the launcher's
+RANK / LOCAL_RANK / WORLD_SIZE are used.  The parent never touches the GPU: it only relays rank 0's JSON line.
+
 One JSON line on rank 0:
-  value        whole-job input GB/s = N * rows * row_len * steps / max-over-ranks wall time
-  roofline     dominant kernel (fx_search_fast) vs the HBM roofline: algorithmic bytes per launch
-               (rows * (row_len + 9): input once + 1 flag + two int32) / its average launch duration, measured
-               live with HIP events on the launch stream
+  value        whole-job input GB/s = N * rows * row_len * steps / max-over-ranks wall time of EXACTLY `--steps` steps after
+               EXACTLY `--warmup` untimed ones (so a short run carries the clock transient of the first launches after an
+               idle gap); `settled` repeats the measurement after SETTLE more launches
+  roofline     dominant kernel vs the HBM roofline: algorithmic bytes per launch (rows * (row_len + 9): input once +
+               1 flag + two int32) / its average launch duration, measured live with HIP events on the launch stream,
+               at settled clocks (`cold_*`: the same over the first launches after an idle gap)
+  parity       GPU flags / from / to of THIS run against the product's tables walked on the host (test harness
+               tests/support/libhostwalk.so, all host cores) over the WHOLE batch of the rank
   cpu_baseline the REAL reference (oracle/_ref/ref_driver, flang build; kind "reference") or the C++ restatement
-               (oracle/liboracle.so; kind "port") on a bounded sample of the same rows, on this host's cores
+               (oracle/liboracle.so; kind "port") on a bounded sample of the same rows, on this host's cores, and the GPU
+               results compared with the reference's on that sample
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -26,12 +36,79 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SETTLE = 30              # untimed launches before any timed leg, so that the clocks have settled (see the warm-up comment below)
+SETTLE = 30              # back-to-back launches after which the clocks have settled
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+DRYRUN = os.environ.get("FXAMD_BENCH_DRYRUN") == "1"   # CPU plumbing check of the N-rank path (gloo, no GPU, no timing claims)
 
 
-def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
-    """Reference CPU path on a bounded sample of the SAME workload rows (rank 0, N=1 only)."""
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start N children (RANK / LOCAL_RANK / WORLD_SIZE set), relay rank 0's line.  Runs BEFORE
+    anything touches the GPU; the parent stays a plain Python process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.PIPE if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def host_walker():
+    path = os.path.join(ROOT, "tests", "support", "libhostwalk.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.hw_batch_mt.argtypes = [ctypes.c_char_p, i64, ctypes.c_int, vp, i64, i64, vp, vp, vp, ctypes.c_int]
+    return lib
+
+
+def full_parity(pattern, rows_dev, flags, frm, to, threads):
+    """The rank's WHOLE batch: GPU results vs the product's tables walked on the host.  Chunked so that the host
+    copy of the rows stays bounded."""
+    import numpy as np
+    lib = host_walker()
+    if lib is None:
+        return {"rows": 0, "mismatches": None, "checker": "host table walker (tests/support/libhostwalk.so missing)"}
+    vp = ctypes.c_void_p
+    n, L = rows_dev.shape
+    pat = pattern.encode()
+    bad = 0
+    first_bad = None
+    t0 = time.perf_counter()
+    step = max(1, (1 << 30) // max(L, 1))
+    for c0 in range(0, n, step):
+        c1 = min(n, c0 + step)
+        rows = np.ascontiguousarray(rows_dev[c0:c1].cpu().numpy())
+        m = c1 - c0
+        f = np.zeros(m, np.uint8)
+        a = np.zeros(m, np.int32)
+        b = np.zeros(m, np.int32)
+        st = lib.hw_batch_mt(pat, len(pat), 0, rows.ctypes.data_as(vp), m, L, f.ctypes.data_as(vp), a.ctypes.data_as(vp), b.ctypes.data_as(vp), threads)
+        if st != 0:
+            return {"rows": 0, "mismatches": None, "checker": "host table walker: compile status %d" % st}
+        d = f != flags[c0:c1].cpu().numpy()
+        if frm is not None:
+            d |= (a != frm[c0:c1].cpu().numpy()) | (b != to[c0:c1].cpu().numpy())
+        k = int(d.sum())
+        if k and first_bad is None:
+            first_bad = int(c0 + np.flatnonzero(d)[0])
+        bad += k
+    return {"rows": int(n), "mismatches": bad, "first_mismatch_row": first_bad, "fields": "flag, from, to" if frm is not None else "flag",
+            "checker": "product tables walked on the host (tests/support/libhostwalk.so, %d threads), whole batch of rank 0" % threads,
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
+def cpu_baseline(cfg, pattern, row_len, gpu_results, budget_s=15.0):
+    """Reference CPU path on a bounded sample of the SAME workload rows (rank 0, N=1 only); its outputs double as a checker of the
+    GPU results on that sample."""
     import numpy as np
     import torch
     from forgex_amd import synth
@@ -39,35 +116,37 @@ def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     use_ref = os.path.exists(ref) and os.access(ref, os.X_OK)
 
-    def run(nrows):
+    def run(nrows, want_out=False):
         rows = synth.batch(cfg, 0, nrows, torch.device("cpu")).numpy()
         if use_ref:
             with tempfile.NamedTemporaryFile(suffix=".rows", delete=False) as f:
                 f.write(rows.tobytes())
                 path = f.name
+            opath = path + ".out" if want_out else "-"
             try:
-                line = "B R %s %d %d %s - %d\n" % (pattern.encode().hex().upper(), row_len, nrows, path, threads)
+                line = "B R %s %d %d %s %s %d\n" % (pattern.encode().hex().upper(), row_len, nrows, path, opath, threads)
                 out = subprocess.run([ref], input=line.encode(), capture_output=True, timeout=600).stdout.decode().split()
+                res = np.loadtxt(opath, dtype=np.int64).reshape(-1, 3) if want_out else None
             finally:
                 os.unlink(path)
+                if want_out and os.path.exists(opath):
+                    os.unlink(opath)
             if len(out) < 2 or out[0] != "B":
                 raise RuntimeError("ref_driver: " + " ".join(out))
-            return float(out[1])
+            return float(out[1]), res
         sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
         import oracle_lib
         t0 = time.perf_counter()
-        oracle_lib.batch(2, pattern.encode(), rows, threads)
-        return time.perf_counter() - t0
+        f, a, b = oracle_lib.batch(2, pattern.encode(), rows, threads)
+        return time.perf_counter() - t0, np.stack([f.astype(np.int64), a.astype(np.int64), b.astype(np.int64)], axis=1)
 
     def table_walker():
         """Second, stronger CPU baseline: the product's own compiled tables walked on ONE host core by the
         test harness (tests/support/libhostwalk.so: one compile per batch, linear-time passes) -- reported, never a fallback."""
-        path = os.path.join(ROOT, "tests", "support", "libhostwalk.so")
-        if not os.path.exists(path):
+        lib = host_walker()
+        if lib is None:
             return None
-        lib = ctypes.CDLL(path)
-        vp, i64 = ctypes.c_void_p, ctypes.c_int64
-        lib.hw_batch.argtypes = [ctypes.c_char_p, i64, ctypes.c_int, vp, i64, i64, vp, vp, vp]
+        vp = ctypes.c_void_p
         nrows = 200000
         rows = np.ascontiguousarray(synth.batch(cfg, 0, nrows, torch.device("cpu")).numpy())
         f = np.zeros(nrows, np.uint8)
@@ -75,7 +154,7 @@ def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
         b = np.zeros(nrows, np.int32)
         pat = pattern.encode()
         t0 = time.perf_counter()
-        st = lib.hw_batch(pat, len(pat), 0, rows.ctypes.data_as(vp), nrows, row_len, f.ctypes.data_as(vp), a.ctypes.data_as(vp), b.ctypes.data_as(vp))
+        st = lib.hw_batch_mt(pat, len(pat), 0, rows.ctypes.data_as(vp), nrows, row_len, f.ctypes.data_as(vp), a.ctypes.data_as(vp), b.ctypes.data_as(vp), 1)
         dt = time.perf_counter() - t0
         if st != 0:
             return None
@@ -88,18 +167,74 @@ def cpu_baseline(cfg, pattern, row_len, budget_s=15.0):
         walker = {"value": None, "sample": "failed: %r" % (e,)}
     try:
         probe = 4 * threads
-        t = run(probe)
+        t, _ = run(probe)
         per_row = max(t / probe, 1e-9)
         sample = int(min(max(probe, budget_s / per_row), 200000))
         sample = max(threads, (sample // threads) * threads)
-        t = run(sample)
+        t, res = run(sample, want_out=True)
+        check = None
+        if res is not None and gpu_results is not None:
+            gf, ga, gb = gpu_results
+            k = min(sample, gf.shape[0])
+            bad = int(((res[:k, 0] != gf[:k]) | (res[:k, 1] != ga[:k]) | (res[:k, 2] != gb[:k])).sum())
+            check = {"rows": k, "mismatches": bad, "checker": "the real reference (oracle/_ref/ref_driver)" if use_ref else "oracle/liboracle.so"}
         return {"value": sample * row_len / t / 1e9, "unit": "GB/s", "cores": threads,
                 "kind": "reference" if use_ref else "port",
                 "sample": "first %d rows of %s (%d B each), %.1f s wall, per-row compile as the elemental operator does" % (
                     sample, cfg, row_len, t),
-                "us_per_row": t / sample * 1e6 * 1.0, "table_walker": walker}
+                "us_per_row": t / sample * 1e6 * 1.0, "gpu_vs_reference_on_sample": check, "table_walker": walker}
     except Exception as e:   # the baseline is reported, never allowed to sink the bench line
         return {"value": None, "unit": "GB/s", "cores": threads, "kind": "reference" if use_ref else "port", "sample": "failed: %r" % (e,)}
+
+
+def host_path_rate(fx, prog, cfg, row_len, nrows=1 << 20):
+    """PCIe-inclusive rate of the host-buffer entry the Fortran module uses (fxamd_match_batch_host: pageable caller memory in,
+    results out), on a bounded slice of the workload.  Reported next to `value`, never as `value`."""
+    import numpy as np
+    import torch
+    from forgex_amd import synth
+    rows = np.ascontiguousarray(synth.batch(cfg, 0, nrows, torch.device("cpu")).numpy())
+    prog.match_host(rows, spans=True)   # first call allocates the handle's chunk slots
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        res = prog.match_host(rows, spans=True)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": nrows * row_len / dt / 1e9, "unit": "GB/s of input, PCIe-inclusive (H2D rows + kernels + D2H results)",
+            "rows": nrows, "ms_per_call": dt * 1e3, "matches": int(res[0].sum())}
+
+
+def dryrun(args, rank, world):
+    """FXAMD_BENCH_DRYRUN=1: the N-rank plumbing on CPU (gloo): rendezvous, shard bounds, packed gather, max-over-ranks reduction and
+    the one JSON line -- no GPU, no match calls, no throughput claim."""
+    import torch
+    import torch.distributed as dist
+    from forgex_amd import dist as fxdist
+    from forgex_amd import synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = args.config
+    _, row_len = synth.SHAPES[cfg]
+    rows_per_gpu = args.rows or 4096
+    start = rank * rows_per_gpu
+    idx = torch.arange(start, start + rows_per_gpu)
+    flags = (idx % 3 == 0).to(torch.uint8)
+    frm = ((idx % row_len) + 1).to(torch.int32) * flags
+    to = torch.full_like(frm, row_len) * flags
+    tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    res = fxdist.gather_results(flags, frm, to, rows_per_gpu * world, row_len)
+    ok = None
+    if rank == 0:
+        all_idx = torch.arange(0, rows_per_gpu * world)
+        ef = (all_idx % 3 == 0).to(torch.uint8)
+        ok = bool(torch.equal(res[0], ef) and torch.equal(res[1], ((all_idx % row_len) + 1).to(torch.int32) * ef))
+        print(json.dumps({"metric": "input GB/s scanned (.in. over 10M strings)", "value": None, "unit": "GB/s", "n_gpus": world, "dryrun": True,
+                          "ranks_joined": int(tt.item()), "gather_ok": ok, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "dry run of the %d-rank plumbing on CPU (gloo); no GPU work" % world, "parallelism": "shard%d" % world,
+                                     "rows_per_gpu": rows_per_gpu}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -107,12 +242,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30,
-                    help="untimed steps first; the clocks settle over the first ~20 back-to-back launches after an idle gap (DESIGN.md 4.1)")
+                    help="untimed steps first; the clocks settle over the first ~20-30 back-to-back launches after an idle gap (DESIGN.md 4.1)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's size; cfg5: 12.5M)")
     ap.add_argument("--flags-only", action="store_true", help="time the flags-only `.in.` entry instead of flags+spans")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the whole-batch host check (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline leg (profiling runs)")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(env_world or "1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if DRYRUN:
+        sys.exit(dryrun(args, rank, world))
 
     import torch
     import torch.distributed as dist
@@ -120,17 +271,12 @@ def main():
     from forgex_amd import synth
     from forgex_amd import dist as fxdist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    use_dist = world > 1 or os.environ.get("FXAMD_BENCH_FORCE_DIST") == "1"   # (world 1 + FORCE: the RCCL calls on a 1-GPU box)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the match path has no CPU fallback"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = args.config
     n_cfg, row_len = synth.SHAPES[cfg]
@@ -151,59 +297,62 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
-    # clock settling: after an idle gap the first ~20 back-to-back launches run at drifting clocks (0.53 -> 0.67 -> 0.50 ms per
-    # launch on config 3); when fewer than SETTLE warm-up steps were asked for, the difference is run first, untimed,
-    # and reported as config.clock_settle_steps
-    settle = max(0, SETTLE - args.warmup)
-    for _ in range(settle):
-        step()
+    def timed(k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---- the contract's region: exactly W untimed steps, then exactly K timed ones, max over ranks ------------------------------
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = timed(args.steps)
     n_matches = int((flags != 0).sum().item())
+    total_bytes = world * rows_per_gpu * row_len * args.steps
+    # ---- the same again at settled clocks (SETTLE more back-to-back launches first) ------------------------------------------------
+    for _ in range(SETTLE):
+        step()
+    dt_settled = timed(args.steps)
 
-    # ---- roofline leg: the dominant kernel alone, HIP events on its launch stream --------------------------
+    # ---- roofline leg: the dominant kernel alone, HIP events on its launch stream --------------------------------------------------
     L = forgex_amd.lib()
     stream = torch.cuda.current_stream(dev)
     reps = max(5, min(args.steps, 200))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    kernel_ms = None
     fast = prog.last_path() in (1, 3, 5, 6, 7, 8)
-    whole_step = cfg == "cfg4"   # non-ASCII rows: the work is in the SECOND pass (on-device UTF-8 decode + scan) -> time the whole step
-    if fast:   # the CPU-side work since the timed region left the GPU idle: settle the clocks again, as the warm-up steps did
-        for _ in range(max(args.warmup, SETTLE)):
-            step()
-    if fast and whole_step:
+    whole_step = cfg == "cfg4"   # non-ASCII rows: several passes share the work -> time the whole step
+
+    def kernel_events(k):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         for a, b in evs:
             a.record(stream)
+            if whole_step:
+                step()
+            else:
+                rc = L.fxamd_launch_fast_only(prog._h, rows.data_ptr(), rows_per_gpu, row_len, flags.data_ptr(),
+                                              frm.data_ptr() if spans else None, to.data_ptr() if spans else None, stream.cuda_stream)
+                assert rc == 0, rc
+            b.record(stream)
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / k
+
+    kernel_ms = cold_ms = None
+    if fast:
+        time.sleep(0.5)   # an idle gap, then the first launches: the cold figure
+        cold_ms = kernel_events(min(reps, 20))
+        for _ in range(SETTLE):
             step()
-            b.record(stream)
-        torch.cuda.synchronize()
-        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
-    elif fast:
-        for a, b in evs:
-            a.record(stream)
-            rc = L.fxamd_launch_fast_only(prog._h, rows.data_ptr(), rows_per_gpu, row_len, flags.data_ptr(),
-                                          frm.data_ptr() if spans else None, to.data_ptr() if spans else None, stream.cuda_stream)
-            assert rc == 0, rc
-            b.record(stream)
-        torch.cuda.synchronize()
-        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / reps
-        step()   # restore complete results (fix-up pass) before the gather below
+        kernel_ms = kernel_events(reps)
+        step()   # restore complete results (later passes) before the checks below
         torch.cuda.synchronize()
     out_bytes = 9 if spans else 1
     alg_bytes = rows_per_gpu * (row_len + out_bytes)
@@ -216,54 +365,64 @@ def main():
             traffic = None
     kname = "fx_search_fast<%d>" % (row_len // 16)
     if whole_step:
-        kname += " first pass + second pass (UTF-8 decode in LDS + scan)"
+        kname += ", all passes of one step"
+
+    def gbs(ms):
+        return (alg_bytes / (ms * 1e-3) / 1e9) if ms else None
     roofline = {"bound": "hbm", "kernel": kname if fast else "fx_general",
-                "achieved": (alg_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms else None,
-                "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
+                "achieved": gbs(kernel_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (gbs(kernel_ms) / HBM_PEAK_GBS) if kernel_ms else None,
+                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)" if traffic else None,
+                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "cold_kernel_ms": cold_ms, "cold_frac": (gbs(cold_ms) / HBM_PEAK_GBS) if cold_ms else None,
+                "cold_note": "first %d launches after a 0.5 s idle gap" % min(reps, 20)}
 
-    # ---- the pure `.in.` verdict (flags only, no spans) on the same rows: an extra, separately timed leg ---------------------------
-    flags_only = None
-    if spans:
+    flags_only = copy_gbs = host_path = None
+    if not args.no_extras:
+        # ---- the pure `.in.` verdict (flags only, no spans) on the same rows: an extra, separately timed leg ---------------------------
+        if spans:
+            try:
+                out_f = (flags, None, None)
+                for _ in range(SETTLE):
+                    prog.match_device(rows, spans=False, out=out_f)
+                torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                for _ in range(args.steps):
+                    prog.match_device(rows, spans=False, out=out_f)
+                torch.cuda.synchronize()
+                fdt = time.perf_counter() - f0
+                flags_only = {"value": world * rows_per_gpu * row_len * args.steps / fdt / 1e9, "unit": "GB/s (this rank's time, all ranks' bytes)",
+                              "ms_per_step": fdt / args.steps * 1e3}
+                step()   # restore flags + spans for the checks below
+                torch.cuda.synchronize()
+            except Exception:
+                flags_only = None
+        # ---- measured device-copy ceiling in the same run: rows -> scratch, read + write bytes per second ----
         try:
-            out_f = (flags, None, None)
-            for _ in range(max(SETTLE, args.warmup)):
-                prog.match_device(rows, spans=False, out=out_f)
-            barrier()
-            f0 = time.perf_counter()
-            for _ in range(args.steps):
-                prog.match_device(rows, spans=False, out=out_f)
+            scratch = torch.empty_like(rows)
+            for _ in range(SETTLE):
+                scratch.copy_(rows)
+            ncopy = max(5, min(args.steps, 50))
+            ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ca.record(stream)
+            for _ in range(ncopy):
+                scratch.copy_(rows)
+            cb.record(stream)
             torch.cuda.synchronize()
-            fdt = time.perf_counter() - f0
-            flags_only = {"value": world * rows_per_gpu * row_len * args.steps / fdt / 1e9, "unit": "GB/s (this rank's time, all ranks' bytes)",
-                          "ms_per_step": fdt / args.steps * 1e3}
-            step()   # restore flags + spans for the checks below
-            torch.cuda.synchronize()
+            copy_gbs = 2.0 * rows.numel() * ncopy / (ca.elapsed_time(cb) * 1e-3) / 1e9
+            del scratch
         except Exception:
-            flags_only = None
-
-    # ---- measured device-copy ceiling in the same run: rows -> scratch, read + write bytes per second ----
-    copy_gbs = None
-    try:
-        scratch = torch.empty_like(rows)
-        for _ in range(max(SETTLE, args.warmup)):
-            scratch.copy_(rows)
-        ncopy = max(5, min(args.steps, 50))
-        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ca.record(stream)
-        for _ in range(ncopy):
-            scratch.copy_(rows)
-        cb.record(stream)
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * rows.numel() * ncopy / (ca.elapsed_time(cb) * 1e-3) / 1e9
-        del scratch
-    except Exception:
-        copy_gbs = None
+            copy_gbs = None
+        if rank == 0:
+            try:
+                host_path = host_path_rate(forgex_amd, forgex_amd.Program(pattern, forgex_amd.OP_SEARCH), cfg, row_len)
+            except Exception as e:
+                host_path = {"value": None, "error": repr(e)}
     roofline["device_copy_gbs"] = copy_gbs   # bytes read + bytes written per second of a plain device-to-device copy of the batch
 
     # ---- packed result gather over RCCL (not part of `value`) ---------------------------------------------------
     gather_ms = None
-    if world > 1:
+    if use_dist:
         f2 = flags
         a2 = frm if spans else torch.zeros(rows_per_gpu, dtype=torch.int32, device=dev)
         b2 = to if spans else torch.zeros(rows_per_gpu, dtype=torch.int32, device=dev)
@@ -275,9 +434,10 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
             assert res[0].shape[0] == rows_per_gpu * world
+            # the gathered shard of rank 0 is what rank 0 computed
+            assert torch.equal(res[0][:rows_per_gpu], flags) and (not spans or torch.equal(res[1][:rows_per_gpu], frm))
 
     if rank == 0:
-        total_bytes = world * rows_per_gpu * row_len * args.steps
         line = {
             "metric": "input GB/s scanned (.in. over 10M strings)", "value": total_bytes / dt / 1e9, "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -285,18 +445,32 @@ def main():
             "config": {"workload": "%s: `%s` .in. (flags%s) over %d x %d B rows per GPU, counter-based PRNG rows resident in HBM" % (
                 cfg, pattern, " + (from,to) spans" if spans else " only", rows_per_gpu, row_len),
                 "rows_per_gpu": rows_per_gpu, "row_len": row_len, "pattern": pattern, "parallelism": "shard%d" % world,
-                "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches,
-                "clock_settle_steps": settle},
+                "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches},
             "frac_of_hbm_peak": total_bytes / dt / 1e9 / (HBM_PEAK_GBS * world),
             "frac_of_one_eighth_gpu": total_bytes / dt / 1e9 / (HBM_PEAK_GBS / 8 * world),
-            "roofline": roofline, "gather_ms": gather_ms, "flags_only": flags_only,
+            "settled": {"value": total_bytes / dt_settled / 1e9, "ms_per_step": dt_settled / args.steps * 1e3,
+                        "note": "the same %d timed steps after %d more untimed launches (clock transient over)" % (args.steps, SETTLE)},
+            "roofline": roofline, "gather_ms": gather_ms, "flags_only": flags_only, "host_path": host_path,
         }
+        threads = os.cpu_count() or 1
+        if not args.no_parity:
+            try:
+                line["parity"] = full_parity(pattern, rows, flags, frm, to, threads)
+            except Exception as e:
+                line["parity"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
+        else:
+            line["parity"] = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, pattern, row_len)
+            gpu_res = None
+            if spans:
+                k = min(rows_per_gpu, 200000)
+                gpu_res = (flags[:k].cpu().numpy().astype("int64"), frm[:k].cpu().numpy().astype("int64"), to[:k].cpu().numpy().astype("int64"))
+            line["cpu_baseline"] = cpu_baseline(cfg, pattern, row_len, gpu_res)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

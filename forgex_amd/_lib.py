@@ -65,7 +65,7 @@ def lib():
     L.fxamd_program_upload.restype = c.c_int
     L.fxamd_match_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp]
     L.fxamd_match_batch_device.restype = c.c_int
-    L.fxamd_program_reserve.argtypes = [vp, i64]
+    L.fxamd_program_reserve.argtypes = [vp, i64, vp]
     L.fxamd_program_reserve.restype = c.c_int
     L.fxamd_match_multi_device.argtypes = [vp, c.c_int32, vp, i64, i64, vp, vp, vp, vp]
     L.fxamd_match_multi_device.restype = c.c_int
@@ -86,5 +86,6 @@ def lib():
 EXPORTED_SYMBOLS = [
     "fxamd_compile", "fxamd_compile_nfa", "fxamd_program_free", "fxamd_program_status", "fxamd_program_blob_size",
     "fxamd_program_blob", "fxamd_program_from_blob", "fxamd_program_info", "fxamd_strerror", "fxamd_program_upload", "fxamd_program_reserve",
-    "fxamd_match_batch_device", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_launch_fast_only", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
+    "fxamd_match_batch_device", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
 ]
+BENCH_SYMBOLS = ["fxamd_launch_fast_only"]   # include/forgex_amd_bench.h: measurement hooks, not part of the boundary

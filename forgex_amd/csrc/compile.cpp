@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstddef>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -393,11 +394,28 @@ struct Blob {
    }
 };
 
+}   // namespace
+
+// FNV-1a over the whole image with the checksum field read as zero
+uint32_t blob_checksum(const uint8_t* b, size_t n) {
+   const size_t c0 = offsetof(FxpHeader, checksum);
+   uint32_t x = 2166136261u;
+   for (size_t i = 0; i < n; ++i) {
+      const uint8_t v = (i >= c0 && i < c0 + 4) ? 0 : b[i];
+      x = (x ^ v) * 16777619u;
+   }
+   return x;
+}
+
+namespace {
 Program finish(FxpHeader h, Blob& bl) {
    while (bl.b.size() % 16) bl.b.push_back(0);
    h.magic = FXP_MAGIC;
    h.version = FXP_VERSION;
    h.total_bytes = static_cast<uint32_t>(bl.b.size());
+   h.checksum = 0;
+   std::memcpy(bl.b.data(), &h, sizeof(h));
+   h.checksum = blob_checksum(bl.b.data(), bl.b.size());
    std::memcpy(bl.b.data(), &h, sizeof(h));
    Program p;
    p.status = static_cast<int>(h.status);
@@ -1403,7 +1421,126 @@ Program make_search_literal(const std::string& all) {
    return finish(h, bl);
 }
 
-Program compile(const std::string& pattern, int op, const Limits& lim) {
+// Wire-format check of a program image that did not come from this compiler (fxamd_program_from_blob): every table must lie
+// inside the image with the extent its header fields imply, and every entry a kernel uses as an index (state ids, row
+// offsets, class ids, page ids) must stay inside its table -- a handle that passes can be run without reading outside the
+// uploaded image.  Returns 0 when the image is sound.
+int validate_blob(const uint8_t* b, size_t size) {
+   if (size < sizeof(FxpHeader) || (size & 15u) != 0) return 1;
+   FxpHeader h;
+   std::memcpy(&h, b, sizeof(h));
+   if (h.magic != FXP_MAGIC || h.version != FXP_VERSION || h.total_bytes != size) return 2;
+   if (h.checksum != blob_checksum(b, size)) return 3;
+   if (h.mode > FXP_MODE_MATCH_ENGINE) return 4;
+   if (h.mode == FXP_MODE_INVALID) return 0;
+   auto inside = [&](uint32_t off, uint64_t bytes) { return off >= sizeof(FxpHeader) && (uint64_t)off + bytes <= size; };
+   auto u16 = [&](uint32_t off, uint64_t i) { uint16_t v; std::memcpy(&v, b + off + 2 * i, 2); return v; };
+   const uint32_t known = FXP_F_INIT_ACCEPTING | FXP_F_PREFILTER | FXP_F_HAS_SUFFIX | FXP_F_FAST_OK | FXP_F_HAS_R | FXP_F_MATCH_LITERAL |
+                          FXP_F_FAST_UTF8 | FXP_F_NFA_SIM | FXP_F_CHAIN_OK | FXP_F_CHAIN_UTF8 | FXP_F_RAW_BYTES | FXP_F_RAGGED_OK | FXP_F_BYTE_DFA |
+                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK;
+   if (h.flags & ~known) return 5;
+   // chain-format table: rows of (ncls + 3) uint16, entries = row offsets of the same table; the 256-entry map holds 2 * column
+   auto chain_ok = [&](uint32_t off_cls, uint32_t off_T, uint32_t T_bytes, uint32_t ncls, uint32_t row_bytes, bool final_col) {
+      if (row_bytes != (ncls + 3u) * 2u || T_bytes == 0 || T_bytes % row_bytes != 0 || T_bytes > 65534u) return false;
+      if (!inside(off_cls, 512) || !inside(off_T, T_bytes)) return false;
+      for (uint32_t i = 0; i < 256; ++i)
+         if (u16(off_cls, i) > 2u * (ncls + 1u) || (u16(off_cls, i) & 1u)) return false;
+      const uint32_t ncols = ncls + 3u;
+      for (uint32_t i = 0; i < T_bytes / 2u; ++i) {
+         if (final_col && i % ncols == ncols - 1u) continue;   // FINAL column: a verdict, not an offset
+         const uint16_t v = u16(off_T, i);
+         if (v >= T_bytes || v % row_bytes != 0) return false;
+      }
+      return true;
+   };
+   auto state_ok = [&](uint32_t v, uint32_t T_bytes, uint32_t row_bytes) { return v < T_bytes && v % row_bytes == 0; };
+   if (h.mode == FXP_MODE_SEARCH_LITERAL) {
+      if (!inside(h.off_all, h.len_all)) return 10;
+      if ((h.flags & FXP_F_FAST_OK) && (!inside(h.off_fastA, 2048) || !inside(h.off_fastR, 2048))) return 11;
+      if (h.flags & FXP_F_CHAIN_OK) {
+         if (!chain_ok(h.off_chain_cls, h.off_chain_TR, h.chain_TR_bytes, h.n_classes, h.chain_row_bytes, false)) return 12;
+         if (!chain_ok(h.off_chain_cls, h.off_chain_TA, h.chain_TA_bytes, h.n_classes, h.chain_row_bytes, false)) return 13;
+         if (!state_ok(h.chain_R_start, h.chain_TR_bytes, h.chain_row_bytes) || !state_ok(h.chain_A_init, h.chain_TA_bytes, h.chain_row_bytes)) return 14;
+      }
+      if (h.flags & (FXP_F_BYTE_DFA | FXP_F_W16_OK | FXP_F_BYTE_W16 | FXP_F_NFA_SIM | FXP_F_FAST_UTF8 | FXP_F_CHAIN_UTF8 | FXP_F_OVERLAP_SINK)) return 15;
+      return 0;
+   }
+   // ---- engine modes: class map ----
+   const uint32_t nc = h.n_classes;
+   if (nc == 0 || nc > 0x7FFFu || h.n_bounds == 0 || h.n_bounds > (1u << 22) || h.n_pages == 0 || h.n_pages > 1024u) return 20;
+   if (h.cls_nul >= nc || h.cls_ffff >= nc) return 21;
+   if (!inside(h.off_bounds, 4ull * h.n_bounds) || !inside(h.off_bound_cls, 2ull * h.n_bounds) || !inside(h.off_ascii_cls, 256) ||
+       !inside(h.off_cls_page, 2048) || !inside(h.off_cls_pages, 128ull * h.n_pages))
+      return 22;
+   {
+      int32_t prev = -1;
+      for (uint32_t i = 0; i < h.n_bounds; ++i) {
+         int32_t v;
+         std::memcpy(&v, b + h.off_bounds + 4ull * i, 4);
+         if ((i == 0 && v != 0) || v <= prev) return 23;
+         prev = v;
+         if (u16(h.off_bound_cls, i) >= nc) return 23;
+      }
+      for (uint32_t i = 0; i < 128; ++i)
+         if (u16(h.off_ascii_cls, i) >= nc) return 24;
+      for (uint32_t i = 0; i < 1024; ++i)
+         if (u16(h.off_cls_page, i) >= h.n_pages) return 25;
+      for (uint64_t i = 0; i < 64ull * h.n_pages; ++i)
+         if (u16(h.off_cls_pages, i) >= nc) return 26;
+   }
+   if (!inside(h.off_prefix, h.len_prefix) || !inside(h.off_suffix, h.len_suffix) || !inside(h.off_all, h.len_all)) return 27;
+   if (h.flags & FXP_F_NFA_SIM) {
+      const uint64_t N = h.nfa_N, w = h.nfa_words;
+      if (w == 0 || N == 0 || N + 1 > 32 * w || h.nfa_entry < 1 || h.nfa_entry > N || h.nfa_exit < 1 || h.nfa_exit > N) return 30;
+      if (!inside(h.off_nfa_init, 4 * w) || !inside(h.off_nfa_f0, 4 * w) || !inside(h.off_nfa_rstart, 4 * w)) return 31;
+      const uint64_t tb = (uint64_t)nc * (N + 1) * w * 4;
+      if (!inside(h.off_nfa_fwd, tb) || !inside(h.off_nfa_rev, tb)) return 32;
+      if (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK | FXP_F_BYTE_DFA | FXP_F_BYTE_W16)) return 33;
+      return 0;
+   }
+   // ---- dense tables of the general engine ----
+   const uint32_t nA = h.nA, nR = h.nR;
+   if (nA < 2 || nA > 0x7FFFu || nR > 0x7FFFu || h.A_init >= nA || h.M_start >= nA) return 40;
+   if (!inside(h.off_TA, 2ull * nA * nc) || !inside(h.off_accA, nA) || !inside(h.off_finalM, nA)) return 41;
+   for (uint64_t i = 0; i < (uint64_t)nA * nc; ++i)
+      if ((u16(h.off_TA, i) & FXP_STATE_MASK) >= nA) return 42;
+   if (h.flags & FXP_F_HAS_R) {
+      if (nR < 1 || h.R_start >= nR || !inside(h.off_TR, 2ull * nR * nc) || !inside(h.off_hitR, nR)) return 43;
+      for (uint64_t i = 0; i < (uint64_t)nR * nc; ++i)
+         if ((u16(h.off_TR, i) & FXP_STATE_MASK) >= nR) return 44;
+      if ((h.flags & FXP_F_OVERLAP_SINK) && h.R_inv >= nR) return 45;
+   } else if (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK | FXP_F_BYTE_DFA | FXP_F_OVERLAP_SINK)) {
+      if (h.mode != FXP_MODE_MATCH_ENGINE) return 46;   // the tile kernels' search needs R
+   }
+   if ((h.flags & FXP_F_FAST_OK) && (!inside(h.off_fastA, 2048) || !inside(h.off_fastR, 2048))) return 50;
+   if ((h.flags & FXP_F_FAST_UTF8) && (!(h.flags & FXP_F_FAST_OK) || nc > 126)) return 51;
+   if (h.flags & FXP_F_CHAIN_OK) {
+      if (nc > 126) return 52;
+      if (!chain_ok(h.off_chain_cls, h.off_chain_TA, h.chain_TA_bytes, nc, h.chain_row_bytes, true)) return 53;
+      if (!state_ok(h.chain_A_init, h.chain_TA_bytes, h.chain_row_bytes)) return 54;
+      if (h.mode != FXP_MODE_MATCH_ENGINE) {
+         if (!chain_ok(h.off_chain_cls, h.off_chain_TR, h.chain_TR_bytes, nc, h.chain_row_bytes, true)) return 55;
+         if (!state_ok(h.chain_R_start, h.chain_TR_bytes, h.chain_row_bytes)) return 56;
+      } else if (h.chain_TR_bytes != 0 && !inside(h.off_chain_TR, h.chain_TR_bytes)) return 57;
+   } else if (h.flags & FXP_F_CHAIN_UTF8) return 58;
+   if (h.flags & FXP_F_W16_OK) {
+      if (!inside(h.off_w16A, 4096) || !inside(h.off_w16R, 4096)) return 60;
+   } else if (h.flags & FXP_F_W16_UTF8) return 61;
+   if (h.flags & FXP_F_BYTE_DFA) {
+      const uint32_t bc = h.byte_n_classes;
+      if (bc == 0 || bc > 256u) return 62;
+      if (!chain_ok(h.off_byte_cls, h.off_byte_TA, h.byte_TA_bytes, bc, h.byte_row_bytes, true)) return 63;
+      if (!state_ok(h.byte_A_init, h.byte_TA_bytes, h.byte_row_bytes)) return 64;
+      if (h.mode != FXP_MODE_MATCH_ENGINE) {
+         if (!chain_ok(h.off_byte_cls, h.off_byte_TR, h.byte_TR_bytes, bc, h.byte_row_bytes, true)) return 65;
+         if (!state_ok(h.byte_R_start, h.byte_TR_bytes, h.byte_row_bytes)) return 66;
+      } else if (h.byte_TR_bytes != 0 && !inside(h.off_byte_TR, h.byte_TR_bytes)) return 67;
+      if ((h.flags & FXP_F_BYTE_W16) && (!inside(h.off_bw16A, 4096) || !inside(h.off_bw16R, 4096))) return 68;
+   } else if (h.flags & FXP_F_BYTE_W16) return 69;
+   return 0;
+}
+
+std::string pattern_text(const std::string& pattern, int op) {
    std::string buff;
    if (op == OP_SEARCH) {
       buff = f_trim(pattern);   // forgex.F90:95,260
@@ -1420,6 +1557,11 @@ Program compile(const std::string& pattern, int op, const Limits& lim) {
          buff = buff.substr(0, std::min(static_cast<size_t>(n), buff.size()));
       }
    }
+   return buff;
+}
+
+Program compile(const std::string& pattern, int op, const Limits& lim) {
+   const std::string buff = pattern_text(pattern, op);
    Tree tree;
    tree.build(buff);
    if (!tree.is_valid) return invalid_program(tree.code);

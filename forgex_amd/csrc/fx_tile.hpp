@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/forgex_amd.h"
+#include "../../include/forgex_amd_bench.h"
 #include "compile.hpp"
 #include "program.h"
 #include "row_engine.hpp"
@@ -421,6 +421,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
       clear_next[0] = 0u;
       clear_next[1] = 0u;
+      clear_next[2] = 0u;
+      clear_next[3] = 0u;
    }
    using F = typename FxF<SCH>::type;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
@@ -896,6 +898,8 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    if (!MARKED && !LIST && blockIdx.x == 0 && threadIdx.x == 0) {
       clear_next[0] = 0u;
       clear_next[1] = 0u;
+      clear_next[2] = 0u;
+      clear_next[3] = 0u;
    }
    using F = typename FxF<SCH>::type;
    __shared__ uint2 permA[SCH == 0 ? 256 : 1];
@@ -1089,11 +1093,11 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
 }
 
 // MODE: 0 first pass, 1 decode second pass, 2 byte-level tables over all tiles, 3 byte-level tables over marked tiles
-// n_deferred: this call's two words ([0] tiles deferred, [1] exception rows left); the other call parity's pair is 8 bytes away
+// n_deferred: this call's group of four words ([0] tiles deferred, [1] exception rows left, [2], [3] spare); the other call parity's group is 16 bytes away
 template <int CH, int MODE, int SCH>
 hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from,
                               int32_t* to, uint32_t* n_deferred, uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
-   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);   // the other parity's pair (16-byte aligned block)
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 16u);   // the other parity's group of four words (32-byte aligned block)
    const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;   // (worklist pass: the host only knows an upper bound)
    int64_t blocks = (n_tiles + 3) / 4;
    const int64_t cap = MODE == 4 ? 256 : 256 * 8;   // grid-stride beyond this (guide §6 G11)
@@ -1154,7 +1158,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
 template <int CH, int MODE, int SCH>
 hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* n_deferred,
                                uint32_t class_map_bytes, uint32_t chain_bytes, uint32_t Lr, hipStream_t st, uint32_t* worklist, int64_t grid_tiles) {
-   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 8u);
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 16u);
    const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    if (blocks > (MODE == 4 ? 256 : 256 * 8)) blocks = MODE == 4 ? 256 : 256 * 8;

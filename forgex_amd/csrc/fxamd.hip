@@ -192,20 +192,56 @@ __global__ void fx_fill(uint8_t* flags, int32_t* from, int32_t* to, int64_t n) {
 // =========================================================================================================
 // C ABI
 // =========================================================================================================
-struct fxamd_program {
-   fxc::Program prog;
-   std::mutex mu;
+// Device-side state of a handle.  The uploaded image is kept per device; the per-call scratch (counter words, worklist, NFA
+// bitsets) is kept per (device, stream): calls on one handle that use DIFFERENT streams -- from one host thread or several --
+// own different scratch and may overlap on the device; calls on the same stream are ordered by the stream.  Enqueueing itself is
+// serialised by the handle's mutex.
+struct DevBlob {
    int device = -1;
    uint8_t* d_blob = nullptr;
-   uint32_t* d_counter = nullptr;   // two words used by alternate calls: set by a first fast pass that deferred a (non-ASCII) tile; each
-                                    // first pass zeroes the other word for the call after it
-   uint32_t parity = 0;             // which word the next call uses
-   uint32_t* d_worklist = nullptr;  // row indices a byte-level pass left to the decode pass (structurally invalid UTF-8); grown on demand
+};
+struct DevScratch {
+   int device = -1;
+   hipStream_t stream = nullptr;
+   uint32_t* d_counter = nullptr;   // two groups of four words used by alternate calls: [0] a first pass deferred tiles, [1] rows in the
+                                    // worklist; each first pass zeroes the other group for the call after it
+   uint32_t parity = 0;             // which group the next call uses
+   uint32_t* d_worklist = nullptr;  // row indices the tile kernels left to a later pass; grown on demand
    int64_t worklist_rows = 0;
    uint32_t* d_nfa_scratch = nullptr;   // bitset scratch of the NFA-simulation kernel (FXP_F_NFA_SIM programs)
    size_t nfa_scratch_rows = 0;
+   uint64_t last_use = 0;
+};
+// host-buffer entry (fxamd_match_batch_host): two chunk slots per device, each with its own stream, device buffers and pinned result
+// staging, so that the H2D copy of one chunk overlaps the kernels and the D2H copy of the other
+struct HostSlot {
+   hipStream_t stream = nullptr;
+   hipEvent_t done = nullptr;
+   uint8_t* d_rows = nullptr;
+   uint8_t* d_flags = nullptr;
+   int32_t *d_from = nullptr, *d_to = nullptr;
+   uint8_t* h_flags = nullptr;   // pinned
+   int32_t *h_from = nullptr, *h_to = nullptr;
+   size_t row_bytes = 0;
+   int64_t rows_cap = 0;
+   bool spans = false;
+   int64_t pending_row0 = -1, pending_n = 0;   // results in flight: user rows [row0, row0 + n)
+};
+struct HostPipe {
+   int device = -1;
+   HostSlot slot[2];
+};
+struct fxamd_program {
+   fxc::Program prog;
+   std::mutex mu;        // guards everything below and serialises enqueueing on this handle
+   std::mutex host_mu;   // one fxamd_match_batch_host call at a time per handle (it owns the chunk slots)
+   std::vector<DevBlob> blobs;
+   std::vector<DevScratch> scratch;
+   std::vector<HostPipe> pipes;
+   uint64_t use_clock = 0;
    int last_path = 0;
 };
+static constexpr size_t FX_MAX_SCRATCH_SETS = 16;
 
 static thread_local int g_last_hip_error = 0;
 static int hip_fail(hipError_t e) {
@@ -217,6 +253,72 @@ static int hip_fail(hipError_t e) {
       hipError_t _e = (call);                         \
       if (_e != hipSuccess) return hip_fail(_e);      \
    } while (0)
+
+// (callers hold p->mu)
+static int blob_for_device(fxamd_program* p, int dev, uint8_t** out) {
+   for (DevBlob& b : p->blobs)
+      if (b.device == dev) {
+         *out = b.d_blob;
+         return FXAMD_OK;
+      }
+   DevBlob nb;
+   nb.device = dev;
+   FX_HIP(hipMalloc((void**)&nb.d_blob, p->prog.blob.size()));
+   const hipError_t e = hipMemcpy(nb.d_blob, p->prog.blob.data(), p->prog.blob.size(), hipMemcpyHostToDevice);
+   if (e != hipSuccess) {
+      (void)hipFree(nb.d_blob);
+      return hip_fail(e);
+   }
+   p->blobs.push_back(nb);
+   *out = nb.d_blob;
+   return FXAMD_OK;
+}
+static void free_scratch(DevScratch& s) {
+   if (s.d_counter) (void)hipFree(s.d_counter);
+   if (s.d_worklist) (void)hipFree(s.d_worklist);
+   if (s.d_nfa_scratch) (void)hipFree(s.d_nfa_scratch);
+   s = DevScratch();
+}
+static int scratch_for(fxamd_program* p, int dev, hipStream_t st, DevScratch** out) {
+   DevScratch* found = nullptr;
+   size_t on_dev = 0;
+   for (DevScratch& s : p->scratch) {
+      if (s.device != dev) continue;
+      ++on_dev;
+      if (s.stream == st) found = &s;
+   }
+   if (!found) {
+      if (on_dev >= FX_MAX_SCRATCH_SETS) {
+         // a caller that keeps coming with new streams: recycle the least recently used set of this device once the device is idle
+         FX_HIP(hipDeviceSynchronize());
+         for (DevScratch& s : p->scratch)
+            if (s.device == dev && (!found || s.last_use < found->last_use)) found = &s;
+         found->stream = st;
+      } else {
+         p->scratch.emplace_back();
+         found = &p->scratch.back();
+         found->device = dev;
+         found->stream = st;
+      }
+   }
+   if (!found->d_counter) {
+      FX_HIP(hipMalloc((void**)&found->d_counter, 32));
+      FX_HIP(hipMemset(found->d_counter, 0, 32));
+   }
+   found->last_use = ++p->use_clock;
+   *out = found;
+   return FXAMD_OK;
+}
+static int grow_worklist(DevScratch* s, int64_t rows) {
+   if (s->worklist_rows >= rows) return FXAMD_OK;
+   // (the old list may still be read by kernels of an earlier call on this stream: hipFree waits for the device)
+   if (s->d_worklist) (void)hipFree(s->d_worklist);
+   s->d_worklist = nullptr;
+   s->worklist_rows = 0;
+   FX_HIP(hipMalloc((void**)&s->d_worklist, (size_t)rows * 4));
+   s->worklist_rows = rows;
+   return FXAMD_OK;
+}
 
 // chunk count the tile kernels are instantiated for that covers row_len (0 = none)
 static int tile_chunks(int64_t row_len) {
@@ -352,6 +454,142 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
    return (h.flags & (sch == 0 ? FXP_F_FAST_UTF8 : (sch == 2 ? FXP_F_W16_UTF8 : FXP_F_CHAIN_UTF8))) != 0;
 }
 
+// ---- the pipeline of one batch call, enqueued on `st` with the scratch set `sc` (p->mu held) ----------------------------------
+static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                         uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
+   const FxpHeader& h = p->prog.hdr();
+   const unsigned gblocks = (unsigned)((n + 255) / 256);
+   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
+   if (h.flags & FXP_F_NFA_SIM) {
+      // bounded scratch: rows are processed in chunks that share one scratch area (allocated on first use)
+      const size_t per_row = (size_t)2 * h.nfa_words * 4;
+      size_t chunk = (size_t(256) << 20) / per_row;
+      if (chunk > 65536) chunk = 65536;
+      if (chunk < 64) chunk = 64;
+      chunk &= ~size_t(63);
+      if (sc->nfa_scratch_rows < chunk) {
+         if (sc->d_nfa_scratch) (void)hipFree(sc->d_nfa_scratch);
+         sc->d_nfa_scratch = nullptr;
+         sc->nfa_scratch_rows = 0;
+         FX_HIP(hipMalloc((void**)&sc->d_nfa_scratch, chunk * per_row));
+         sc->nfa_scratch_rows = chunk;
+      }
+      for (int64_t b0 = 0; b0 < n; b0 += (int64_t)chunk) {
+         const int64_t cnt = n - b0 < (int64_t)chunk ? n - b0 : (int64_t)chunk;
+         hipLaunchKernelGGL(fx_nfa, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, d_rows, b0, b0 + cnt, (int32_t)row_len, d_blob, d_flags,
+                            d_from, d_to, sc->d_nfa_scratch);
+         FX_HIP(hipGetLastError());
+      }
+      p->last_path = 4;
+      return FXAMD_OK;
+   }
+   const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
+   if (h.mode == FXP_MODE_MATCH_ENGINE) {   // `.match.` has no span: from/to stay untouched
+      d_from = nullptr;
+      d_to = nullptr;
+   }
+   const int scheme = fast_scheme(h, d_rows, row_len);
+   if (scheme >= 0) {
+      const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
+      sc->parity ^= 1u;
+      uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
+      // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
+      const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
+      const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
+      const int bsch = bytes_scheme(h);
+      const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
+      PassOpts first, marked, listp;
+      first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
+      // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
+      // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
+      if (bytes || !utf8_tables) {
+         const int rc = grow_worklist(sc, n);
+         if (rc != FXAMD_OK) return rc;
+         first.worklist = marked.worklist = listp.worklist = sc->d_worklist;
+         listp.gate_word = 1;
+         listp.grid_tiles = (n + 63) >> 6;
+      }
+      // exception rows of a byte-level pass: the decode pass over the gathered worklist when the class-level tables can decode,
+      // else the row-level fix-up through the general engine
+      auto list_fixup = [&]() -> int {   // the general engine over the worklist
+         if (aligned16 && (size_t)64 * row_len + prog_lds <= 65536u) {
+            int64_t tb = (n + 63) / 64;
+            if (tb > 16384) tb = 16384;
+            hipLaunchKernelGGL(fx_fixup_list_tiled, dim3((unsigned)tb), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, (int32_t)row_len, d_blob,
+                               d_flags, d_from, d_to, sc->d_worklist, ctr + 1, prog_lds);
+         } else {
+            int64_t lblocks = (n + 255) / 256;
+            if (lblocks > 4096) lblocks = 4096;
+            hipLaunchKernelGGL(fx_fixup_list, dim3((unsigned)lblocks), dim3(256), prog_lds, st, d_rows, (int32_t)row_len, d_blob, d_flags, d_from, d_to,
+                               sc->d_worklist, ctr + 1, prog_lds);
+         }
+         FX_HIP(hipGetLastError());
+         return FXAMD_OK;
+      };
+      auto exceptions = [&]() -> int {
+         if (!utf8_tables) return list_fixup();
+         if (is_match) FX_HIP(match_by<4>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, listp));
+         else FX_HIP(fast_by<4>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp));
+         return FXAMD_OK;
+      };
+      if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
+         FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+         p->last_path = 1 + big;
+         return FXAMD_OK;
+      }
+      if (bytes && scheme != 0) {
+         // no 8-state class-level tables to be faster with on ASCII: the byte-level tables take every tile, UTF-8 or not, in one pass
+         if (is_match) FX_HIP(match_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
+         else FX_HIP(fast_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+         p->last_path = 7;
+         return exceptions();
+      }
+      // first pass with the class-level tables: pure-ASCII tiles are finished here
+      if (is_match) FX_HIP(match_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
+      else FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+      if (bytes) {
+         // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
+         if (is_match) FX_HIP(match_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
+         else FX_HIP(fast_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
+         p->last_path = 8;
+         return exceptions();
+      }
+      if (utf8_tables) {
+         // deferred tiles: the decode pass rewrites UTF-8 to symbol ids in LDS and scans only those tiles
+         if (is_match) FX_HIP(match_by<1>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
+         else FX_HIP(fast_by<1>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
+         p->last_path = 1 + big;
+         return FXAMD_OK;
+      }
+      // rows holding bytes >= 0x80 (and overlap rows) were listed one by one: row-level fix-up over that list
+      p->last_path = 3 + big - (big ? 1 : 0);
+      return list_fixup();
+   }
+   if (aligned16 && (size_t)64 * row_len + prog_lds <= 65536u) {   // (64 KB: the dynamic LDS a launch gets without opting in to more)
+      const unsigned tblocks = (unsigned)((n + 63) / 64);
+      hipLaunchKernelGGL(fx_general_tiled, dim3(tblocks), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, n, (int32_t)row_len, d_blob,
+                         d_flags, d_from, d_to, prog_lds);
+   } else {
+      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, d_blob, d_flags, d_from, d_to, 0, prog_lds);
+   }
+   FX_HIP(hipGetLastError());
+   p->last_path = 2;
+   return FXAMD_OK;
+}
+
+static void free_slot(HostSlot& s) {
+   if (s.stream) (void)hipStreamDestroy(s.stream);
+   if (s.done) (void)hipEventDestroy(s.done);
+   if (s.d_rows) (void)hipFree(s.d_rows);
+   if (s.d_flags) (void)hipFree(s.d_flags);
+   if (s.d_from) (void)hipFree(s.d_from);
+   if (s.d_to) (void)hipFree(s.d_to);
+   if (s.h_flags) (void)hipHostFree(s.h_flags);
+   if (s.h_from) (void)hipHostFree(s.h_from);
+   if (s.h_to) (void)hipHostFree(s.h_to);
+   s = HostSlot();
+}
+
 extern "C" {
 
 int fxamd_last_hip_error(void) { return g_last_hip_error; }
@@ -363,13 +601,16 @@ int fxamd_device_count(void) {
 
 int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status) {
    if (!out || pattern_len < 0 || (!pattern && pattern_len > 0) || (op != FXAMD_OP_SEARCH && op != FXAMD_OP_MATCH)) return FXAMD_E_ARG;
-   fxamd_program* p = new (std::nothrow) fxamd_program();
-   if (!p) return FXAMD_E_NOMEM;
-   try {
+   fxamd_program* p = nullptr;
+   try {   // nothing may cross the C boundary: the library never aborts the process
+      p = new fxamd_program();
       p->prog = fxc::compile(std::string(pattern ? pattern : "", (size_t)pattern_len), op);
    } catch (const std::bad_alloc&) {
       delete p;
       return FXAMD_E_NOMEM;
+   } catch (...) {
+      delete p;
+      return FXAMD_E_ARG;
    }
    if (status) *status = p->prog.status;
    *out = p;
@@ -383,29 +624,44 @@ int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64
    if (!out || n_states < 2 || entry < 1 || entry > n_states || exit_state < 1 || exit_state > n_states || n_transitions < 0) return FXAMD_E_ARG;
    if (n_transitions > 0 && (!src || !dst || !seg_begin || !seg_min || !seg_max)) return FXAMD_E_ARG;
    if (op != FXAMD_OP_SEARCH && op != FXAMD_OP_MATCH) return FXAMD_E_ARG;
-   fxfe::Nfa nfa;
-   nfa.nfa_top = n_states;
-   nfa.entry = entry;
-   nfa.exit = exit_state;
-   nfa.nodes.resize((size_t)n_states + 1);
-   for (int64_t t = 0; t < n_transitions; ++t) {
-      if (src[t] < 1 || src[t] > n_states || dst[t] < 1 || dst[t] > n_states || seg_begin[t + 1] < seg_begin[t]) return FXAMD_E_ARG;
-      fxfe::NfaTransition tr;
-      tr.dst = dst[t];
-      for (int64_t k = seg_begin[t]; k < seg_begin[t + 1]; ++k) tr.c.emplace_back(seg_min[k], seg_max[k]);
-      tr.c_top = (int)tr.c.size();
-      nfa.nodes[(size_t)src[t]].forward.push_back(tr);
+   if (len_all < 0 || len_prefix < 0 || len_suffix < 0) return FXAMD_E_ARG;
+   if (n_transitions > 0 && seg_begin[0] < 0) return FXAMD_E_ARG;
+   fxamd_program* p = nullptr;
+   try {
+      fxfe::Nfa nfa;
+      nfa.nfa_top = n_states;
+      nfa.entry = entry;
+      nfa.exit = exit_state;
+      nfa.nodes.resize((size_t)n_states + 1);
+      for (int64_t t = 0; t < n_transitions; ++t) {
+         if (src[t] < 1 || src[t] > n_states || dst[t] < 1 || dst[t] > n_states || seg_begin[t + 1] < seg_begin[t]) return FXAMD_E_ARG;
+         fxfe::NfaTransition tr;
+         tr.dst = dst[t];
+         for (int64_t k = seg_begin[t]; k < seg_begin[t + 1]; ++k) {
+            // a segment is a code-point range min <= max, or one of the reference's markers with min == max (SEG_EPSILON (-1,-1),
+            // the unused SEG_INIT slots above the code space)
+            if (seg_min[k] > seg_max[k]) return FXAMD_E_ARG;
+            tr.c.emplace_back(seg_min[k], seg_max[k]);
+         }
+         tr.c_top = (int)tr.c.size();
+         nfa.nodes[(size_t)src[t]].forward.push_back(tr);
+      }
+      fxfe::Literals lit;
+      lit.all.assign(lit_all ? lit_all : "", (size_t)(lit_all ? len_all : 0));
+      lit.prefix.assign(lit_prefix ? lit_prefix : "", (size_t)(lit_prefix ? len_prefix : 0));
+      lit.suffix.assign(lit_suffix ? lit_suffix : "", (size_t)(lit_suffix ? len_suffix : 0));
+      p = new fxamd_program();
+      if (op == FXAMD_OP_SEARCH && !fxfe::f_eq(lit.all, ""))
+         p->prog = fxc::make_search_literal(lit.all);   // whole-pattern literal: raw-byte INDEX path (forgex.F90:111-130)
+      else
+         p->prog = fxc::compile_from_nfa(nfa, lit, op);
+   } catch (const std::bad_alloc&) {
+      delete p;
+      return FXAMD_E_NOMEM;
+   } catch (...) {
+      delete p;
+      return FXAMD_E_ARG;
    }
-   fxfe::Literals lit;
-   lit.all.assign(lit_all ? lit_all : "", (size_t)(lit_all ? len_all : 0));
-   lit.prefix.assign(lit_prefix ? lit_prefix : "", (size_t)(lit_prefix ? len_prefix : 0));
-   lit.suffix.assign(lit_suffix ? lit_suffix : "", (size_t)(lit_suffix ? len_suffix : 0));
-   fxamd_program* p = new (std::nothrow) fxamd_program();
-   if (!p) return FXAMD_E_NOMEM;
-   if (op == FXAMD_OP_SEARCH && !fxfe::f_eq(lit.all, ""))
-      p->prog = fxc::make_search_literal(lit.all);   // whole-pattern literal: raw-byte INDEX path (forgex.F90:111-130)
-   else
-      p->prog = fxc::compile_from_nfa(nfa, lit, op);
    if (status) *status = p->prog.status;
    *out = p;
    return FXAMD_OK;
@@ -413,10 +669,11 @@ int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64
 
 void fxamd_program_free(fxamd_program* p) {
    if (!p) return;
-   if (p->d_blob) (void)hipFree(p->d_blob);
-   if (p->d_counter) (void)hipFree(p->d_counter);
-   if (p->d_worklist) (void)hipFree(p->d_worklist);
-   if (p->d_nfa_scratch) (void)hipFree(p->d_nfa_scratch);
+   for (DevBlob& b : p->blobs)
+      if (b.d_blob) (void)hipFree(b.d_blob);
+   for (DevScratch& s : p->scratch) free_scratch(s);
+   for (HostPipe& hp : p->pipes)
+      for (HostSlot& s : hp.slot) free_slot(s);
    delete p;
 }
 int32_t fxamd_program_status(const fxamd_program* p) { return p ? p->prog.status : FXAMD_E_ARG; }
@@ -428,17 +685,17 @@ int fxamd_program_blob(const fxamd_program* p, void* buf, int64_t capacity) {
 }
 int fxamd_program_from_blob(const void* blob, int64_t size, fxamd_program** out) {
    if (!blob || !out || size < (int64_t)sizeof(FxpHeader)) return FXAMD_E_ARG;
-   FxpHeader h;
-   std::memcpy(&h, blob, sizeof(h));
-   if (h.magic != FXP_MAGIC || h.version != FXP_VERSION || h.total_bytes != (uint64_t)size) return FXAMD_E_BLOB;
-   const uint32_t offs[] = {h.off_bounds, h.off_bound_cls, h.off_ascii_cls, h.off_TA, h.off_TR, h.off_accA, h.off_hitR,
-                            h.off_finalM, h.off_prefix, h.off_suffix, h.off_all, h.off_fastA, h.off_fastR};
-   for (uint32_t o : offs)
-      if (o > h.total_bytes) return FXAMD_E_BLOB;
-   fxamd_program* p = new (std::nothrow) fxamd_program();
-   if (!p) return FXAMD_E_NOMEM;
-   p->prog.blob.assign((const uint8_t*)blob, (const uint8_t*)blob + size);
-   p->prog.status = (int)h.status;
+   // images from outside are checked table by table (extent inside the image, index entries inside their tables) and by checksum
+   if (fxc::validate_blob((const uint8_t*)blob, (size_t)size) != 0) return FXAMD_E_BLOB;
+   fxamd_program* p = nullptr;
+   try {
+      p = new fxamd_program();
+      p->prog.blob.assign((const uint8_t*)blob, (const uint8_t*)blob + size);
+   } catch (...) {
+      delete p;
+      return FXAMD_E_NOMEM;
+   }
+   p->prog.status = (int)p->prog.hdr().status;
    *out = p;
    return FXAMD_OK;
 }
@@ -462,37 +719,29 @@ int fxamd_program_upload(fxamd_program* p) {
    std::lock_guard<std::mutex> g(p->mu);
    int dev = -1;
    FX_HIP(hipGetDevice(&dev));
-   if (p->d_blob && p->device == dev) return FXAMD_OK;
-   if (p->d_blob) {
-      (void)hipFree(p->d_blob);
-      p->d_blob = nullptr;
-   }
-   FX_HIP(hipMalloc((void**)&p->d_blob, p->prog.blob.size()));
-   if (!p->d_counter) {
-      FX_HIP(hipMalloc((void**)&p->d_counter, 16));
-      FX_HIP(hipMemset(p->d_counter, 0, 16));
-   }
-   FX_HIP(hipMemcpy(p->d_blob, p->prog.blob.data(), p->prog.blob.size(), hipMemcpyHostToDevice));
-   p->device = dev;
-   return FXAMD_OK;
+   uint8_t* d_blob = nullptr;
+   return blob_for_device(p, dev, &d_blob);
 }
 
-int fxamd_program_reserve(fxamd_program* p, int64_t max_rows) {
+int fxamd_program_reserve(fxamd_program* p, int64_t max_rows, void* hip_stream) {
    if (!p || max_rows < 0) return FXAMD_E_ARG;
-   int rc = fxamd_program_upload(p);
-   if (rc != FXAMD_OK) return rc;
    std::lock_guard<std::mutex> g(p->mu);
-   if (p->worklist_rows < max_rows) {
-      if (p->d_worklist) (void)hipFree(p->d_worklist);
-      p->d_worklist = nullptr;
-      p->worklist_rows = 0;
-      FX_HIP(hipMalloc((void**)&p->d_worklist, (size_t)max_rows * 4));
-      p->worklist_rows = max_rows;
-   }
-   return FXAMD_OK;
+   int dev = -1;
+   FX_HIP(hipGetDevice(&dev));
+   uint8_t* d_blob = nullptr;
+   int rc = blob_for_device(p, dev, &d_blob);
+   if (rc != FXAMD_OK) return rc;
+   DevScratch* sc = nullptr;
+   rc = scratch_for(p, dev, (hipStream_t)hip_stream, &sc);
+   if (rc != FXAMD_OK) return rc;
+   return grow_worklist(sc, max_rows);
 }
 
-int fxamd_last_path(const fxamd_program* p) { return p ? p->last_path : FXAMD_E_ARG; }
+int fxamd_last_path(const fxamd_program* p) {
+   if (!p) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(const_cast<fxamd_program*>(p)->mu);
+   return p->last_path;
+}
 
 int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
                            int32_t* d_to, void* hip_stream) {
@@ -501,17 +750,25 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const FxpHeader& h = p->prog.hdr();
    const int scheme = fast_scheme(h, d_rows, row_len);
    if (scheme < 0 || h.mode == FXP_MODE_MATCH_ENGINE) return FXAMD_E_ARG;
-   int rc = fxamd_program_upload(p);
+   std::lock_guard<std::mutex> g(p->mu);
+   int dev = -1;
+   FX_HIP(hipGetDevice(&dev));
+   uint8_t* d_blob = nullptr;
+   int rc = blob_for_device(p, dev, &d_blob);
    if (rc != FXAMD_OK) return rc;
-   uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);
+   DevScratch* sc = nullptr;
+   rc = scratch_for(p, dev, (hipStream_t)hip_stream, &sc);
+   if (rc != FXAMD_OK) return rc;
+   sc->parity ^= 1u;
+   uint32_t* ctr = sc->d_counter + 4u * sc->parity;
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   if (scheme != 0 && bytes && p->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
-      po.worklist = p->d_worklist;
-      FX_HIP(fast_by<2>(bytes_scheme(h), h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
+   if (scheme != 0 && bytes && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
+      po.worklist = sc->d_worklist;
+      FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
    } else {
-      FX_HIP(fast_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
+      FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
    }
    return FXAMD_OK;
 }
@@ -524,139 +781,22 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    if (n == 0) return FXAMD_OK;
    hipStream_t st = (hipStream_t)hip_stream;
    const FxpHeader& h = p->prog.hdr();
-   const unsigned gblocks = (unsigned)((n + 255) / 256);
+   std::lock_guard<std::mutex> g(p->mu);
    if (h.mode == FXP_MODE_INVALID) {
-      hipLaunchKernelGGL(fx_fill, dim3(gblocks), dim3(256), 0, st, d_flags, d_from, d_to, n);
+      hipLaunchKernelGGL(fx_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_flags, d_from, d_to, n);
       FX_HIP(hipGetLastError());
       p->last_path = 0;
       return FXAMD_OK;
    }
-   int rc = fxamd_program_upload(p);
+   int dev = -1;
+   FX_HIP(hipGetDevice(&dev));
+   uint8_t* d_blob = nullptr;
+   int rc = blob_for_device(p, dev, &d_blob);
    if (rc != FXAMD_OK) return rc;
-   const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
-   if (h.flags & FXP_F_NFA_SIM) {
-      // bounded scratch: rows are processed in chunks that share one scratch area (allocated on first use)
-      const size_t per_row = (size_t)2 * h.nfa_words * 4;
-      size_t chunk = (size_t(256) << 20) / per_row;
-      if (chunk > 65536) chunk = 65536;
-      if (chunk < 64) chunk = 64;
-      chunk &= ~size_t(63);
-      {
-         std::lock_guard<std::mutex> g(p->mu);
-         if (p->nfa_scratch_rows < chunk) {
-            if (p->d_nfa_scratch) (void)hipFree(p->d_nfa_scratch);
-            p->d_nfa_scratch = nullptr;
-            p->nfa_scratch_rows = 0;
-            FX_HIP(hipMalloc((void**)&p->d_nfa_scratch, chunk * per_row));
-            p->nfa_scratch_rows = chunk;
-         }
-      }
-      for (int64_t b0 = 0; b0 < n; b0 += (int64_t)chunk) {
-         const int64_t cnt = n - b0 < (int64_t)chunk ? n - b0 : (int64_t)chunk;
-         hipLaunchKernelGGL(fx_nfa, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, d_rows, b0, b0 + cnt, (int32_t)row_len, p->d_blob, d_flags,
-                            d_from, d_to, p->d_nfa_scratch);
-         FX_HIP(hipGetLastError());
-      }
-      p->last_path = 4;
-      return FXAMD_OK;
-   }
-   const uint32_t prog_lds = h.total_bytes <= 32768u ? h.total_bytes : 0u;   // tables in LDS when they fit comfortably
-   if (h.mode == FXP_MODE_MATCH_ENGINE) {   // `.match.` has no span: from/to stay untouched
-      d_from = nullptr;
-      d_to = nullptr;
-   }
-   const int scheme = fast_scheme(h, d_rows, row_len);
-   if (scheme >= 0) {
-      const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
-      uint32_t* ctr = p->d_counter + 2u * (p->parity ^= 1u);   // this call's words: [0] tiles deferred, [1] exception rows left
-      // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
-      const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
-      const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
-      const int bsch = bytes_scheme(h);
-      const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
-      PassOpts first, marked, listp;
-      first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
-      // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
-      // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
-      if (bytes || !utf8_tables) {
-         std::lock_guard<std::mutex> g(p->mu);
-         if (p->worklist_rows < n) {
-            if (p->d_worklist) (void)hipFree(p->d_worklist);
-            p->d_worklist = nullptr;
-            p->worklist_rows = 0;
-            FX_HIP(hipMalloc((void**)&p->d_worklist, (size_t)n * 4));
-            p->worklist_rows = n;
-         }
-         first.worklist = marked.worklist = listp.worklist = p->d_worklist;
-         listp.gate_word = 1;
-         listp.grid_tiles = (n + 63) >> 6;
-      }
-      // exception rows of a byte-level pass: the decode pass over the gathered worklist when the class-level tables can decode,
-      // else the row-level fix-up through the general engine
-      auto list_fixup = [&]() -> int {   // the general engine over the worklist
-         if (aligned16 && (size_t)64 * row_len + prog_lds <= 65536u) {
-            int64_t tb = (n + 63) / 64;
-            if (tb > 16384) tb = 16384;
-            hipLaunchKernelGGL(fx_fixup_list_tiled, dim3((unsigned)tb), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, (int32_t)row_len, p->d_blob,
-                               d_flags, d_from, d_to, p->d_worklist, ctr + 1, prog_lds);
-         } else {
-            int64_t lblocks = (n + 255) / 256;
-            if (lblocks > 4096) lblocks = 4096;
-            hipLaunchKernelGGL(fx_fixup_list, dim3((unsigned)lblocks), dim3(256), prog_lds, st, d_rows, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to,
-                               p->d_worklist, ctr + 1, prog_lds);
-         }
-         FX_HIP(hipGetLastError());
-         return FXAMD_OK;
-      };
-      auto exceptions = [&]() -> int {
-         if (!utf8_tables) return list_fixup();
-         if (is_match) FX_HIP(match_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, listp));
-         else FX_HIP(fast_by<4>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp));
-         return FXAMD_OK;
-      };
-      if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
-         FX_HIP(fast_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
-         p->last_path = 1 + big;
-         return FXAMD_OK;
-      }
-      if (bytes && scheme != 0) {
-         // no 8-state class-level tables to be faster with on ASCII: the byte-level tables take every tile, UTF-8 or not, in one pass
-         if (is_match) FX_HIP(match_by<2>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
-         else FX_HIP(fast_by<2>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
-         p->last_path = 7;
-         return exceptions();
-      }
-      // first pass with the class-level tables: pure-ASCII tiles are finished here
-      if (is_match) FX_HIP(match_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
-      else FX_HIP(fast_by<0>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
-      if (bytes) {
-         // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
-         if (is_match) FX_HIP(match_by<3>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
-         else FX_HIP(fast_by<3>(bsch, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
-         p->last_path = 8;
-         return exceptions();
-      }
-      if (utf8_tables) {
-         // deferred tiles: the decode pass rewrites UTF-8 to symbol ids in LDS and scans only those tiles
-         if (is_match) FX_HIP(match_by<1>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
-         else FX_HIP(fast_by<1>(scheme, h, p->d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
-         p->last_path = 1 + big;
-         return FXAMD_OK;
-      }
-      // rows holding bytes >= 0x80 (and overlap rows) were listed one by one: row-level fix-up over that list
-      p->last_path = 3 + big - (big ? 1 : 0);
-      return list_fixup();
-   }
-   if (aligned16 && (size_t)64 * row_len + prog_lds <= 65536u) {   // (64 KB: the dynamic LDS a launch gets without opting in to more)
-      const unsigned tblocks = (unsigned)((n + 63) / 64);
-      hipLaunchKernelGGL(fx_general_tiled, dim3(tblocks), dim3(64), (size_t)64 * row_len + prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob,
-                         d_flags, d_from, d_to, prog_lds);
-   } else {
-      hipLaunchKernelGGL(fx_general, dim3(gblocks), dim3(256), prog_lds, st, d_rows, n, (int32_t)row_len, p->d_blob, d_flags, d_from, d_to, 0, prog_lds);
-   }
-   FX_HIP(hipGetLastError());
-   p->last_path = 2;
-   return FXAMD_OK;
+   DevScratch* sc = nullptr;
+   rc = scratch_for(p, dev, st, &sc);
+   if (rc != FXAMD_OK) return rc;
+   return enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags, d_from, d_to, st);
 }
 
 // m patterns over the same device-resident rows: results pattern-major ([m][n]).  One pass of the pipeline per pattern, enqueued
@@ -673,49 +813,134 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
    return FXAMD_OK;
 }
 
+// Host-buffer entry (what the Fortran module binds): the batch is cut into chunks that flow through two slots -- H2D copy of
+// the chunk's rows, the kernels, D2H copy of its results into pinned staging, each slot on its own stream -- so the copy of
+// one chunk overlaps the kernels and the result copy of the other.  Device buffers, pinned staging and streams are kept in
+// the handle: steady-state calls allocate nothing.
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags, int32_t* h_from,
                            int32_t* h_to) {
-   if (!p || n < 0 || row_len < 0 || !h_flags || (n > 0 && row_len > 0 && !h_rows)) return FXAMD_E_ARG;
+   if (!p || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || !h_flags || (n > 0 && row_len > 0 && !h_rows)) return FXAMD_E_ARG;
    if ((h_from == nullptr) != (h_to == nullptr)) return FXAMD_E_ARG;
+   if (p->prog.status >= 100) return FXAMD_E_UNSUPPORTED;
    if (n == 0) return FXAMD_OK;
-   uint8_t *d_rows = nullptr, *d_flags = nullptr;
-   int32_t *d_from = nullptr, *d_to = nullptr;
+   const FxpHeader& h = p->prog.hdr();
+   if (h.mode == FXP_MODE_MATCH_ENGINE) {   // `.match.`: from/to stay untouched (nothing is allocated or copied for them)
+      h_from = nullptr;
+      h_to = nullptr;
+   }
+   const bool spans = h_from != nullptr;
+   std::lock_guard<std::mutex> hg(p->host_mu);
+   int dev = -1;
+   FX_HIP(hipGetDevice(&dev));
+   HostPipe* hp = nullptr;
+   {
+      std::lock_guard<std::mutex> g(p->mu);
+      for (HostPipe& q : p->pipes)
+         if (q.device == dev) hp = &q;
+      if (!hp) {
+         p->pipes.emplace_back();
+         hp = &p->pipes.back();
+         hp->device = dev;
+      }
+   }
+   // chunk size: about 64 MB of rows (a multiple of 64 rows: whole tiles), at least one row
+   const size_t rl = (size_t)(row_len > 0 ? row_len : 1);
+   int64_t chunk_rows = (int64_t)((size_t(64) << 20) / rl) & ~int64_t(63);
+   if (chunk_rows < 64) chunk_rows = 64;
+   if (chunk_rows > n) chunk_rows = n;
+   const bool reg = std::getenv("FXAMD_HOST_REGISTER") != nullptr && row_len > 0;   // pin the caller's rows in place for the call (experiment)
+   bool registered = false;
+   if (reg) registered = hipHostRegister(const_cast<uint8_t*>(h_rows), (size_t)n * rl, hipHostRegisterDefault) == hipSuccess;
    int rc = FXAMD_OK;
-   const size_t bytes = (size_t)n * (size_t)row_len;
-   auto cleanup = [&]() {
-      if (d_rows) (void)hipFree(d_rows);
-      if (d_flags) (void)hipFree(d_flags);
-      if (d_from) (void)hipFree(d_from);
-      if (d_to) (void)hipFree(d_to);
+   auto fail = [&](hipError_t e) { rc = hip_fail(e); };
+   auto prepare = [&](HostSlot& s) {
+      if (!s.stream && rc == FXAMD_OK) {
+         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+         if (e != hipSuccess) return fail(e);
+      }
+      const size_t need = (size_t)chunk_rows * rl;
+      if (s.row_bytes < need) {
+         if (s.d_rows) (void)hipFree(s.d_rows);
+         s.d_rows = nullptr;
+         s.row_bytes = 0;
+         const hipError_t e = hipMalloc((void**)&s.d_rows, need);
+         if (e != hipSuccess) return fail(e);
+         s.row_bytes = need;
+      }
+      if (s.rows_cap < chunk_rows || (spans && !s.spans)) {
+         if (s.d_flags) (void)hipFree(s.d_flags);
+         if (s.d_from) (void)hipFree(s.d_from);
+         if (s.d_to) (void)hipFree(s.d_to);
+         if (s.h_flags) (void)hipHostFree(s.h_flags);
+         if (s.h_from) (void)hipHostFree(s.h_from);
+         if (s.h_to) (void)hipHostFree(s.h_to);
+         s.d_flags = s.h_flags = nullptr;
+         s.d_from = s.d_to = s.h_from = s.h_to = nullptr;
+         s.rows_cap = 0;
+         s.spans = false;
+         const int64_t cap = chunk_rows > s.rows_cap ? chunk_rows : s.rows_cap;
+         hipError_t e = hipMalloc((void**)&s.d_flags, (size_t)cap);
+         if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_flags, (size_t)cap, hipHostMallocDefault);
+         if (e == hipSuccess && spans) e = hipMalloc((void**)&s.d_from, (size_t)cap * 4);
+         if (e == hipSuccess && spans) e = hipMalloc((void**)&s.d_to, (size_t)cap * 4);
+         if (e == hipSuccess && spans) e = hipHostMalloc((void**)&s.h_from, (size_t)cap * 4, hipHostMallocDefault);
+         if (e == hipSuccess && spans) e = hipHostMalloc((void**)&s.h_to, (size_t)cap * 4, hipHostMallocDefault);
+         if (e != hipSuccess) return fail(e);
+         s.rows_cap = cap;
+         s.spans = spans;
+      }
    };
-#define FX_HIP_C(call)                    \
-   do {                                   \
-      hipError_t _e = (call);             \
-      if (_e != hipSuccess) {             \
-         cleanup();                       \
-         return hip_fail(_e);             \
-      }                                   \
-   } while (0)
-   FX_HIP_C(hipMalloc((void**)&d_rows, bytes ? bytes : 16));
-   FX_HIP_C(hipMalloc((void**)&d_flags, (size_t)n));
-   if (h_from) {
-      FX_HIP_C(hipMalloc((void**)&d_from, (size_t)n * 4));
-      FX_HIP_C(hipMalloc((void**)&d_to, (size_t)n * 4));
+   // results of a slot's last chunk: wait for its D2H copies, then hand them to the caller's arrays
+   auto drain = [&](HostSlot& s) {
+      if (s.pending_row0 < 0) return;
+      const hipError_t e = hipEventSynchronize(s.done);
+      if (e != hipSuccess && rc == FXAMD_OK) fail(e);
+      if (rc == FXAMD_OK) {
+         std::memcpy(h_flags + s.pending_row0, s.h_flags, (size_t)s.pending_n);
+         if (spans) {
+            std::memcpy(h_from + s.pending_row0, s.h_from, (size_t)s.pending_n * 4);
+            std::memcpy(h_to + s.pending_row0, s.h_to, (size_t)s.pending_n * 4);
+         }
+      }
+      s.pending_row0 = -1;
+      s.pending_n = 0;
+   };
+   for (HostSlot& s : hp->slot) {
+      s.pending_row0 = -1;
+      prepare(s);
    }
-   if (bytes) FX_HIP_C(hipMemcpy(d_rows, h_rows, bytes, hipMemcpyHostToDevice));
-   rc = fxamd_match_batch_device(p, d_rows, n, row_len, d_flags, d_from, d_to, nullptr);
-   if (rc != FXAMD_OK) {
-      cleanup();
-      return rc;
+   int which = 0;
+   for (int64_t r0 = 0; r0 < n && rc == FXAMD_OK; r0 += chunk_rows, which ^= 1) {
+      HostSlot& s = hp->slot[which];
+      drain(s);   // the slot's buffers are free again once its previous chunk has been handed over
+      if (rc != FXAMD_OK) break;
+      const int64_t cnt = n - r0 < chunk_rows ? n - r0 : chunk_rows;
+      hipError_t e = hipSuccess;
+      if (row_len > 0) e = hipMemcpyAsync(s.d_rows, h_rows + (size_t)r0 * rl, (size_t)cnt * rl, hipMemcpyHostToDevice, s.stream);
+      if (e != hipSuccess) {
+         fail(e);
+         break;
+      }
+      rc = fxamd_match_batch_device(p, s.d_rows, cnt, row_len, s.d_flags, spans ? s.d_from : nullptr, spans ? s.d_to : nullptr, s.stream);
+      if (rc != FXAMD_OK) break;
+      e = hipMemcpyAsync(s.h_flags, s.d_flags, (size_t)cnt, hipMemcpyDeviceToHost, s.stream);
+      if (e == hipSuccess && spans) e = hipMemcpyAsync(s.h_from, s.d_from, (size_t)cnt * 4, hipMemcpyDeviceToHost, s.stream);
+      if (e == hipSuccess && spans) e = hipMemcpyAsync(s.h_to, s.d_to, (size_t)cnt * 4, hipMemcpyDeviceToHost, s.stream);
+      if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
+      if (e != hipSuccess) {
+         fail(e);
+         break;
+      }
+      s.pending_row0 = r0;
+      s.pending_n = cnt;
    }
-   FX_HIP_C(hipDeviceSynchronize());
-   FX_HIP_C(hipMemcpy(h_flags, d_flags, (size_t)n, hipMemcpyDeviceToHost));
-   if (h_from) {
-      FX_HIP_C(hipMemcpy(h_from, d_from, (size_t)n * 4, hipMemcpyDeviceToHost));
-      FX_HIP_C(hipMemcpy(h_to, d_to, (size_t)n * 4, hipMemcpyDeviceToHost));
+   for (HostSlot& s : hp->slot) {
+      if (rc != FXAMD_OK && s.stream) (void)hipStreamSynchronize(s.stream);   // nothing of a failed call stays in flight
+      drain(s);
    }
-   cleanup();
-   return FXAMD_OK;
+   if (registered) (void)hipHostUnregister(const_cast<uint8_t*>(h_rows));
+   return rc;
 }
 
 #ifdef FX_STAMP

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 11u
+#define FXP_VERSION 12u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -102,7 +102,7 @@ struct FxpHeader {
    uint32_t off_bw16A, off_bw16R;   // uint8 [256][16]
    uint32_t w16_finalM[4], bw16_finalM[4];   // `.match.`: byte j = verdict of state j after the last text byte (byte-level: 2 = redo by the decode path)
    uint32_t R_inv;        // FXP_F_OVERLAP_SINK: that state of R (a row that ends its backward pass there is left to the general engine)
-   uint32_t reserved[1];
+   uint32_t checksum;     // FNV-1a of the whole image with this field read as zero (fxc::blob_checksum); checked by fxamd_program_from_blob
 };
 
 #define FXP_STATE_MASK 0x7FFFu

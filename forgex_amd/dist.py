@@ -32,33 +32,46 @@ def unpack_results(bits, frm, to, n):
     return flags, frm.to(torch.int32), to.to(torch.int32)
 
 
+def packed_layout(n, row_len):
+    """Byte layout of one shard's packed results: [bits | pad to 16][from, narrow][pad to 16][to, narrow] -> (off_from, off_to, total)."""
+    w = torch.empty(0, dtype=span_dtype(row_len)).element_size()
+    nb = ((n + 7) // 8 + 15) & ~15
+    ns = (n * w + 15) & ~15
+    return nb, nb + ns, nb + 2 * ns
+
+
 def gather_results(flags, frm, to, n_total, row_len, dst=0):
-    """Every rank passes its shard's results; rank `dst` returns (flags, from, to) for all n_total rows, others None."""
+    """Every rank passes its shard's results; rank `dst` returns (flags, from, to) for all n_total rows, others None.
+    ONE collective: each shard travels as a single uint8 image (bits + narrowed spans) -- byte tensors are the one dtype every
+    backend moves (RCCL has no 16-bit integer type)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     bits, f8, t8 = pack_results(flags, frm, to, row_len)
-    out = None
-    pieces = []
-    for tns, per_row in ((bits, False), (f8, True), (t8, True)):
-        sizes = []
-        for r in range(world):
-            a, b = shard_bounds(n_total, r, world)
-            sizes.append((b - a + 7) // 8 if not per_row else b - a)
-        mx = max(sizes)
-        buf = tns.new_zeros(mx)
-        buf[:tns.shape[0]] = tns
-        if rank == dst:
-            lst = [tns.new_zeros(mx) for _ in range(world)]
-            dist.gather(buf, lst, dst=dst)
-            pieces.append([lst[r][:sizes[r]] for r in range(world)])
-        else:
-            dist.gather(buf, None, dst=dst)
-    if rank == dst:
-        fl, fr, tt = [], [], []
-        for r in range(world):
-            a, b = shard_bounds(n_total, r, world)
-            f, x, y = unpack_results(pieces[0][r], pieces[1][r], pieces[2][r], b - a)
-            fl.append(f)
-            fr.append(x)
-            tt.append(y)
-        out = (torch.cat(fl), torch.cat(fr), torch.cat(tt))
-    return out
+    sizes = []
+    for r in range(world):
+        a, b = shard_bounds(n_total, r, world)
+        sizes.append(b - a)
+    mx = max(packed_layout(m, row_len)[2] for m in sizes)
+    n = flags.shape[0]
+    off_f, off_t, _ = packed_layout(n, row_len)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=flags.device)
+    buf[:bits.numel()] = bits
+    fb, tb = f8.view(torch.uint8), t8.view(torch.uint8)
+    buf[off_f:off_f + fb.numel()] = fb
+    buf[off_t:off_t + tb.numel()] = tb
+    if rank != dst:
+        dist.gather(buf, None, dst=dst)
+        return None
+    lst = [torch.empty(mx, dtype=torch.uint8, device=flags.device) for _ in range(world)]
+    dist.gather(buf, lst, dst=dst)
+    dt = span_dtype(row_len)
+    w = torch.empty(0, dtype=dt).element_size()
+    fl, fr, tt = [], [], []
+    for r in range(world):
+        m = sizes[r]
+        o_f, o_t, _ = packed_layout(m, row_len)
+        img = lst[r]
+        f, x, y = unpack_results(img[:(m + 7) // 8], img[o_f:o_f + m * w].view(dt), img[o_t:o_t + m * w].view(dt), m)
+        fl.append(f)
+        fr.append(x)
+        tt.append(y)
+    return torch.cat(fl), torch.cat(fr), torch.cat(tt)

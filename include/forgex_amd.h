@@ -18,7 +18,8 @@
  *
  * Rows are the storage of a Fortran `character(row_len) :: s(n)`: n*row_len contiguous bytes, no terminators.
  * All functions return 0 on success or a negative FXAMD_E_* code; they never abort the process.
- * A program handle may be used from several host threads; distinct handles are independent.
+ * A program handle may be used from several host threads: enqueueing is serialised per handle, the per-call device scratch is
+ * kept per (device, stream), so calls that use different streams may overlap on the device; distinct handles are independent.
  * There is NO CPU matching path: every match call needs a HIP device and fails with FXAMD_E_HIP otherwise.
  */
 #ifndef FORGEX_AMD_H
@@ -70,18 +71,19 @@ const char* fxamd_strerror(int32_t status);
 /* Upload the tables to the current HIP device (idempotent; done lazily by the match calls otherwise). */
 int fxamd_program_upload(fxamd_program* p);
 
-/* Upload the tables and allocate the handle's device scratch for batches of up to max_rows rows now (4 bytes per row), so that
- * later fxamd_match_batch_device calls only enqueue kernels (stream capture, latency-sensitive callers).  Optional: the match
- * calls do both lazily. */
-int fxamd_program_reserve(fxamd_program* p, int64_t max_rows);
+/* Upload the tables to the current device and allocate the scratch of (current device, hip_stream) for batches of up to max_rows
+ * rows now (4 bytes per row), so that later fxamd_match_batch_device calls on that stream only enqueue kernels (stream capture,
+ * latency-sensitive callers).  Optional: the match calls do both lazily. */
+int fxamd_program_reserve(fxamd_program* p, int64_t max_rows, void* hip_stream);
 
 /* Device-resident batch: d_rows, d_flags (n bytes: 0/1), d_from, d_to (n int32 each, may both be NULL) are
  * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
  * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
  * `.match.`: flags = verdict, from/to untouched.  Invalid pattern: all flags 0, from/to 0.
  * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2 bytes .. 64 KiB when
- * d_rows is 16-byte aligned, other shapes run on the general kernel (one lane per row, roughly 20x slower).  Calls on ONE handle must not overlap in time (per-handle device scratch);
- * distinct handles are independent. */
+ * d_rows is 16-byte aligned, other shapes run on the general kernel (one lane per row, roughly 20x slower).  The handle keeps its
+ * uploaded tables per device and its scratch per (device, stream): the call works on whatever device is current, and calls on
+ * one handle may overlap on the device when they use different streams. */
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream);
 
@@ -91,14 +93,11 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
 int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8_t* d_rows, int64_t n, int64_t row_len,
                              uint8_t* d_flags, int32_t* d_from, int32_t* d_to, void* hip_stream);
 
-/* Host-buffer convenience used by the Fortran module: H2D copy, match, D2H copy, synchronous. */
+/* Host-buffer entry used by the Fortran module; synchronous.  The batch flows through two chunk slots (about 64 MB of rows each,
+ * own stream, device buffers and pinned result staging kept in the handle): the H2D copy of one chunk overlaps the kernels and
+ * the D2H copy of the other.  `.match.` programs leave h_from / h_to untouched.  One call at a time per handle (further callers wait). */
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
                            int32_t* h_from, int32_t* h_to);
-
-/* Measurement hook (bench.py roofline leg only): enqueue ONLY the dominant fast kernel, without the fix-up pass, so
- * its launch duration can be bracketed with HIP events.  FXAMD_E_ARG when the fast path does not apply. */
-int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
-                           int32_t* d_from, int32_t* d_to, void* hip_stream);
 
 /* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ second fast pass with
  * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up (over a worklist) of non-ASCII rows and of rows where two occurrences of a bordered prefix literal overlap,

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../forgex_amd/csrc/compile.hpp"
@@ -98,6 +99,84 @@ int hw_batch(const char* pat, int64_t plen, int op, const uint8_t* rows, int64_t
    }
    return 0;
 }
+// the same on `nthreads` host threads (full-batch parity checks of the GPU results: bench.py, tests/test_gpu_parity.py)
+int hw_batch_mt(const char* pat, int64_t plen, int op, const uint8_t* rows, int64_t n, int64_t L, uint8_t* flags, int32_t* from,
+                int32_t* to, int nthreads) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
+   if (p.status != 0) return p.status;
+   if (nthreads < 1) nthreads = 1;
+   auto work = [&](int64_t lo, int64_t hi) {
+      fxrow::ProgView pv(p.blob.data());
+      for (int64_t i = lo; i < hi; ++i) {
+         HostRow r{rows + i * L};
+         fxrow::Result res;
+         run_any(pv, p, r, static_cast<int>(L), res);
+         flags[i] = static_cast<uint8_t>(res.flag);
+         if (from) from[i] = res.from;
+         if (to) to[i] = res.to;
+      }
+   };
+   std::vector<std::thread> th;
+   for (int t = 0; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
+   for (auto& t : th) t.join();
+   return 0;
+}
+// wire-format check of the program this compiler emits for a pattern (0 = sound), and of an arbitrary image
+int hw_validate(const char* pat, int64_t plen, int op) {
+   fxc::Program p = fxc::compile(std::string(pat, static_cast<size_t>(plen)), op);
+   return fxc::validate_blob(p.blob.data(), p.blob.size());
+}
+int hw_validate_blob(const uint8_t* blob, int64_t size) { return fxc::validate_blob(blob, static_cast<size_t>(size)); }
+uint32_t hw_blob_checksum(const uint8_t* blob, int64_t size) { return fxc::blob_checksum(blob, static_cast<size_t>(size)); }
+
+// The range-NFA and the literals the front end builds for a pattern, flattened the way INTEGRATION.md section B describes for
+// the reference's nfa_graph_t -- the input of fxamd_compile_nfa.  Two calls: with cap == 0 the counts are returned in
+// counts[0..5] = n_states, entry, exit, n_transitions, n_segments, status; with cap >= counts the arrays are filled.
+int hw_dump_nfa(const char* pat, int64_t plen, int op, int64_t* counts, int64_t cap_tr, int64_t cap_seg, int32_t* src, int32_t* dst,
+                int64_t* seg_begin, int32_t* seg_min, int32_t* seg_max, char* lits, int64_t lit_cap, int64_t* lit_len) {
+   const std::string buff = fxc::pattern_text(std::string(pat, static_cast<size_t>(plen)), op);
+   fxfe::Tree tree;
+   tree.build(buff);
+   counts[5] = tree.is_valid ? 0 : tree.code;
+   if (!tree.is_valid) return 1;
+   fxfe::Literals lit = fxfe::extract_literal(tree);
+   fxfe::Nfa nfa = fxfe::build_nfa(tree, 8192);
+   counts[5] = nfa.status;
+   if (nfa.status != 0) return 1;
+   int64_t nt = 0, ns = 0;
+   for (int i = 1; i <= nfa.nfa_top; ++i)
+      for (const fxfe::NfaTransition& tr : nfa.nodes[static_cast<size_t>(i)].forward) {
+         if (tr.dst == fxfe::NFA_NULL_TRANSITION) continue;
+         if (nt < cap_tr) {
+            src[nt] = i;
+            dst[nt] = tr.dst;
+            seg_begin[nt] = ns;
+         }
+         for (const fxfe::Seg& sg : tr.c) {
+            if (ns < cap_seg) {
+               seg_min[ns] = sg.min;
+               seg_max[ns] = sg.max;
+            }
+            ++ns;
+         }
+         ++nt;
+      }
+   if (nt <= cap_tr && cap_tr > 0) seg_begin[nt] = ns;
+   counts[0] = nfa.nfa_top;
+   counts[1] = nfa.entry;
+   counts[2] = nfa.exit;
+   counts[3] = nt;
+   counts[4] = ns;
+   const std::string* ls[3] = {&lit.all, &lit.prefix, &lit.suffix};
+   int64_t used = 0;
+   for (int k = 0; k < 3; ++k) {
+      lit_len[k] = static_cast<int64_t>(ls[k]->size());
+      if (used + lit_len[k] <= lit_cap) std::memcpy(lits + used, ls[k]->data(), ls[k]->size());
+      used += lit_len[k];
+   }
+   return 0;
+}
+
 // symbol-id image of ONE row (length L, multiple of 16) as fx_translate produces it; `expect` gets the same image derived
 // from the strict forward parse (fwd_symbol).  Returns 0, or status / -1 when the program has no UTF-8 fast tables.
 int hw_translate(const char* pat, int64_t plen, const uint8_t* row, int64_t L, uint8_t* got, uint8_t* expect) {

@@ -13,16 +13,19 @@ sys.path.insert(0, %r)
 from forgex_amd import dist as fxdist, synth
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-n_total, L = 1003, 128
+n_total = 1003
 a, b = fxdist.shard_bounds(n_total, rank, world)
-g = torch.Generator().manual_seed(5)
-flags_all = (torch.rand(n_total, generator=g) < 0.5).to(torch.uint8)
-from_all = (torch.randint(1, L, (n_total,), generator=g) * flags_all).to(torch.int32)
-to_all = (torch.randint(1, L + 1, (n_total,), generator=g) * flags_all).to(torch.int32)
-res = fxdist.gather_results(flags_all[a:b], from_all[a:b], to_all[a:b], n_total, L, dst=0)
-if rank == 0:
-    f, x, y = res
-    assert torch.equal(f, flags_all) and torch.equal(x, from_all) and torch.equal(y, to_all)
+for L in (128, 256, 70000):   # spans narrowed to 1, 2 and 4 bytes (config 5, config 3, long rows)
+    g = torch.Generator().manual_seed(5)
+    flags_all = (torch.rand(n_total, generator=g) < 0.5).to(torch.uint8)
+    from_all = (torch.randint(1, L, (n_total,), generator=g) * flags_all).to(torch.int32)
+    to_all = (torch.randint(1, L + 1, (n_total,), generator=g) * flags_all).to(torch.int32)
+    res = fxdist.gather_results(flags_all[a:b], from_all[a:b], to_all[a:b], n_total, L, dst=0)
+    if rank == 0:
+        f, x, y = res
+        assert torch.equal(f, flags_all) and torch.equal(x, from_all) and torch.equal(y, to_all), L
+    else:
+        assert res is None
     # every shard regenerates its own rows: shard rows == the same index range of the full batch
     full = synth.batch("cfg5", 0, 64, torch.device("cpu"))
     print("OK", int(f.sum()))
@@ -68,3 +71,36 @@ def test_two_rank_gather_gloo(tmp_path):
                         "--master-port", "29731", str(script)], env=env, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert "OK" in r.stdout.decode()
+
+
+def _bench_dryrun(cmd):
+    env = dict(os.environ, FXAMD_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` as the driver may invoke it (no launcher): the parent starts two rank processes before anything
+    touches a GPU and relays rank 0's single JSON line.  CPU dry run (gloo) of exactly that plumbing."""
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "1001"])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True
+    assert line["config"]["parallelism"] == "shard2"
+
+
+def test_bench_under_torch_distributed_run():
+    """The documented launcher form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2."""
+    line = _bench_dryrun([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29741", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, FXAMD_BENCH_DRYRUN="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], env=env, capture_output=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr

@@ -112,14 +112,187 @@ def test_config_rows_tables_vs_oracle(built):
 
 
 def test_c_abi_exports_every_declared_symbol(built):
+    """Both headers: the drop-in boundary (forgex_amd.h) and the measurement hooks (forgex_amd_bench.h) -- every declared symbol is
+    exported, and nothing measurement-only is declared in the boundary header."""
     import forgex_amd
     from forgex_amd import _lib
     header = open(os.path.join(golden.ROOT, "include", "forgex_amd.h")).read()
     declared = sorted(set(re.findall(r"\b(fxamd_[a-z_]+)\s*\(", header)))
     assert declared == sorted(_lib.EXPORTED_SYMBOLS)
+    bench = open(os.path.join(golden.ROOT, "include", "forgex_amd_bench.h")).read()
+    hooks = sorted(set(re.findall(r"\b(fxamd_[a-z_]+)\s*\(", bench)))
+    assert hooks == sorted(_lib.BENCH_SYMBOLS) and not set(hooks) & set(declared)
     L = forgex_amd.lib()
-    for name in declared:
+    for name in declared + hooks:
         assert hasattr(L, name), name
+
+
+def _hostwalk():
+    lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.hw_validate.argtypes = [ctypes.c_char_p, i64, ctypes.c_int]
+    lib.hw_validate_blob.argtypes = [vp, i64]
+    lib.hw_blob_checksum.argtypes = [vp, i64]
+    lib.hw_blob_checksum.restype = ctypes.c_uint32
+    lib.hw_dump_nfa.argtypes = [ctypes.c_char_p, i64, ctypes.c_int, vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp]
+    return lib
+
+
+def _golden_patterns():
+    pats = []
+    for _, kind, f in golden.load_ref_tests():
+        if kind in ("in", "match", "regex"):
+            pats.append((golden.unhx(f[0]), 1 if kind == "match" else 0))
+    return sorted(set(pats))
+
+
+def test_every_compiled_program_passes_the_wire_format_check(built):
+    """fxc::validate_blob (what fxamd_program_from_blob applies to images from outside) accepts every program this compiler emits
+    for the patterns of the reference's own tests, both operators, and for the BASELINE patterns."""
+    from forgex_amd import synth
+    lib = _hostwalk()
+    pats = _golden_patterns() + [(p.encode(), 0) for p in synth.PATTERNS.values()] + [(p.encode(), 1) for p in synth.PATTERNS.values()]
+    pats += [(rb"[ab]*a[ab]{20}", 0), (rb"aa[bc]", 0), (rb"abc", 0), (rb"a(", 0), (rb"--[a-z]+", 0), (rb"[\w.]+@[\w.]+\.[a-z]{2,4}", 0)]
+    assert len(pats) > 300
+    for pat, op in pats:
+        assert lib.hw_validate(pat, len(pat), op) == 0, (pat, op)
+
+
+def test_corrupt_blobs_are_rejected(built):
+    """Wire format: a patched offset, count, table entry or flag -- with the checksum repaired, so that the STRUCTURAL check is what
+    has to catch it -- is refused with FXAMD_E_BLOB, as are truncation and a stale checksum."""
+    import struct
+    import forgex_amd as fx
+    from forgex_amd import synth
+    lib = _hostwalk()
+    L = fx.lib()
+
+    def load(blob):
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+        rc = L.fxamd_program_from_blob(buf, len(blob), ctypes.byref(h))
+        if rc == 0:
+            L.fxamd_program_free(h)
+        return rc
+
+    def fixed(blob):
+        b = bytearray(blob)
+        off = FIELDS["checksum"]
+        b[off:off + 4] = b"\0\0\0\0"
+        arr = (ctypes.c_char * len(b)).from_buffer(b)
+        struct.pack_into("<I", b, off, lib.hw_blob_checksum(arr, len(b)))
+        return bytes(b)
+
+    # field offsets of FxpHeader (all uint32), read from program.h so that the test follows the wire format
+    src = open(os.path.join(golden.ROOT, "forgex_amd", "csrc", "program.h")).read()
+    body = src[src.index("struct FxpHeader {"):src.index("};", src.index("struct FxpHeader {"))]
+    body = re.sub(r"//[^\n]*", "", body)
+    names = []
+    for decl in re.findall(r"uint32_t\s+([^;]+);", body):
+        for item in decl.split(","):
+            m = re.match(r"\s*(\w+)(?:\[(\d+)\])?\s*$", item)
+            names += [m.group(1)] * int(m.group(2) or 1) if m.group(2) else [m.group(1)]
+    FIELDS = {}
+    for i, nm in enumerate(names):
+        FIELDS.setdefault(nm, 4 * i)
+    n_bad = 0
+    for cfg in ("cfg2", "cfg3", "cfg4", "cfg1"):
+        good = fx.Program(synth.PATTERNS[cfg], fx.OP_SEARCH).blob()
+        assert struct.unpack_from("<I", good, FIELDS["total_bytes"])[0] == len(good)
+        assert load(good) == 0 and load(fixed(good)) == 0
+        assert load(good[:-16]) == -4                                  # truncated
+        stale = bytearray(good)
+        stale[len(stale) // 2] ^= 0x40
+        assert load(bytes(stale)) == -4                                # checksum
+        for field, value in (("off_cls_page", 0x7FFFFFF0), ("n_classes", 60000), ("off_fastA", len(good) - 8), ("nA", 0x7000), ("nR", 0x7000),
+                             ("off_TA", len(good) - 2), ("n_pages", 1000), ("off_byte_TR", len(good) - 4), ("byte_TR_bytes", 60000),
+                             ("off_bw16R", len(good) - 64), ("off_w16A", 0xFFFFFFF0), ("chain_TA_bytes", 65000), ("A_init", 0x6000),
+                             ("byte_R_start", 0xFFF0), ("mode", 9), ("flags", 0x80000000), ("cls_ffff", 0x4000), ("n_bounds", 1 << 21),
+                             ("byte_n_classes", 300), ("byte_row_bytes", 6)):
+            b = bytearray(good)
+            old = struct.unpack_from("<I", b, FIELDS[field])[0]
+            if field == "flags":
+                value |= old
+            if old == value:
+                continue
+            struct.pack_into("<I", b, FIELDS[field], value)
+            rc = load(fixed(bytes(b)))
+            flags = struct.unpack_from("<I", good, FIELDS["flags"])[0]
+            table_present = {"off_fastA": 8, "off_byte_TR": 0x1000, "byte_TR_bytes": 0x1000, "off_bw16R": 0x8000, "off_w16A": 0x2000,
+                             "chain_TA_bytes": 0x100, "byte_R_start": 0x1000, "byte_n_classes": 0x1000, "byte_row_bytes": 0x1000}.get(field)
+            if table_present is not None and not (flags & table_present):
+                continue   # the table is absent from this program: its fields are not read
+            assert rc == -4, (cfg, field, rc)
+            n_bad += 1
+        # a table ENTRY that points outside its table (byte-level chain table of R)
+        flags = struct.unpack_from("<I", good, FIELDS["flags"])[0]
+        if flags & 0x1000:
+            b = bytearray(good)
+            off = struct.unpack_from("<I", b, FIELDS["off_byte_TR"])[0]
+            struct.pack_into("<H", b, off + 2, 0xFFF0)
+            assert load(fixed(bytes(b))) == -4
+            n_bad += 1
+    assert n_bad > 40
+    # NFA-simulation program: nfa_words = 0 must not reach the launch code (it divides by the per-row scratch size)
+    good = fx.Program(r"[ab]*a[ab]{20}", fx.OP_SEARCH).blob()
+    assert load(good) == 0
+    b = bytearray(good)
+    struct.pack_into("<I", b, FIELDS["nfa_words"], 0)
+    assert load(fixed(bytes(b))) == -4
+
+
+def test_compile_nfa_equals_compile_on_the_golden_patterns(built):
+    """INTEGRATION.md route B: the range-NFA and the literals the front end builds, flattened the way a Fortran host would flatten
+    the reference's nfa_graph_t, handed to fxamd_compile_nfa -- the program must be byte-identical to fxamd_compile's."""
+    import forgex_amd as fx
+    from forgex_amd import synth
+    lib = _hostwalk()
+    L = fx.lib()
+    vp = ctypes.c_void_p
+    n_checked = 0
+    pats = _golden_patterns() + [(p.encode(), 0) for p in synth.PATTERNS.values()] + [(rb"aa[bc]", 0), (rb"abc.*xyz", 0), (rb"[ab]*a[ab]{20}", 0)]
+    for pat, op in pats:
+        counts = (ctypes.c_int64 * 6)()
+        lit_len = (ctypes.c_int64 * 3)()
+        rc = lib.hw_dump_nfa(pat, len(pat), op, counts, 0, 0, None, None, None, None, None, None, 0, lit_len)
+        if rc != 0:
+            continue   # invalid pattern: no NFA to hand over
+        nt, ns = counts[3], counts[4]
+        src, dst = np.zeros(max(nt, 1), np.int32), np.zeros(max(nt, 1), np.int32)
+        sb = np.zeros(nt + 1, np.int64)
+        smin, smax = np.zeros(max(ns, 1), np.int32), np.zeros(max(ns, 1), np.int32)
+        lits = ctypes.create_string_buffer(int(sum(lit_len)) + 1)
+        rc = lib.hw_dump_nfa(pat, len(pat), op, counts, nt, ns, src.ctypes.data_as(vp), dst.ctypes.data_as(vp), sb.ctypes.data_as(vp),
+                             smin.ctypes.data_as(vp), smax.ctypes.data_as(vp), lits, len(lits), lit_len)
+        assert rc == 0 and counts[3] == nt and counts[4] == ns
+        raw = lits.raw
+        la, lp, ls = int(lit_len[0]), int(lit_len[1]), int(lit_len[2])
+        h = ctypes.c_void_p()
+        st = ctypes.c_int32(-1)
+        rc = L.fxamd_compile_nfa(int(counts[0]), int(counts[1]), int(counts[2]), nt, src.ctypes.data_as(vp), dst.ctypes.data_as(vp),
+                                 sb.ctypes.data_as(vp), smin.ctypes.data_as(vp), smax.ctypes.data_as(vp), raw[:la], la, raw[la:la + lp], lp,
+                                 raw[la + lp:la + lp + ls], ls, op, ctypes.byref(h), ctypes.byref(st))
+        assert rc == 0, (pat, rc)
+        n = L.fxamd_program_blob_size(h)
+        buf = (ctypes.c_char * n)()
+        assert L.fxamd_program_blob(h, buf, n) == 0
+        L.fxamd_program_free(h)
+        want = fx.Program(pat, op)
+        assert st.value == want.status and bytes(buf) == want.blob(), (pat, op)
+        n_checked += 1
+    assert n_checked > 300
+    # argument checks: nothing crosses the boundary as an exception or an out-of-bounds read
+    one = np.array([1], np.int32)
+    two = np.array([2], np.int32)
+    h = ctypes.c_void_p()
+    st = ctypes.c_int32(0)
+    bad_begin = np.array([-1, 1], np.int64)
+    lo, hi = np.array([98], np.int32), np.array([97], np.int32)
+    ok_begin = np.array([0, 1], np.int64)
+    for sb_, mn, mx in ((bad_begin, lo, lo), (ok_begin, lo, hi)):
+        rc = L.fxamd_compile_nfa(2, 1, 2, 1, one.ctypes.data_as(vp), two.ctypes.data_as(vp), sb_.ctypes.data_as(vp), mn.ctypes.data_as(vp),
+                                 mx.ctypes.data_as(vp), b"", 0, b"", 0, b"", 0, 0, ctypes.byref(h), ctypes.byref(st))
+        assert rc == -1
 
 
 def test_compile_status_and_blob_roundtrip(built):
