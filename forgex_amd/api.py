@@ -121,7 +121,7 @@ class Program:
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         n, rl = rows.shape
         flags = np.zeros(n, dtype=np.uint8)
-        frm = np.zeros(n, dtype=np.int32) if spans else None
+        frm = np.zeros(n, dtype=np.int32) if spans else None   # (`.match.` programs leave them untouched: 0 / 0)
         to = np.zeros(n, dtype=np.int32) if spans else None
         vp = ctypes.c_void_p
         rc = _lib.lib().fxamd_match_batch_host(self._h, rows.ctypes.data_as(vp), n, rl, flags.ctypes.data_as(vp),

@@ -592,3 +592,154 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
     of, oa, ob = oracle_lib.batch(2, rb"aa[bc]", rows, NT)
     assert np.array_equal(f, of) and np.array_equal(a, oa) and np.array_equal(b, ob)
     assert 0 < int(of.sum()) < n
+
+
+def _hostwalk_mt():
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.hw_batch_mt.argtypes = [ctypes.c_char_p, i64, ctypes.c_int, vp, i64, i64, vp, vp, vp, ctypes.c_int]
+    return lib
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_full_size_configs_vs_host_table_walker(fx, cfg):
+    """GPU flags / from / to against the product's tables walked on the host over the FULL batch of the config
+    (config 5: one rank's shard of 12.5M rows) -- every row, not a prefix of the batch.  The walker itself is pinned to the
+    oracle and the real reference by the CPU tests."""
+    import ctypes
+    import torch
+    from forgex_amd import synth
+    lib = _hostwalk_mt()
+    vp = ctypes.c_void_p
+    dev = torch.device("cuda")
+    n, L = synth.SHAPES[cfg]
+    if cfg == "cfg5":
+        n //= 8
+    pat = synth.PATTERNS[cfg].encode()
+    prog = fx.Program(pat, fx.OP_SEARCH)
+    step = 2_500_000
+    total = matches = 0
+    for start in range(0, n, step):
+        m = min(step, n - start)
+        base = start if cfg != "cfg5" else 3 * n + start   # (shard 3 of the 8)
+        rows = synth.batch(cfg, base, m, dev)
+        f, a, b = prog.match_device(rows)
+        torch.cuda.synchronize()
+        host = np.ascontiguousarray(rows.cpu().numpy())
+        hf, ha, hb = np.zeros(m, np.uint8), np.zeros(m, np.int32), np.zeros(m, np.int32)
+        assert lib.hw_batch_mt(pat, len(pat), 0, host.ctypes.data_as(vp), m, L, hf.ctypes.data_as(vp), ha.ctypes.data_as(vp), hb.ctypes.data_as(vp), NT) == 0
+        gf, ga, gb = f.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()
+        bad = np.flatnonzero((gf != hf) | (ga != ha) | (gb != hb))
+        assert bad.size == 0, (cfg, start + int(bad[0]), int(gf[bad[0]]), int(ga[bad[0]]), int(gb[bad[0]]), int(hf[bad[0]]), int(ha[bad[0]]), int(hb[bad[0]]))
+        total += m
+        matches += int(hf.sum())
+    assert total == n and 0 < matches < n
+
+
+def test_program_from_blob_runs_on_the_device(fx):
+    """Wire format: a program shipped as a blob -- what one rank would send another -- gives the same results on the
+    device as the program it was taken from, for every table family (v_perm, wide, chain, byte-level, literal, NFA simulation)."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    cases = [("cfg3", rb"[a-z]+\d+", fx.OP_SEARCH), ("cfg4", synth.PATTERNS["cfg4"].encode(), fx.OP_SEARCH), ("cfg2", rb"foo(bar|baz)", fx.OP_SEARCH),
+             ("cfg3", rb"\d{3}-\d{4}", fx.OP_SEARCH), ("cfg3", rb"[\w.]+@[\w.]+\.[a-z]{2,4}", fx.OP_SEARCH), ("cfg2", b"foobar", fx.OP_SEARCH),
+             ("cfg1", rb"\d{3}-\d{4}", fx.OP_MATCH), ("cfg3", rb"[ab]*a[ab]{20}", fx.OP_SEARCH), ("cfg3", rb"aa[bc]", fx.OP_SEARCH)]
+    for cfg, pat, op in cases:
+        n = 5000 if b"{20}" not in pat else 300
+        rows = synth.batch(cfg, 0, n, dev)
+        p = fx.Program(pat, op)
+        q = fx.Program.from_blob(p.blob(), op)
+        spans = op == fx.OP_SEARCH
+        f1, a1, b1 = p.match_device(rows, spans=spans)
+        f2, a2, b2 = q.match_device(rows, spans=spans)
+        torch.cuda.synchronize()
+        assert torch.equal(f1, f2) and p.last_path() == q.last_path(), pat
+        if spans:
+            assert torch.equal(a1, a2) and torch.equal(b1, b2), pat
+        of, oa, ob = oracle_lib.batch(2 if spans else 1, pat, rows.cpu().numpy(), NT)
+        assert np.array_equal(f2.cpu().numpy(), of), pat
+        if spans:
+            assert np.array_equal(a2.cpu().numpy(), oa) and np.array_equal(b2.cpu().numpy(), ob), pat
+
+
+def test_one_handle_on_several_streams_and_threads(fx):
+    """Re-entrancy per handle: ONE program used from four host threads, each on its own stream, repeatedly and at
+    the same time -- the per-call device scratch is kept per (device, stream), so the calls may overlap on the device."""
+    import threading
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    prog = fx.Program(synth.PATTERNS["cfg4"], fx.OP_SEARCH)   # deferred tiles + worklist + decode pass: every piece of scratch is in use
+    batches = [synth.batch("cfg4", 40000 * i, 40000 - 64 * i, dev) for i in range(4)]
+    want = []
+    for rows in batches:
+        f, a, b = prog.match_device(rows)
+        torch.cuda.synchronize()
+        want.append((f.clone(), a.clone(), b.clone()))
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    f, a, b = prog.match_device(batches[i])
+                    st.synchronize()
+                    if not (torch.equal(f, want[i][0]) and torch.equal(a, want[i][1]) and torch.equal(b, want[i][2])):
+                        errs.append(i)
+        except Exception as e:   # noqa
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def test_one_handle_on_two_devices(fx):
+    """A handle used on a second GPU keeps separate tables and scratch there (round-1 advisor finding)."""
+    import torch
+    from forgex_amd import synth
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    prog = fx.Program(synth.PATTERNS["cfg4"], fx.OP_SEARCH)
+    res = []
+    for d in (0, 1, 0, 1):
+        rows = synth.batch("cfg4", 0, 20000, torch.device("cuda", d))
+        f, a, b = prog.match_device(rows)
+        torch.cuda.synchronize(d)
+        res.append((f.cpu(), a.cpu(), b.cpu()))
+    for r in res[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(r, res[0]))
+
+
+def test_host_buffer_entry_chunks_and_match_spans(fx):
+    """fxamd_match_batch_host: batches larger than one chunk slot (two slots alternate, results drained per chunk), a ragged last
+    chunk, and `.match.` programs leaving the caller's from / to untouched."""
+    import torch
+    from forgex_amd import synth
+    n = 700_001   # 700001 x 256 B = 179 MB: three chunks of ~64 MB, the last one short and not a multiple of 64 rows
+    rows = synth.batch("cfg3", 0, n, torch.device("cuda"))
+    host = np.ascontiguousarray(rows.cpu().numpy())
+    prog = fx.Program(synth.PATTERNS["cfg3"], fx.OP_SEARCH)
+    f, a, b = prog.match_device(rows)
+    torch.cuda.synchronize()
+    for spans in (True, False, True):
+        hf, ha, hb = prog.match_host(host, spans=spans)
+        assert np.array_equal(hf, f.cpu().numpy())
+        if spans:
+            assert np.array_equal(ha, a.cpu().numpy()) and np.array_equal(hb, b.cpu().numpy())
+    pm = fx.Program(rb"\d{3}-\d{4}", fx.OP_MATCH)
+    small = synth.batch("cfg1", 0, 1000, torch.device("cpu")).numpy()
+    import ctypes
+    vp = ctypes.c_void_p
+    fl = np.zeros(1000, np.uint8)
+    fa = np.full(1000, 1234567, np.int32)
+    fb = np.full(1000, -7654321, np.int32)
+    rc = fx.lib().fxamd_match_batch_host(pm._h, small.ctypes.data_as(vp), 1000, 8, fl.ctypes.data_as(vp), fa.ctypes.data_as(vp), fb.ctypes.data_as(vp))
+    assert rc == 0 and (fa == 1234567).all() and (fb == -7654321).all()
+    of, _, _ = oracle_lib.batch(1, rb"\d{3}-\d{4}", small, NT)
+    assert np.array_equal(fl, of)
