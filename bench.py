@@ -204,7 +204,7 @@ def host_path_rate(fx, prog, cfg, row_len, nrows=1 << 20):
             "rows": nrows, "ms_per_call": dt * 1e3, "matches": int(res[0].sum())}
 
 
-def dryrun(args, rank, world):
+def dryrun(args, rank, world, emit):
     """FXAMD_BENCH_DRYRUN=1: the N-rank plumbing on CPU (gloo): rendezvous, shard bounds, packed gather, max-over-ranks reduction and
     the one JSON line -- no GPU, no match calls, no throughput claim."""
     import torch
@@ -228,12 +228,13 @@ def dryrun(args, rank, world):
         all_idx = torch.arange(0, rows_per_gpu * world)
         ef = (all_idx % 3 == 0).to(torch.uint8)
         ok = bool(torch.equal(res[0], ef) and torch.equal(res[1], ((all_idx % row_len) + 1).to(torch.int32) * ef))
-        print(json.dumps({"metric": "input GB/s scanned (.in. over 10M strings)", "value": None, "unit": "GB/s", "n_gpus": world, "dryrun": True,
-                          "ranks_joined": int(tt.item()), "gather_ok": ok, "steps": args.steps, "warmup": args.warmup,
-                          "config": {"workload": "dry run of the %d-rank plumbing on CPU (gloo); no GPU work" % world, "parallelism": "shard%d" % world,
-                                     "rows_per_gpu": rows_per_gpu}}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        emit({"metric": "input GB/s scanned (.in. over 10M strings)", "value": None, "unit": "GB/s", "n_gpus": world, "dryrun": True,
+              "ranks_joined": int(tt.item()), "gather_ok": ok, "steps": args.steps, "warmup": args.warmup,
+              "config": {"workload": "dry run of the %d-rank plumbing on CPU (gloo); no GPU work" % world, "parallelism": "shard%d" % world,
+                         "rows_per_gpu": rows_per_gpu}})
     return 0
 
 
@@ -262,8 +263,18 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries ONE line: everything a library prints there while the run lasts (RCCL prints a version banner on stdout) goes
+    # to stderr instead, and rank 0's JSON line is written to the real stdout at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     if DRYRUN:
-        sys.exit(dryrun(args, rank, world))
+        sys.exit(dryrun(args, rank, world, emit))
 
     import torch
     import torch.distributed as dist
@@ -437,6 +448,7 @@ def main():
             # the gathered shard of rank 0 is what rank 0 computed
             assert torch.equal(res[0][:rows_per_gpu], flags) and (not spans or torch.equal(res[1][:rows_per_gpu], frm))
 
+    line = None
     if rank == 0:
         line = {
             "metric": "input GB/s scanned (.in. over 10M strings)", "value": total_bytes / dt / 1e9, "unit": "GB/s",
@@ -468,10 +480,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, pattern, row_len, gpu_res)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 if __name__ == "__main__":

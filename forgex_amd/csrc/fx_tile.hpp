@@ -62,14 +62,18 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
    }
 }
 
-// Long rows (ANY Lr > 256): the tile is walked in 256-byte SEGMENTS (the last one shorter when Lr % 256 != 0).  Piece q*64+lane of segment `seg` = row
-// 4q + lane/16, chunk lane%16 of that segment: 16 lanes read 256 contiguous bytes of one row.  Same buffer resource trick:
-// extent = the tile's valid bytes, the row / segment distance rides in the scalar offset (which the range check includes).
-__device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
+// Long rows (ANY Lr > 16*CH, CH = 16 or 8): the tile is walked in SEGMENTS of 16*CH bytes (the last one shorter when Lr is not a
+// multiple).  Piece q*64+lane of segment `seg` = row (64/CH) q + lane/CH, chunk lane%CH of that segment: CH lanes read 16*CH
+// contiguous bytes of one row.  Same buffer resource trick: extent = the tile's valid bytes, the row / segment distance rides in
+// the scalar offset (which the range check includes).  CH = 8 with 256-byte rows is the HALF-ROW staging of the headline
+// configuration: 8 KB of LDS per wave instead of 16, so that three waves per SIMD fit.
+template <int CH>
+__device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
                                               uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable) {
    // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
-   // (k_lo, k_hi) = (0, 15); the short last one has k_hi = its last (possibly partial) chunk and the chunks behind it repeat that
+   // (k_lo, k_hi) = (0, CH-1); the short last one has k_hi = its last (possibly partial) chunk and the chunks behind it repeat that
    // one (never walked).  Rows start at any byte: the pieces are unaligned buffer loads.
+   static_assert(CH == 16 || CH == 8, "segment walker: 16 or 8 chunks per segment");
    const int64_t rows_left = n - row0;
    // (extent rounded up to whole dwords, as in load_tile)
    const uint32_t valid = !enable ? 0u : ((rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u)) + 3u) & ~3u;
@@ -77,13 +81,13 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[16], const uint8_t* __r
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
                                                                          __builtin_amdgcn_readfirstlane(valid), 0x00020000);
-   uint32_t kc = lane & 15u;
+   uint32_t kc = lane % CH;
    kc = kc < k_lo ? k_lo : (kc > k_hi ? k_hi : kc);
-   const uint32_t voff = (lane >> 4) * Lr + (kc - k_lo) * 16u;
+   const uint32_t voff = (lane / CH) * Lr + (kc - k_lo) * 16u;
    const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_byte);
 #pragma unroll
-   for (int q = 0; q < 16; ++q) {
-      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)(4 * q) * Lr, FX_LOAD_AUX);
+   for (int q = 0; q < CH; ++q) {
+      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)((64 / CH) * q) * Lr, FX_LOAD_AUX);
       v[q] = make_uint4(t.x, t.y, t.z, t.w);
    }
 }
@@ -381,11 +385,12 @@ __device__ unsigned long long fx_stamp_acc[16];
       else load_tile<CH>(st, rows, (tn) << 6, n, lane, (en), Lr);      \
    } while (0)
 
-// segment sg of a long row: bytes [256 sg, 256 sg + 256) of every row; the LAST segment is shorter when Lr % 256 != 0 and sits
+// segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en))
-#define PREFETCH_SEG_FWD(st, tn, sg, en) PREFETCH_SEG(st, tn, sg, en)
+   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en))
+#define PREFETCH_SEG_FWD(st, tn, sg, en) \
+   load_tile_seg<16>(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en))
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
@@ -408,9 +413,10 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    // RAGGED: Lr = true row length (16 <= Lr < 16*CH, Lr % 4 == 0); such rows are padded with symbol 255 in LDS.  The aligned
    // instantiation keeps the row length a compile-time constant (the hot path).
    const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;
-   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;   // segments per row: 256 bytes each, the last one shorter when Lr % 256 != 0
+   constexpr uint32_t SEGB = 16u * CH;                   // bytes of one LDS tile row = one segment of a long row
+   const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // segments per row, the last one shorter when Lr % SEGB != 0
    constexpr bool ragged = RAGGED;
-   static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
+   static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 or 8, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
@@ -575,6 +581,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
                const uint4 c = tile[tile_cell(lane, k)];
                acc |= c.x | c.y | c.z | c.w;
             }
+            na = acc;
+            if (LONG && seg != 0u) continue;
             if (row0 + lane < n) {
                flags[row0 + lane] = (uint8_t)(acc & 1u);
                if (SPANS) {
@@ -588,8 +596,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          // LONG: bytes of this segment (256, or what is left of the row in its last segment): groups behind the row end are not
          // walked, the group the row ends in is walked over its valid bytes only -- no pad symbol is needed, so the byte-level
          // tables work on rows of any length
-         const uint32_t seg_len = LONG ? (Lr - seg * 256u < 256u ? Lr - seg * 256u : 256u) : 16u * CH;
-         const uint32_t gbase = LONG ? seg * 32u : 0u;   // 8-byte groups to the left of this segment
+         const uint32_t seg_len = LONG ? (Lr - seg * SEGB < SEGB ? Lr - seg * SEGB : SEGB) : SEGB;
+         const uint32_t gbase = LONG ? seg * (SEGB / 8u) : 0u;   // 8-byte groups to the left of this segment
          // the chunk loop in two instantiations: every group whole (always, unless LONG and this is a row's short last segment) or
          // with the per-group byte counts
          auto walk = [&](auto whole_groups) {
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          };
          if constexpr (!LONG) walk(std::true_type{});
          else {
-            if (seg_len == 256u) walk(std::true_type{});
+            if (seg_len == SEGB) walk(std::true_type{});
             else walk(std::false_type{});
          }
          if (!LONG || seg == 0u) break;
@@ -1107,17 +1115,18 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
-   if (Lr > 256u) {   // long rows: segment-walking instantiation, CH = 16, first-pass / byte-level modes only
-      if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
+   if (Lr > 16u * CH) {   // long rows: segment-walking instantiation (CH = 16: any length; CH = 8, first pass with the 8-state tables:
+                          // half-row staging of 256-byte rows), first-pass / byte-level modes only
+      if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 0)) {
          constexpr int CHN = SCH;
-         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<16, true, MODE, CHN, false, true>)
-                                : reinterpret_cast<const void*>(&fx_search_fast<16, false, MODE, CHN, false, true>);
+         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false, true>)
+                                : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
-         if (spans) hipLaunchKernelGGL((fx_search_fast<16, true, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
-         else hipLaunchKernelGGL((fx_search_fast<16, false, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
          return hipGetLastError();
       } else {
          return hipErrorInvalidValue;   // (never dispatched)

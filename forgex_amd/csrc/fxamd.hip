@@ -303,7 +303,8 @@ static int scratch_for(fxamd_program* p, int dev, hipStream_t st, DevScratch** o
    }
    if (!found->d_counter) {
       FX_HIP(hipMalloc((void**)&found->d_counter, 32));
-      FX_HIP(hipMemset(found->d_counter, 0, 32));
+      // zeroed IN STREAM ORDER: a memset on the null stream is not ordered against kernels on a non-blocking stream
+      FX_HIP(hipMemsetAsync(found->d_counter, 0, 32, st));
    }
    found->last_use = ++p->use_clock;
    *out = found;
@@ -335,7 +336,13 @@ struct PassOpts {
    uint32_t defer_tiles = 0, gate_word = 0;
    uint32_t* worklist = nullptr;   // BYTES passes append exception rows, the worklist decode pass (MODE 4) reads them
    int64_t grid_tiles = 0;         // MODE 4: upper bound of the worklist's tiles (the count itself lives on the device)
+   bool half = false;              // first pass over 256-byte rows with the 8-state tables: stage HALF rows (CH = 8 segment walker)
 };
+// 256-byte rows on the 8-state tables: half-row staging (8 KB of LDS per wave: three waves per SIMD instead of two)
+static bool half_rows(int scheme, int64_t row_len) {
+   static const bool on = std::getenv("FXAMD_HALF") != nullptr;
+   return on && scheme == 0 && row_len == 256;
+}
 
 template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
@@ -421,7 +428,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.inv_on = 1u;
       fp.inv = WIDE ? (h.R_inv < 8u ? h.R_inv : 0x80u + h.R_inv - 8u) * 0x01010101u : (CHAIN ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
-   switch (chunks_of(row_len)) {
+   switch (po.half ? 8 : chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_fast<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_fast<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -500,6 +507,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
       PassOpts first, marked, listp;
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
+      first.half = !is_match && half_rows(scheme, row_len);
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
       if (bytes || !utf8_tables) {
@@ -764,6 +772,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
+   po.half = half_rows(scheme, row_len);
    if (scheme != 0 && bytes && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
