@@ -339,8 +339,9 @@ def main():
     L = forgex_amd.lib()
     stream = torch.cuda.current_stream(dev)
     reps = max(5, min(args.steps, 200))
-    fast = prog.last_path() in (1, 3, 5, 6, 7, 8)
-    whole_step = cfg == "cfg4"   # non-ASCII rows: several passes share the work -> time the whole step
+    one_launch = prog.last_path() in (9, 10, 11)   # fx_search_one: the step IS one kernel launch
+    fast = one_launch or prog.last_path() in (1, 3, 5, 6, 7, 8)
+    whole_step = one_launch or cfg == "cfg4"   # multi-pass pipeline on non-ASCII rows: several passes share the work -> time the whole step
 
     def kernel_events(k):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
@@ -374,8 +375,8 @@ def main():
             traffic = json.load(open(tpath)).get(cfg)
         except Exception:
             traffic = None
-    kname = "fx_search_fast<%d>" % (row_len // 16)
-    if whole_step:
+    kname = ("fx_search_one<%d>" if one_launch else "fx_search_fast<%d>") % (row_len // 16)
+    if whole_step and not one_launch:
         kname += ", all passes of one step"
 
     def gbs(ms):

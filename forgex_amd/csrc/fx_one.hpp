@@ -1,0 +1,426 @@
+// fx_search_one: the `.in.` / regex search of fx_search_fast for rows of up to 256 bytes in ONE launch.
+//
+// fx_search_fast needs up to three launches per call when rows may hold bytes >= 0x80 (first pass that DEFERS such tiles, a second
+// pass over them, a third over the exception rows), reads deferred tiles twice and pays for the empty gate launches on pure-ASCII
+// batches.  Here every tile is finished by the wave that staged it, with the scheme its bytes ask for:
+//   * pure-ASCII tile            -> class-level tables (v_perm / wide v_perm / chain), exactly the first pass of fx_search_fast
+//   * tile with a byte >= 0x80   -> byte-level tables (FXP_F_BYTE_DFA; chain or wide format) on the RAW bytes of the same LDS tile,
+//                                   or, without them (ragged rows, programs without byte-level automata), the in-LDS UTF-8
+//                                   decode (fxrow::translate_cell16) followed by the class-level scan
+//   * exception rows of the byte-level tables (structurally invalid UTF-8: the backward pass ends in the INVALID state) are kept
+//     in a per-wave queue in LDS (64 row indices); when a tile would overflow it, and once more at the end of the kernel after
+//     the block's four queues have been merged, the queued rows are GATHERED into a tile (lane r loads row queue[r] into its
+//     own cells), decoded in LDS and scanned with the class-level tables -- the decode pass of fx_search_fast's MODE 4, inside
+//     the same launch.
+// Programs whose class-level tables cannot decode UTF-8 (candidate-list driver: prefix literals outside the equivalence proof)
+// and rows longer than 256 bytes stay on fx_search_fast and its worklist fix-up.
+#pragma once
+#include "fx_tile.hpp"
+
+template <int SCH_, bool BYTES_, bool DECODED_>
+struct FxScanCfg {
+   static constexpr int sch = SCH_;
+   static constexpr bool bytes = BYTES_, decoded = DECODED_;
+};
+
+// SCH: scheme of the class-level tables (0 v_perm, 1 chain, 2 wide); BSCH: scheme of the byte-level tables (0 = none in this
+// launch, 1 chain, 2 wide).  SCH == 0 && BSCH != 0: per-tile selection.  SCH != 0 && BSCH != 0: the byte-level tables take every
+// tile (the class-level ones are no faster on ASCII), the class-level tables only serve the exception rows.
+template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED>
+__global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
+                                                       FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
+                                                       uint32_t class_map_in_lds, uint32_t Lr) {
+   static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
+   constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0;
+   const uint32_t L = RAGGED ? Lr : 16u * CH;
+   constexpr bool ragged = RAGGED;
+   __shared__ uint2 permR[SCH == 0 ? 256 : 1];
+   __shared__ uint2 permA[SCH == 0 ? 256 : 1];
+   __shared__ uint4 wideR[SCH == 2 ? 256 : 1];
+   __shared__ uint4 wideA[SCH == 2 ? 256 : 1];
+   __shared__ uint4 bwideR[BSCH == 2 ? 256 : 1];
+   __shared__ uint4 bwideA[BSCH == 2 ? 256 : 1];
+   __shared__ uint32_t pool_q[HAS_B ? 4 * 64 : 1];   // per-wave queues of exception rows
+   __shared__ uint32_t pool_cnt[4];
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   // ---- tables -> LDS ----
+   uint8_t* dyn = reinterpret_cast<uint8_t*>(tiles + 4 * 64 * (CH + 1));
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(dyn);   // class-level chain: symbol -> 2*column map (512 B), then T_R, then T_A
+   const uint32_t c_tr = SCH == 1 ? h->chain_TR_bytes : 0u, c_ta = SCH == 1 ? h->chain_TA_bytes : 0u;
+   const uint32_t c_bytes = SCH == 1 ? ((512u + c_tr + c_ta + 15u) & ~15u) : 0u;
+   uint16_t* bmap = reinterpret_cast<uint16_t*>(dyn + c_bytes);   // byte-level chain tables, same layout
+   const uint32_t b_tr = BSCH == 1 ? h->byte_TR_bytes : 0u, b_ta = BSCH == 1 ? h->byte_TA_bytes : 0u;
+   const uint32_t b_bytes = BSCH == 1 ? ((512u + b_tr + b_ta + 15u) & ~15u) : 0u;
+   if (SCH == 1) {
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_chain_cls);
+      const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TR);
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TA);
+      const uint32_t nr = c_tr / 2, na = c_ta / 2;
+      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+   } else if (SCH == 2) {
+      wideR[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_w16R)[threadIdx.x];
+      wideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_w16A)[threadIdx.x];
+   } else {
+      permR[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastR)[threadIdx.x];
+      permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
+   }
+   if (BSCH == 1) {
+      const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_byte_cls);
+      const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + h->off_byte_TR);
+      const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_byte_TA);
+      const uint32_t nr = b_tr / 2, na = b_ta / 2;
+      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) bmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+   } else if (BSCH == 2) {
+      bwideR[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_bw16R)[threadIdx.x];
+      bwideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_bw16A)[threadIdx.x];
+   }
+   // BMP class map (page index + pages) of the in-LDS UTF-8 decode, behind the tables when it fits
+   const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
+   const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
+   if (class_map_in_lds) {
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(dyn + c_bytes + b_bytes);
+      const uint32_t n16 = 1024u + h->n_pages * 64u;
+      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      page_p = l16;
+      pages_p = l16 + 1024;
+   }
+   __syncthreads();
+   const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
+                               reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
+   const uint32_t sym_ffff = 128u + h->cls_ffff;
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const bool raw = (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search: bytes are symbols, nothing is decoded
+   uint4* tile = tiles + wave * (64 * (CH + 1));
+   // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (see fx_search_fast)
+   tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   const bool whole = RAGGED && (Lr & 15u) == 0u;
+   if (whole)
+      for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   uint32_t* myq = pool_q + (HAS_B ? wave * 64u : 0u);
+
+   // ---- one scan of the tile in LDS: backward pass (leftmost start), forward pass (longest end), results -----------------------
+   // cfg: table scheme; bytes = byte-level tables on raw bytes; decoded = the tile was rewritten into symbol ids (every byte value
+   // means something: no byte >= 0x80 test).  Returns true when a class-level scan of RAW bytes met a byte >= 0x80: nothing was
+   // written, the tile has to be redone.  `except` = this lane's row ended the byte-level backward pass in the INVALID state.
+   auto scan = [&](auto cfg, const int64_t row, const bool row_ok, bool& except) -> bool {
+      using C = decltype(cfg);
+      constexpr int S_ = C::sch;
+      constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2, BYTES = C::bytes, DECODED = C::decoded;
+      using F = typename FxF<S_>::type;
+      using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+      const FastParams& P = BYTES ? fpb : fp;
+      const uint16_t* cm = BYTES ? bmap : cmap;
+      const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideR : wideR) : reinterpret_cast<const TabT*>(permR));
+      const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideA : wideA) : reinterpret_cast<const TabT*>(permA));
+      const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cm) + 512;
+      const uint8_t* TAp = TRp + (CHAIN ? (BYTES ? b_tr : c_tr) : 0u);
+      uint32_t state = P.R_start;
+      uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
+      uint32_t na = 0;
+      if (ragged && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);
+      {
+         F fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
+         if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+         lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll
+         for (int k = CH - 1; k >= 0; --k) {
+            if (!ragged || (whole && !DECODED && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
+            lookup8(fb, wk.x, wk.y, tabR);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fa, state, TRp);
+               gsel = mx >= P.hit_min ? (uint32_t)(2 * k + 1) : gsel;
+               esel = mx >= P.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 1) {
+               wk = wn;
+               lookup8(fa, wk.z, wk.w, tabR);
+               if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fb, state, TRp);
+               gsel = mx >= P.hit_min ? (uint32_t)(2 * k) : gsel;
+               esel = mx >= P.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      }
+      // a class-level scan of raw bytes that met a byte >= 0x80: the tile is redone with the byte-level tables / after a decode
+      if (!BYTES && !DECODED && !raw && __builtin_amdgcn_ballot_w64((na & 0x80808080u) != 0) != 0) return true;
+      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
+      {
+         // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
+         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
+         const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+         F f[8];
+         lookup8(f, rw.x, rw.y, tabR);
+         uint32_t st = esel, loc = 8;
+#pragma unroll
+         for (int i = 7; i >= 0; --i) {
+            st = fxstep(f[i], st, TRp);
+            loc = st >= P.hit_min ? (uint32_t)i : loc;
+         }
+         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
+         const F fz = tabR[0];   // leading NUL
+         state = fxstep(fz, state, TRp);
+         s = state >= P.hit_min ? 1u : s;
+      }
+      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8: the row is queued for the decode pass
+      except = BYTES && state == P.inv;
+      // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
+      uint32_t cur = (s != 0 && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
+      uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
+      uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
+      if (s == 1) {
+         const F f = tabA[0];
+         cur = fxstep(f, cur, TAp);
+         mm = cur >= P.acc_min ? 2u : 0u;
+      }
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         uint32_t o[8];
+         fetch32<RAGGED, false>(o, tb, lane, j, (uint32_t)L);
+         constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
+         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
+#pragma unroll
+         for (int gb = 0; gb < 4; gb += GB) {
+            F f[8 * GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+               const uint32_t entry = cur;
+               uint32_t st[8];
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f[8 * g + q], cur, TAp);
+                  st[q] = cur;
+               }
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool hit = mx >= P.acc_min;
+               gl = hit ? (uint32_t)(gb + g) : gl;
+               el = hit ? entry : el;
+               blo = hit ? o[2 * (gb + g)] : blo;
+               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
+            }
+         }
+         {
+            F fr8[8];
+            lookup8(fr8, blo, bhi, tabA);
+            uint32_t st = el, loc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               st = fxstep(fr8[q], st, TAp);
+               loc = st >= P.acc_min ? (uint32_t)q : loc;
+            }
+            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+         }
+         j += 32u;
+         // matches longer than the window: 8 symbols per round trip, the next group read one round ahead (see fx_search_fast)
+         if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+            const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
+            uint32_t gb = j & ~7u;
+            uint32_t t0[2], t1[2];
+            group_words<RAGGED, false>(t0[0], t0[1], tb, lane, gb, (uint32_t)L);
+            group_words<RAGGED, false>(t1[0], t1[1], tb, lane, gb + 8u, (uint32_t)L);
+            do {
+               uint32_t t2[2];
+               group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
+               const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
+               const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
+               F f8[8];
+               lookup8(f8, o0, o1, tabA);
+               uint32_t loc = 8;
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f8[q], cur, TAp);
+                  loc = cur >= P.acc_min ? (uint32_t)q : loc;
+               }
+               mm = loc != 8u ? j + loc + 3u : mm;
+               j += 8u;
+               gb += 8u;
+               t0[0] = t1[0]; t0[1] = t1[1];
+               t1[0] = t2[0]; t1[1] = t2[1];
+            } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
+         }
+      }
+      uint32_t flag = 0;
+      int32_t fr = 0, tt = 0;
+      if (SPANS) {
+         if (s != 0 && mm != 0) {   // api_internal_m.F90:140-148
+            fr = (int32_t)(s - 1);
+            if (fr == 0) fr = 1;
+            tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
+            if (fr > 0 && tt > 0) flag = 1;
+            else { fr = 0; tt = 0; }
+         }
+      } else {
+         flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
+      }
+      if (row_ok && !except) {
+         flags[row] = (uint8_t)flag;
+         if (SPANS) {
+            from[row] = fr;
+            to[row] = tt;
+         }
+      }
+      return false;
+   };
+
+   // ---- the wave's loop: tiles of the batch, and -- when its queue would overflow, and at the end -- gathered tiles of exception rows
+   uint32_t pool_n = 0;        // rows in this wave's queue (wave-uniform)
+   uint64_t pend_mask = 0;     // lanes whose row of the last byte-level scan is an exception not yet queued (wave-uniform)
+   uint32_t pend_row = 0;      // that row (per lane)
+   uint32_t phase = 0, pass = wave, total = 0, pre1 = 0, pre2 = 0, pre3 = 0;
+   uint4 stage[CH];
+   if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
+   else load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   for (int64_t t = wave_global;;) {
+      bool is_tile = false;
+      uint32_t take = 0, take_base = 0;
+      if (phase == 0) {
+         if (HAS_B && pend_mask != 0 && pool_n + (uint32_t)__builtin_popcountll(pend_mask) <= 64u) {
+            if ((pend_mask >> lane) & 1ull) myq[pool_n + (uint32_t)__builtin_popcountll(pend_mask & ((1ull << lane) - 1ull))] = pend_row;
+            pool_n += (uint32_t)__builtin_popcountll(pend_mask);
+            pend_mask = 0;
+         }
+         if (HAS_B && pend_mask != 0) {
+            take = pool_n;   // the queue has to be drained before the pending rows fit
+         } else if (t < n_tiles) {
+            is_tile = true;
+         } else {
+            if (!HAS_B) break;
+            // end of the wave's tiles: merge the block's four queues; each wave then takes every fourth gathered tile
+            if (lane == 0) pool_cnt[wave] = pool_n;
+            __syncthreads();
+            const uint32_t c0 = pool_cnt[0], c1 = pool_cnt[1], c2 = pool_cnt[2], c3 = pool_cnt[3];
+            pre1 = c0;
+            pre2 = c0 + c1;
+            pre3 = c0 + c1 + c2;
+            total = pre3 + c3;
+            phase = 1;
+            continue;
+         }
+      } else {
+         if (pass * 64u >= total) break;
+         take_base = pass * 64u;
+         take = total - take_base < 64u ? total - take_base : 64u;
+         pass += 4u;
+      }
+      int64_t row;
+      bool row_ok;
+      bool hint = false;   // a sampled look at the staged bytes found a byte >= 0x80 (wave-uniform)
+      if (is_tile) {
+         row = (t << 6) + lane;
+         row_ok = row < n;
+         if (!ALLB && !raw) {
+            const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+            hint = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
+         }
+         if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(stage, tile, lane, Lr >> 4);
+         else if (RAGGED) store_tile_relayout<CH>(stage, tile, lane, Lr);
+         else store_tile<CH>(stage, tile, lane);
+         // the ONE place the staging registers are reloaded; a tile behind the last one is "loaded" with zero valid bytes
+         t += wave_stride;
+         if (RAGGED) load_tile<CH>(stage, rows, t << 6, n, lane, true, Lr);
+         else load_tile<CH>(stage, rows, t << 6, n, lane);
+      } else {
+         // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
+         row_ok = lane < take;
+         uint32_t ridx = 0;
+         if (HAS_B && row_ok) {
+            if (phase == 0) ridx = myq[lane];
+            else {
+               const uint32_t g = take_base + lane;
+               const uint32_t w = g >= pre3 ? 3u : (g >= pre2 ? 2u : (g >= pre1 ? 1u : 0u));
+               const uint32_t pb = w == 3u ? pre3 : (w == 2u ? pre2 : (w == 1u ? pre1 : 0u));
+               ridx = pool_q[w * 64u + (g - pb)];
+            }
+         }
+         row = (int64_t)ridx;
+         const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+#pragma unroll 1
+         for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
+         if (phase == 0) pool_n = 0;
+      }
+      bool except = false;
+      bool redo = false;
+      if (is_tile && !ALLB && !hint) redo = scan(FxScanCfg<SCH, false, false>{}, row, row_ok, except);
+      const bool nonascii = !is_tile || hint || redo;   // (gathered rows always take the decode)
+      if constexpr (HAS_B) {
+         if (is_tile && (ALLB || nonascii)) {
+            (void)scan(FxScanCfg<(BSCH != 0 ? BSCH : 1), true, false>{}, row, row_ok, except);
+            pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
+            pend_row = (uint32_t)row;
+         }
+      }
+      if ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii)) {
+         // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
+         // (fxrow::translate_cell16); the 4 bytes before / after a cell are taken from the ORIGINAL neighbours.
+         uint32_t prev = 0;
+         uint4 cur = tile[tile_cell(lane, 0)];
+         for (int k = 0; k < CH; ++k) {
+            const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+            const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+            tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+            prev = cur.w;
+            cur = nxt;
+         }
+         (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, except);
+      }
+   }
+}
+
+// FastParams of the class-level tables (fp) and of the byte-level tables (fpb) are prepared by the host (fxamd.hip)
+template <int CH, int SCH, int BSCH>
+hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
+                      uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st) {
+   const int64_t n_tiles = (n + 63) >> 6;
+   int64_t blocks = (n_tiles + 3) / 4;
+   if (blocks > 256 * 8) blocks = 256 * 8;
+   const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
+   // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
+   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 8192 : 0)) + (BSCH == 2 ? 8192 : 0) + 1024 + 64;
+   const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const size_t lds = tiles_b + table_bytes + map_lds;
+   const bool ragged = Lr != 16u * CH;
+   const bool spans = from && to;
+   if (ragged) {
+      if constexpr (BSCH == 0) {
+         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true>);
+         if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+         }
+         if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+         else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+         return hipGetLastError();
+      } else {
+         return hipErrorInvalidValue;   // (never dispatched: byte-level tables need whole chunks)
+      }
+   }
+   const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, BSCH, false>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, BSCH, false>);
+   if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+   }
+   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+   else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+   return hipGetLastError();
+}
+
+// every (CH, SCH, BSCH) the dispatch code of fxamd.hip can ask for
+#define FX_ONE_COMBOS(X, CH) X(CH, 0, 0) X(CH, 1, 0) X(CH, 2, 0) X(CH, 0, 1) X(CH, 0, 2) X(CH, 1, 1) X(CH, 1, 2) X(CH, 2, 1) X(CH, 2, 2)
+#define FX_ONE_ALL(X) \
+   FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 3) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 6) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)
+#define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t)

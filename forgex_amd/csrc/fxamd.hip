@@ -11,13 +11,16 @@
 //   fx_general           one lane = one row through fxrow::run_row (row_engine.hpp): every mode, UTF-8 decode
 //                        on device, candidate-list driver, literal search, `.match.`; also the fix-up pass for
 //                        rows the fast kernel flags as non-ASCII.
-#include "fx_tile.hpp"
+#include "fx_one.hpp"
 
 #ifndef FX_SINGLE_TU   // the launcher instantiations live in fx_tile_inst.hip (one object per chunk count)
 #define FX_X(CH, M, S)                                                  \
    extern template hipError_t launch_fast<CH, M, S> FX_TILE_SIG_FAST;   \
    extern template hipError_t launch_match<CH, M, S> FX_TILE_SIG_MATCH;
 FX_TILE_ALL(FX_X)
+#undef FX_X
+#define FX_X(CH, S, B) extern template hipError_t launch_one<CH, S, B> FX_ONE_SIG;
+FX_ONE_ALL(FX_X)
 #undef FX_X
 #endif
 
@@ -440,6 +443,70 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    }
 }
 
+// ---- fx_search_one: the whole search in one launch (rows of up to 256 bytes, class-level tables that can decode UTF-8) ----------
+// FastParams of one table family: class-level tables of scheme `sch`, or (bytes) the byte-level tables in the chain / wide format
+static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
+   FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
+                 0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u};
+   if (sch == 2) {   // encoded state bytes, replicated like the 8-state scheme's
+      fp.R_start = (bytes ? h.bw16_R_start : h.w16_R_start) * 0x01010101u;
+      fp.A_init = (bytes ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
+      fp.hit_min = (bytes ? h.bw16_hit_min : h.w16_hit_min) * 0x01010101u;
+      fp.acc_min = (bytes ? h.bw16_acc_min : h.w16_acc_min) * 0x01010101u;
+      fp.inv = bytes ? h.bw16_inv_R * 0x01010101u : 0u;
+   } else if (bytes) {
+      fp.R_start = h.byte_R_start;
+      fp.A_init = h.byte_A_init;
+      fp.hit_min = h.byte_hit_min;
+      fp.acc_min = h.byte_acc_min;
+      fp.inv = h.byte_inv_R;
+   } else if (sch == 1) {   // states are row byte offsets, compared as plain integers
+      fp.R_start = h.chain_R_start;
+      fp.A_init = h.chain_A_init;
+      fp.hit_min = h.chain_hit_min;
+      fp.acc_min = h.chain_acc_min;
+   }
+   return fp;
+}
+template <int SCH, int BSCH>
+static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
+                                int32_t* d_from, int32_t* d_to, hipStream_t st) {
+   const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
+   const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
+   const uint32_t table_bytes = (SCH == 1 ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u) +
+                                (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
+   const uint32_t Lr = (uint32_t)row_len;
+   switch (tile_chunks(row_len)) {
+      case 1: return launch_one<1, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 2: return launch_one<2, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 3: return launch_one<3, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 4: return launch_one<4, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 6: return launch_one<6, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 8: return launch_one<8, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 12: return launch_one<12, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      default: return launch_one<16, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+   }
+}
+// bsch: 0 = no byte-level tables for these rows, 1 chain, 2 wide
+static hipError_t launch_one_any(int sch, int bsch, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                                 uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
+#define FX_ONE_CASE(S, B) \
+   if (sch == S && bsch == B) return launch_one_ch<S, B>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st);
+   FX_ONE_CASE(0, 0) FX_ONE_CASE(1, 0) FX_ONE_CASE(2, 0) FX_ONE_CASE(0, 1) FX_ONE_CASE(0, 2) FX_ONE_CASE(1, 1) FX_ONE_CASE(1, 2) FX_ONE_CASE(2, 1) FX_ONE_CASE(2, 2)
+#undef FX_ONE_CASE
+   return hipErrorInvalidValue;
+}
+// Which byte-level format rides along in the one-launch kernel: wide v_perm when the tables exist in it and two blocks per CU still
+// fit next to it (4 tiles + class-level tables + 8 KB), else the chain format (a few hundred bytes to a few KB), 0 = none.
+static int one_bytes_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, int sch) {
+   if (!bytes_ok(h, d_rows, row_len)) return 0;
+   const size_t tiles_b = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1);
+   const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 8192 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
+   if (bytes_scheme(h) == 2 && tiles_b + cls_b + 8192 + 2048 <= 80 * 1024) return 2;
+   if (tiles_b + cls_b + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 + 2048 <= 150 * 1024) return 1;
+   return 0;
+}
+
 // runtime scheme -> instantiation (byte-level modes have no 8-state variant)
 template <int MODE>
 static hipError_t fast_by(int sch, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
@@ -543,6 +610,14 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
          FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          p->last_path = 1 + big;
+         return FXAMD_OK;
+      }
+      if (!is_match && utf8_tables && !first.half && !std::getenv("FXAMD_MULTIPASS")) {
+         // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
+         // the in-LDS decode on the others, exception rows through per-wave queues); last_path 9 / 10 / 11
+         const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
+         FX_HIP(launch_one_any(scheme, ob, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
+         p->last_path = ob == 0 ? 9 : (scheme == 0 ? 10 : 11);
          return FXAMD_OK;
       }
       if (bytes && scheme != 0) {
