@@ -61,6 +61,8 @@ def lib():
     L.fxamd_program_info.restype = c.c_int
     L.fxamd_strerror.argtypes = [c.c_int32]
     L.fxamd_strerror.restype = c.c_char_p
+    L.fxamd_strerror_copy.argtypes = [c.c_int32, vp, i64]
+    L.fxamd_strerror_copy.restype = i64
     L.fxamd_program_upload.argtypes = [vp]
     L.fxamd_program_upload.restype = c.c_int
     L.fxamd_match_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp]
@@ -85,7 +87,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "fxamd_compile", "fxamd_compile_nfa", "fxamd_program_free", "fxamd_program_status", "fxamd_program_blob_size",
-    "fxamd_program_blob", "fxamd_program_from_blob", "fxamd_program_info", "fxamd_strerror", "fxamd_program_upload", "fxamd_program_reserve",
+    "fxamd_program_blob", "fxamd_program_from_blob", "fxamd_program_info", "fxamd_strerror", "fxamd_strerror_copy", "fxamd_program_upload", "fxamd_program_reserve",
     "fxamd_match_batch_device", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
 ]
 BENCH_SYMBOLS = ["fxamd_launch_fast_only"]   # include/forgex_amd_bench.h: measurement hooks, not part of the boundary

@@ -349,8 +349,16 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          }
          row = (int64_t)ridx;
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+         // (four loads in flight: the staging registers hold the next tile's loads and stay untouched)
 #pragma unroll 1
-         for (int k = 0; k < CH; ++k) tile[tile_cell(lane, k)] = row_ok ? src[k] : make_uint4(0, 0, 0, 0);
+         for (int k0 = 0; k0 < CH; k0 += 4) {
+            uint4 g4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g4[i] = (row_ok && k0 + i < CH) ? src[k0 + i < CH ? k0 + i : 0] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+               if (k0 + i < CH) tile[tile_cell(lane, k0 + i)] = g4[i];
+         }
          if (phase == 0) pool_n = 0;
       }
       bool except = false;
@@ -365,16 +373,43 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          }
       }
       if ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii)) {
-         // On-device UTF-8 decode, in place in LDS: lane r rewrites its own row cell by cell into fast-path symbol ids
-         // (fxrow::translate_cell16); the 4 bytes before / after a cell are taken from the ORIGINAL neighbours.
-         uint32_t prev = 0;
-         uint4 cur = tile[tile_cell(lane, 0)];
-         for (int k = 0; k < CH; ++k) {
-            const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
-            const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
-            tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
-            prev = cur.w;
-            cur = nxt;
+         // On-device UTF-8 decode, in place in LDS, into fast-path symbol ids (fxrow::translate_cell16); the 4 bytes before / after
+         // a cell are taken from the ORIGINAL neighbours.
+         if (HAS_B && !is_tile) {
+            // gathered tile: usually a handful of rows (one merged pass per block), and a single wave's serial decode of a row is
+            // what the end of the kernel waits for -- so FOUR lanes share a row (a quarter of its cells each), sixteen rows per round.
+            // All reads of a round are issued before its writes (one wave: its LDS operations complete in order).
+            constexpr int CQ = (CH + 3) / 4;
+            const uint32_t q = lane & 3u;
+            for (uint32_t r0 = 0; r0 < take; r0 += 16u) {
+               const uint32_t r = r0 + (lane >> 2);
+               uint4 outc[CQ];
+               uint32_t k = q * CQ;
+               uint32_t prev = (k >= 1u && k - 1u < (uint32_t)CH) ? tile[tile_cell(r, k - 1u)].w : 0u;
+               uint4 cur = k < (uint32_t)CH ? tile[tile_cell(r, k)] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+               for (int i = 0; i < CQ; ++i, ++k) {
+                  const uint4 nxt = k + 1u < (uint32_t)CH ? tile[tile_cell(r, k + 1u)] : make_uint4(0, 0, 0, 0);
+                  const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+                  outc[i] = make_uint4(o.x, o.y, o.z, o.w);
+                  prev = cur.w;
+                  cur = nxt;
+               }
+               k = q * CQ;
+#pragma unroll
+               for (int i = 0; i < CQ; ++i, ++k)
+                  if (k < (uint32_t)CH) tile[tile_cell(r, k)] = outc[i];
+            }
+         } else {
+            uint32_t prev = 0;   // lane r rewrites its own row cell by cell
+            uint4 cur = tile[tile_cell(lane, 0)];
+            for (int k = 0; k < CH; ++k) {
+               const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+               tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+               prev = cur.w;
+               cur = nxt;
+            }
          }
          (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, except);
       }
@@ -387,7 +422,6 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
                       uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
-   if (blocks > 256 * 8) blocks = 256 * 8;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
    const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 8192 : 0)) + (BSCH == 2 ? 8192 : 0) + 1024 + 64;
@@ -395,6 +429,17 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
+   // Grid: with byte-level tables every block ends with one merged pass over its exception rows, so the grid is sized to what is
+   // RESIDENT (one tail per CU slot, not one per 1/8 of it); without them the usual cap with grid-stride beyond it.
+   {
+      static const int env_mult = std::getenv("FXAMD_ONE_GRID") ? std::atoi(std::getenv("FXAMD_ONE_GRID")) : 0;
+      const size_t per_block = lds + static_b;
+      int64_t resident = per_block > 0 ? (int64_t)((160 * 1024) / per_block) : 8;   // blocks per CU by LDS (the binding resource of these kernels)
+      if (resident < 1) resident = 1;
+      if (resident > 8) resident = 8;
+      const int64_t cap = 256 * (env_mult > 0 ? env_mult : (BSCH != 0 ? resident : 8));
+      if (blocks > cap) blocks = cap;
+   }
    if (ragged) {
       if constexpr (BSCH == 0) {
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true>);

@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    constexpr uint32_t SEGB = 16u * CH;                   // bytes of one LDS tile row = one segment of a long row
    const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // segments per row, the last one shorter when Lr % SEGB != 0
    constexpr bool ragged = RAGGED;
+   constexpr bool HALFROW = LONG && CH == 8;   // 256-byte rows staged as two 128-byte halves (the launcher guarantees Lr == 256)
    static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 or 8, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
@@ -506,6 +507,83 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
    };
    const uint32_t list_count = LIST ? n_deferred[1] : 0u;
+   // Forward pass over the symbol stream of one row from text index j (state `cur`, 0 = this lane does not walk): first 32 symbols
+   // straight-line -- five aligned 8-byte row reads, a byte shift to start exactly at j, all 32 table lookups issued before the
+   // chain; per 8-byte group only "any accept" (v_max3) + entry state are kept and the last accepting group is re-walked for the
+   // exact byte -- then 8 symbols per round trip while any lane is alive.  `src`: the LDS tile (FROM_GLOBAL false) or the row itself
+   // in global memory; Lx: the length of what `src` holds (the virtual end-of-row symbols follow it).  mm: max_match so far, updated.
+   auto forward_pass = [&](auto from_global, const uint8_t* src, const uint32_t Lx, uint32_t cur, uint32_t& mm, uint32_t j) {
+      constexpr bool FG = decltype(from_global)::value;
+      if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) return;
+      uint32_t o[8];
+      fetch32<RAGGED, FG>(o, src, lane, j, Lx);
+      constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
+      uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
+#pragma unroll
+      for (int gb = 0; gb < 4; gb += GB) {
+         F f[8 * GB];
+#pragma unroll
+         for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
+#pragma unroll
+         for (int g = 0; g < GB; ++g) {
+            const uint32_t entry = cur;
+            uint32_t st[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               cur = fxstep(f[8 * g + q], cur, TAp);
+               st[q] = cur;
+            }
+            const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+            const bool hit = mx >= fp.acc_min;
+            gl = hit ? (uint32_t)(gb + g) : gl;
+            el = hit ? entry : el;
+            blo = hit ? o[2 * (gb + g)] : blo;
+            bhi = hit ? o[2 * (gb + g) + 1] : bhi;
+         }
+      }
+      {
+         F fr8[8];
+         lookup8(fr8, blo, bhi, tabA);
+         uint32_t st = el, loc = 0;
+#pragma unroll
+         for (int q = 0; q < 8; ++q) {
+            st = fxstep(fr8[q], st, TAp);
+            loc = st >= fp.acc_min ? (uint32_t)q : loc;
+         }
+         mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+      }
+      j += 32u;
+      STAMP(4);
+      // matches longer than the window: 8 symbols per round trip.  The stream is a rolling window of two aligned 8-byte groups
+      // (t0, t1); the group after them is read one round ahead, so a round waits for its table lookups only.  Wave-uniform: dead
+      // lanes (state 0 is absorbing and below acc_min) ride along.
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
+         uint32_t gb = j & ~7u;
+         uint32_t t0[2], t1[2];
+         group_words<RAGGED, FG>(t0[0], t0[1], src, lane, gb, Lx);
+         group_words<RAGGED, FG>(t1[0], t1[1], src, lane, gb + 8u, Lx);
+         do {
+            uint32_t t2[2];
+            group_words<RAGGED, FG>(t2[0], t2[1], src, lane, gb + 16u, Lx);
+            const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
+            const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
+            F f8[8];
+            lookup8(f8, o0, o1, tabA);
+            uint32_t loc = 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               cur = fxstep(f8[q], cur, TAp);
+               loc = cur >= fp.acc_min ? (uint32_t)q : loc;
+            }
+            mm = loc != 8u ? j + loc + 3u : mm;
+            j += 8u;
+            gb += 8u;
+            t0[0] = t1[0]; t0[1] = t1[1];
+            t1[0] = t2[0]; t1[1] = t2[1];
+         } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
+      }
+   };
    // `live`: the tile in `stage` is to be scanned (always, except in the marked-tile passes); on return it says so for t_next
    auto do_tile = [&](uint4 (&stage)[CH], bool& live, const int64_t t, const int64_t t_next) {
       const int64_t row0 = t << 6;
@@ -527,6 +605,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       uint32_t state = fp.R_start;
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
       uint32_t na = 0;
+      uint32_t s_half = 0, mm_half = 0;   // half-row staging: start / max_match resolved while the right half was in LDS
       for (uint32_t seg = S - 1u;; --seg) {   // one pass unless LONG: the row's 256-byte segments, right to left
          if (!LIST) {
             const bool process = live;
@@ -654,16 +733,43 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             if (seg_len == SEGB) walk(std::true_type{});
             else walk(std::false_type{});
          }
+         if constexpr (HALFROW) {
+            // Half-row staging (two segments per row): the right half is in LDS now and will be overwritten by the left one.  A row
+            // whose leftmost hit SO FAR lies here gets its exact start and -- speculatively: a hit in the left half supersedes it --
+            // its forward pass now, from LDS (this half + the end-of-row column), instead of from global memory afterwards.
+            if (seg == 1u && __builtin_amdgcn_ballot_w64(gsel != 0xFFFFFFFFu) != 0) {
+               const uint32_t gl8 = gsel != 0xFFFFFFFFu ? gsel - SEGB / 8u : 0u;   // group inside this half
+               const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, gl8 >> 1) << 4) + ((gl8 & 1u) << 3));
+               F f[8];
+               lookup8(f, rw.x, rw.y, tabR);
+               uint32_t st = esel, loc = 8;
+#pragma unroll
+               for (int i = 7; i >= 0; --i) {
+                  st = fxstep(f[i], st, TRp);
+                  loc = st >= fp.hit_min ? (uint32_t)i : loc;
+               }
+               s_half = gsel != 0xFFFFFFFFu ? gsel * 8u + 2u + loc : 0u;
+               if (SPANS && fp.lit_len == 0) {
+                  uint32_t mmh = 0;
+                  // coordinates of this half: text index j - SEGB, length SEGB; max_match moves back by SEGB afterwards
+                  forward_pass(std::false_type{}, tb, SEGB, s_half != 0u ? fp.A_init : 0u, mmh, s_half != 0u ? s_half - 2u - SEGB : 0u);
+                  mm_half = mmh != 0u ? mmh + SEGB : 0u;
+               }
+            }
+         }
          if (!LONG || seg == 0u) break;
       }
       STAMP(2);
       uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
       {
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
-         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
+         // (half-row staging: a hit group of the right half was resolved while that half was in LDS -- s_half; the re-walk here is
+         //  for hit groups of the left half, which is what the tile holds now)
+         const bool here = !HALFROW || gsel < SEGB / 8u;
+         const uint32_t g = (gsel != 0xFFFFFFFFu && here) ? gsel : 0u;
          uint2 rw;
          uint32_t nv = 8;   // LONG: valid bytes of the group (the row may end inside it)
-         if (LONG) {   // (its segment left the tile: from global memory)
+         if (LONG && !HALFROW) {   // (its segment left the tile: from global memory)
             rw = make_uint2(0, 0);
             if (row_ok) {
                const uint8_t* rp = rows + row * (int64_t)L;
@@ -682,11 +788,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
 #pragma unroll
          for (int i = 7; i >= 0; --i) {
             const uint32_t nx = fxstep(f[i], st, TRp);
-            const bool on = !LONG || (uint32_t)i < nv;   // (per lane)
+            const bool on = !LONG || HALFROW || (uint32_t)i < nv;   // (per lane)
             st = on ? nx : st;
             loc = on && nx >= fp.hit_min ? (uint32_t)i : loc;
          }
-         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
+         s = gsel != 0xFFFFFFFFu ? (here ? g * 8u + 2u + loc : s_half) : 0u;
          const F fz = tabR[0];   // leading NUL
          state = fxstep(fz, state, TRp);
          s = state >= fp.hit_min ? 1u : s;
@@ -719,7 +825,9 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // flags only: a start inside the text always gives to >= from >= 1, so only starts at the leading NUL need the walk.
       // The row is extended virtually: position L holds the trailing NUL (byte 0 -> F[0]), later positions kill the state;
       // an accept after consuming position `pos` gives max_match = pos + 3 for text bytes and for the trailing NUL alike.
-      uint32_t cur = (s != 0 && !nonascii && (SPANS || s == 1) && fp.lit_len == 0) ? fp.A_init : 0u;
+      // (half-row staging: a start in the right half had its forward pass while that half was in LDS -- mm_half)
+      const bool fwd_here = !HALFROW || s != s_half || s == 0u;
+      uint32_t cur = (s != 0 && fwd_here && !nonascii && (SPANS || s == 1) && fp.lit_len == 0) ? fp.A_init : 0u;
       uint32_t mm = (fp.lit_len != 0 && s != 0) ? s + fp.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
@@ -728,79 +836,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          mm = cur >= fp.acc_min ? 2u : 0u;
       }
       STAMP(3);
-      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-         // First 32 symbols from j, straight-line: five aligned 8-byte row reads, a byte shift to start exactly at j,
-         // all 32 table lookups issued before the chain; per 8-byte group only "any accept" (v_max3) + entry state
-         // are kept and the last accepting group is re-walked for the exact byte.
-         uint32_t o[8];
-         fetch32<RAGGED, LONG>(o, fsrc, lane, j, (uint32_t)L);
-         constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
-         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
-#pragma unroll
-         for (int gb = 0; gb < 4; gb += GB) {
-            F f[8 * GB];
-#pragma unroll
-            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
-#pragma unroll
-            for (int g = 0; g < GB; ++g) {
-               const uint32_t entry = cur;
-               uint32_t st[8];
-#pragma unroll
-               for (int q = 0; q < 8; ++q) {
-                  cur = fxstep(f[8 * g + q], cur, TAp);
-                  st[q] = cur;
-               }
-               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-               const bool hit = mx >= fp.acc_min;
-               gl = hit ? (uint32_t)(gb + g) : gl;
-               el = hit ? entry : el;
-               blo = hit ? o[2 * (gb + g)] : blo;
-               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
-            }
-         }
-         {
-            F fr8[8];
-            lookup8(fr8, blo, bhi, tabA);
-            uint32_t st = el, loc = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-               st = fxstep(fr8[q], st, TAp);
-               loc = st >= fp.acc_min ? (uint32_t)q : loc;
-            }
-            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
-         }
-         j += 32u;
-         STAMP(4);
-         // matches longer than the window: 8 symbols per round trip.  The stream is a rolling window of two aligned 8-byte groups
-         // (t0, t1); the group after them is read one round ahead, so a round waits for its table lookups only.  Wave-uniform: dead
-         // lanes (state 0 is absorbing and below acc_min) ride along.
-         if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-            const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
-            uint32_t gb = j & ~7u;
-            uint32_t t0[2], t1[2];
-            group_words<RAGGED, LONG>(t0[0], t0[1], fsrc, lane, gb, (uint32_t)L);
-            group_words<RAGGED, LONG>(t1[0], t1[1], fsrc, lane, gb + 8u, (uint32_t)L);
-            do {
-               uint32_t t2[2];
-               group_words<RAGGED, LONG>(t2[0], t2[1], fsrc, lane, gb + 16u, (uint32_t)L);
-               const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
-               const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
-               F f8[8];
-               lookup8(f8, o0, o1, tabA);
-               uint32_t loc = 8;
-#pragma unroll
-               for (int q = 0; q < 8; ++q) {
-                  cur = fxstep(f8[q], cur, TAp);
-                  loc = cur >= fp.acc_min ? (uint32_t)q : loc;
-               }
-               mm = loc != 8u ? j + loc + 3u : mm;
-               j += 8u;
-               gb += 8u;
-               t0[0] = t1[0]; t0[1] = t1[1];
-               t1[0] = t2[0]; t1[1] = t2[1];
-            } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
-         }
-      }
+      forward_pass(std::integral_constant<bool, LONG>{}, fsrc, (uint32_t)L, cur, mm, j);
+      if (HALFROW && !fwd_here && fp.lit_len == 0) mm = mm_half;
       STAMP(5);
       uint32_t flag = 0;
       int32_t fr = 0, tt = 0;
@@ -1108,7 +1145,9 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(n_deferred) ^ 16u);   // the other parity's group of four words (32-byte aligned block)
    const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;   // (worklist pass: the host only knows an upper bound)
    int64_t blocks = (n_tiles + 3) / 4;
-   const int64_t cap = MODE == 4 ? 256 : 256 * 8;   // grid-stride beyond this (guide §6 G11)
+   // grid-stride beyond the cap (guide §6 G11); a whole number of rounds of what is resident (two blocks per CU at 256-byte rows,
+   // three with half-row staging), so that the last round fills the chip too
+   const int64_t cap = MODE == 4 ? 256 : ((CH == 8 && Lr > 16u * CH) ? 256 * 9 : 256 * 8);
    if (blocks > cap) blocks = cap;
    // decode passes: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;

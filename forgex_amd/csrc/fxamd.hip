@@ -343,8 +343,8 @@ struct PassOpts {
 };
 // 256-byte rows on the 8-state tables: half-row staging (8 KB of LDS per wave: three waves per SIMD instead of two)
 static bool half_rows(int scheme, int64_t row_len) {
-   static const bool on = std::getenv("FXAMD_HALF") != nullptr;
-   return on && scheme == 0 && row_len == 256;
+   const bool off = std::getenv("FXAMD_NO_HALF") != nullptr;   // (test / experiment hook: 256-byte rows on the one-launch kernel)
+   return !off && scheme == 0 && row_len == 256;
 }
 
 template <int MODE, int SCH>
@@ -574,7 +574,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
       PassOpts first, marked, listp;
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
-      first.half = !is_match && half_rows(scheme, row_len);
+      // 256-byte rows on the 8-state tables keep the multi-pass pipeline: its first pass stages HALF rows when spans are asked for
+      // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
+      const bool keep_multipass = !is_match && half_rows(scheme, row_len);
+      first.half = keep_multipass && d_from != nullptr;
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
       if (bytes || !utf8_tables) {
@@ -612,7 +615,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          p->last_path = 1 + big;
          return FXAMD_OK;
       }
-      if (!is_match && utf8_tables && !first.half && !std::getenv("FXAMD_MULTIPASS")) {
+      if (!is_match && utf8_tables && !keep_multipass && !std::getenv("FXAMD_MULTIPASS")) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
          // the in-LDS decode on the others, exception rows through per-wave queues); last_path 9 / 10 / 11
          const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
@@ -796,6 +799,14 @@ int fxamd_program_info(const fxamd_program* p, int32_t* info) {
    return FXAMD_OK;
 }
 const char* fxamd_strerror(int32_t status) { return fxfe::status_message(status); }
+int64_t fxamd_strerror_copy(int32_t status, char* buf, int64_t capacity) {
+   if (!buf || capacity <= 0) return 0;
+   const char* m = fxfe::status_message(status);
+   int64_t n = (int64_t)std::strlen(m);
+   if (n > capacity) n = capacity;
+   std::memcpy(buf, m, (size_t)n);
+   return n;
+}
 
 int fxamd_program_upload(fxamd_program* p) {
    if (!p) return FXAMD_E_ARG;
@@ -847,7 +858,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   po.half = half_rows(scheme, row_len);
+   po.half = half_rows(scheme, row_len) && d_from != nullptr;
    if (scheme != 0 && bytes && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));

@@ -2,20 +2,30 @@
 !
 ! Same public names as the reference module (reference src/forgex.F90:24-54):
 !     is_valid_regex, operator(.in.), operator(.match.), regex, regex_f
-! with the same argument meaning and error behaviour, bound through iso_c_binding to the C ABI of
+! with the same argument lists, the same PURITY (`pure elemental` operators and is_valid_regex, `pure` regex / regex_f:
+! reference src/forgex.F90:58,74,163,235,351) and the same error behaviour, bound through iso_c_binding to the C ABI of
 ! include/forgex_amd.h (libforgex_amd.so: host table compiler + HIP kernels for gfx950).
 !
-! Differences a maintainer should know (INTEGRATION.md):
-!   * the specifics are IMPURE (they call the GPU library); the reference's own `IMPURE` build switch
-!     (reference src/forgex.F90:10-13) is the precedent.  `impure elemental` keeps every array shape working.
-!   * rank-1 character arrays resolve to NON-elemental batch specifics (a non-elemental specific is preferred over an
+! What a maintainer should know (INTEGRATION.md):
+!   * The C entry points are declared PURE in the interface block below.  That is the contract the library keeps: a call's
+!     results depend on its arguments only, nothing the caller can observe is modified, handles are thread-safe -- so the
+!     public procedures keep the reference's `pure` / `elemental` attributes and stay callable from pure procedures and
+!     `do concurrent`.  (The reference's own IMPURE switch, src/forgex.F90:10-13, is available here too: -DIMPURE.)
+!   * Rank-1 character arrays resolve to NON-elemental batch specifics (a non-elemental specific is preferred over an
 !     elemental one), so `pattern .in. strs(:)` compiles the pattern ONCE and matches all rows in one kernel launch
-!     instead of re-parsing the pattern per element (reference src/forgex.F90:98,139-140).
+!     instead of re-parsing the pattern per element (reference src/forgex.F90:98,139-140); `patterns(:) .in. strs(:)`
+!     compiles every DISTINCT pattern once and matches the rows of each in one batch.
 !   * `regex` gains a batch form returning from(:)/to(:) for a rank-1 text array.
-!   * there is no CPU matching path: without a HIP device the calls stop with an error message.
+!   * There is no CPU matching path: without a HIP device the calls stop with an error message.
+#if defined(IMPURE)
+#define PURE_
+#define ELEMENTAL_ impure elemental
+#else
+#define PURE_ pure
+#define ELEMENTAL_ pure elemental
+#endif
 module forgex
    use, intrinsic :: iso_c_binding
-   use, intrinsic :: iso_fortran_env, only: error_unit
    implicit none
    private
 
@@ -29,7 +39,7 @@ module forgex
    integer, parameter :: INVALID_CHAR_INDEX = -9999
 
    interface
-      function fxamd_compile(pattern, pattern_len, op, prog, status) bind(C, name='fxamd_compile') result(rc)
+      PURE_ function fxamd_compile(pattern, pattern_len, op, prog, status) bind(C, name='fxamd_compile') result(rc)
          import :: c_char, c_int64_t, c_int, c_ptr, c_int32_t
          character(kind=c_char), intent(in) :: pattern(*)
          integer(c_int64_t), value :: pattern_len
@@ -38,20 +48,22 @@ module forgex
          integer(c_int32_t), intent(out) :: status
          integer(c_int) :: rc
       end function
-      subroutine fxamd_program_free(prog) bind(C, name='fxamd_program_free')
+      PURE_ subroutine fxamd_program_free(prog) bind(C, name='fxamd_program_free')
          import :: c_ptr
          type(c_ptr), value :: prog
       end subroutine
-      function fxamd_match_batch_host(prog, rows, n, row_len, flags, from, to) bind(C, name='fxamd_match_batch_host') result(rc)
+      PURE_ function fxamd_match_batch_host(prog, rows, n, row_len, flags, from, to) bind(C, name='fxamd_match_batch_host') result(rc)
          import :: c_ptr, c_int64_t, c_int
          type(c_ptr), value :: prog, rows, flags, from, to
          integer(c_int64_t), value :: n, row_len
          integer(c_int) :: rc
       end function
-      function fxamd_strerror(status) bind(C, name='fxamd_strerror') result(msg)
-         import :: c_int32_t, c_ptr
+      PURE_ function fxamd_strerror_copy(status, buf, cap) bind(C, name='fxamd_strerror_copy') result(n)
+         import :: c_int32_t, c_char, c_int64_t
          integer(c_int32_t), value :: status
-         type(c_ptr) :: msg
+         character(kind=c_char), intent(inout) :: buf(*)
+         integer(c_int64_t), value :: cap
+         integer(c_int64_t) :: n
       end function
    end interface
 
@@ -62,11 +74,13 @@ module forgex
    interface operator(.in.)
       module procedure :: operator__in
       module procedure :: operator__in_batch
+      module procedure :: operator__in_patterns
    end interface
 
    interface operator(.match.)
       module procedure :: operator__match
       module procedure :: operator__match_batch
+      module procedure :: operator__match_patterns
    end interface
 
    interface regex
@@ -80,47 +94,41 @@ module forgex
 
 contains
 
-   function error_message(code) result(msg)
+   !> get_error_message of the reference (src/essential/error_m.F90:127-211), from the library's table
+   PURE_ function error_message(code) result(msg)
       integer, intent(in) :: code
       character(:), allocatable :: msg
-      type(c_ptr) :: p
-      character(kind=c_char), pointer :: s(:)
-      integer :: n
-      p = fxamd_strerror(int(code, c_int32_t))
-      call c_f_pointer(p, s, [1024])
-      n = 0
-      do while (n < 1024)
-         if (s(n+1) == c_null_char) exit
-         n = n + 1
+      character(kind=c_char) :: buf(256)
+      integer(c_int64_t) :: n
+      integer :: i
+      n = fxamd_strerror_copy(int(code, c_int32_t), buf, int(size(buf), c_int64_t))
+      allocate(character(int(n)) :: msg)
+      do i = 1, int(n)
+         msg(i:i) = buf(i)
       end do
-      allocate(character(n) :: msg)
-      msg = transfer(s(1:n), msg)
    end function error_message
 
-   subroutine compile(pattern, op, prog, status)
+   PURE_ subroutine compile(pattern, op, prog, status)
       character(*), intent(in) :: pattern
       integer(c_int), intent(in) :: op
       type(c_ptr), intent(out) :: prog
       integer, intent(out) :: status
       integer(c_int32_t) :: st
       integer(c_int) :: rc
-      character(kind=c_char), allocatable :: buf(:)
-      allocate(buf(max(1, len(pattern))))
-      if (len(pattern) > 0) buf = transfer(pattern, buf)
+      character(kind=c_char) :: buf(max(1, len(pattern)))
+      integer :: i
+      do i = 1, len(pattern)
+         buf(i) = pattern(i:i)
+      end do
       rc = fxamd_compile(buf, int(len(pattern), c_int64_t), op, prog, st)
-      if (rc /= 0) then
-         write(error_unit, '(a,i0)') 'forgex (amd): fxamd_compile failed, rc=', rc
-         error stop
-      end if
+      if (rc /= 0) error stop 'forgex (amd): fxamd_compile failed'
       status = int(st)
-      if (status >= 100) then   ! where the reference itself would `error stop` (state limits, SURVEY.md section 5)
-         write(error_unit, '(a)') 'forgex (amd): '//error_message(status)
-         error stop
-      end if
+      ! where the reference itself would `error stop` (tree / NFA / DFA limits, SURVEY.md section 5)
+      if (status >= 100) error stop 'forgex (amd): pattern exceeds the limits of the automaton builder (status >= 100)'
    end subroutine compile
 
    !> run one batch: rows = storage of character(row_len) :: s(n)
-   subroutine run_batch(prog, rows, n, row_len, flags, from, to)
+   PURE_ subroutine run_batch(prog, rows, n, row_len, flags, from, to)
       type(c_ptr), intent(in) :: prog, rows
       integer, intent(in) :: n, row_len
       integer(c_int8_t), intent(inout), target :: flags(:)
@@ -132,40 +140,43 @@ contains
       else
          rc = fxamd_match_batch_host(prog, rows, int(n, c_int64_t), int(row_len, c_int64_t), c_loc(flags), c_null_ptr, c_null_ptr)
       end if
-      if (rc /= 0) then
-         write(error_unit, '(a,i0,a)') 'forgex (amd): fxamd_match_batch_host failed, rc=', rc, &
-            ' (the match path needs a HIP device; there is no CPU fallback)'
-         error stop
-      end if
+      if (rc /= 0) error stop 'forgex (amd): fxamd_match_batch_host failed (the match path needs a HIP device; there is no CPU fallback)'
    end subroutine run_batch
 
-   impure elemental function is_valid_regex_pattern(pattern) result(res)
+   ELEMENTAL_ function is_valid_regex_pattern(pattern) result(res)
       character(*), intent(in) :: pattern
       logical :: res
       type(c_ptr) :: prog
-      integer :: status
-      call compile(pattern, FXAMD_OP_SEARCH, prog, status)
-      res = status == 0
+      integer(c_int32_t) :: st
+      integer(c_int) :: rc
+      character(kind=c_char) :: buf(max(1, len(pattern)))
+      integer :: i
+      do i = 1, len(pattern)
+         buf(i) = pattern(i:i)
+      end do
+      rc = fxamd_compile(buf, int(len(pattern), c_int64_t), FXAMD_OP_SEARCH, prog, st)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_compile failed'
+      res = st == 0 .or. st >= 100     ! (beyond the builder's limits is still a VALID pattern)
       call fxamd_program_free(prog)
    end function is_valid_regex_pattern
 
    !---------------------------------------------------------------------------------------------------------------
-   ! batch specifics: pattern compiled once, all rows in one launch
-   function operator__in_batch(pattern, str) result(res)
+   ! batch specifics: pattern compiled once, all rows in one call
+   PURE_ function operator__in_batch(pattern, str) result(res)
       character(*), intent(in) :: pattern
       character(*), intent(in), target, contiguous :: str(:)
       logical :: res(size(str))
       res = flags_batch(pattern, str, FXAMD_OP_SEARCH)
    end function operator__in_batch
 
-   function operator__match_batch(pattern, str) result(res)
+   PURE_ function operator__match_batch(pattern, str) result(res)
       character(*), intent(in) :: pattern
       character(*), intent(in), target, contiguous :: str(:)
       logical :: res(size(str))
       res = flags_batch(pattern, str, FXAMD_OP_MATCH)
    end function operator__match_batch
 
-   function flags_batch(pattern, str, op) result(res)
+   PURE_ function flags_batch(pattern, str, op) result(res)
       character(*), intent(in) :: pattern
       character(*), intent(in), target, contiguous :: str(:)
       integer(c_int), intent(in) :: op
@@ -185,26 +196,81 @@ contains
    end function flags_batch
 
    !---------------------------------------------------------------------------------------------------------------
-   ! elemental specifics (scalars and arrays of any other rank): one row per call
-   impure elemental function operator__in(pattern, str) result(res)
+   ! an ARRAY of patterns against an array of rows, element by element (the elemental contract of the reference's operators,
+   ! src/forgex.F90:74,163, on two conformable arrays): every DISTINCT pattern is compiled once and meets its rows in one batch
+   PURE_ function operator__in_patterns(pattern, str) result(res)
+      character(*), intent(in) :: pattern(:)
+      character(*), intent(in) :: str(:)
+      logical :: res(size(str))
+      res = flags_patterns(pattern, str, FXAMD_OP_SEARCH)
+   end function operator__in_patterns
+
+   PURE_ function operator__match_patterns(pattern, str) result(res)
+      character(*), intent(in) :: pattern(:)
+      character(*), intent(in) :: str(:)
+      logical :: res(size(str))
+      res = flags_patterns(pattern, str, FXAMD_OP_MATCH)
+   end function operator__match_patterns
+
+   PURE_ function flags_patterns(pattern, str, op) result(res)
+      character(*), intent(in) :: pattern(:)
+      character(*), intent(in) :: str(:)
+      integer(c_int), intent(in) :: op
+      logical :: res(size(str))
+      logical :: done(size(str))
+      character(len(str)), allocatable, target :: rows(:)
+      integer, allocatable :: idx(:)
+      logical, allocatable :: r(:)
+      integer :: i, j, m
+      if (size(pattern) /= size(str)) error stop 'forgex (amd): pattern and str arrays do not conform'
+      done = .false.
+      res = .false.
+      do i = 1, size(str)
+         if (done(i)) cycle
+         ! rows that share pattern(i) (compared as the library sees them: byte for byte, trailing blanks included)
+         m = 0
+         allocate(idx(size(str) - i + 1))
+         do j = i, size(str)
+            if (.not. done(j)) then
+               if (pattern(j) == pattern(i)) then
+                  m = m + 1
+                  idx(m) = j
+                  done(j) = .true.
+               end if
+            end if
+         end do
+         allocate(rows(m))
+         do j = 1, m
+            rows(j) = str(idx(j))
+         end do
+         r = flags_batch(pattern(i), rows, op)
+         do j = 1, m
+            res(idx(j)) = r(j)
+         end do
+         deallocate(rows, idx, r)
+      end do
+   end function flags_patterns
+
+   !---------------------------------------------------------------------------------------------------------------
+   ! elemental specifics (scalars and arrays of any other shape): one row per call
+   ELEMENTAL_ function operator__in(pattern, str) result(res)
       character(*), intent(in) :: pattern, str
       logical :: res
       res = flag_one(pattern, str, FXAMD_OP_SEARCH)
    end function operator__in
 
-   impure elemental function operator__match(pattern, str) result(res)
+   ELEMENTAL_ function operator__match(pattern, str) result(res)
       character(*), intent(in) :: pattern, str
       logical :: res
       res = flag_one(pattern, str, FXAMD_OP_MATCH)
    end function operator__match
 
-   function flag_one(pattern, str, op) result(res)
+   PURE_ function flag_one(pattern, str, op) result(res)
       character(*), intent(in) :: pattern, str
       integer(c_int), intent(in) :: op
       logical :: res
-      character(:), allocatable, target :: row(:)
+      character(len(str)), target :: row(1)
       logical :: r(1)
-      allocate(character(len(str)) :: row(1))
       row(1) = str
       r = flags_batch(pattern, row, op)
       res = r(1)
@@ -212,14 +278,13 @@ contains
 
    !---------------------------------------------------------------------------------------------------------------
    !> `call regex(pattern, text, res, length, from, to, status, err_msg)` -- reference src/forgex.F90:235-347
-   subroutine subroutine__regex(pattern, text, res, length, from, to, status, err_msg)
+   PURE_ subroutine subroutine__regex(pattern, text, res, length, from, to, status, err_msg)
       character(*),              intent(in)    :: pattern, text
       character(:), allocatable, intent(inout) :: res
       integer, optional,         intent(inout) :: length, from, to, status
       character(*), optional,    intent(inout) :: err_msg
-      character(:), allocatable, target :: row(:)
+      character(len(text)), target :: row(1)
       integer :: f(1), t(1), st
-      allocate(character(len(text)) :: row(1))
       row(1) = text
       call subroutine__regex_batch(pattern, row, f, t, st)
       if (present(status)) status = st
@@ -245,7 +310,7 @@ contains
    end subroutine subroutine__regex
 
    !> batch form: 1-based byte spans of the leftmost-longest match of every row (0,0 = none; -9999 = invalid pattern)
-   subroutine subroutine__regex_batch(pattern, text, from, to, status)
+   PURE_ subroutine subroutine__regex_batch(pattern, text, from, to, status)
       character(*), intent(in) :: pattern
       character(*), intent(in), target, contiguous :: text(:)
       integer, intent(inout) :: from(:), to(:)
@@ -254,7 +319,8 @@ contains
       integer :: st
       integer(c_int8_t), allocatable, target :: flags(:)
       integer(c_int32_t), allocatable, target :: f(:), t(:)
-      call compile(trim_keep(pattern), FXAMD_OP_SEARCH, prog, st)
+      ! (the pattern goes to the library untrimmed: fxamd_compile applies the reference's own TRIM / ^ / $ handling)
+      call compile(pattern, FXAMD_OP_SEARCH, prog, st)
       if (present(status)) status = st
       if (st /= 0) then
          from = INVALID_CHAR_INDEX
@@ -269,14 +335,7 @@ contains
       call fxamd_program_free(prog)
    end subroutine subroutine__regex_batch
 
-   !> the pattern goes to the library untrimmed: fxamd_compile applies the reference's own TRIM / ^ / $ handling
-   pure function trim_keep(pattern) result(p)
-      character(*), intent(in) :: pattern
-      character(:), allocatable :: p
-      p = pattern
-   end function trim_keep
-
-   function function__regex(pattern, text) result(res)
+   PURE_ function function__regex(pattern, text) result(res)
       character(*), intent(in)  :: pattern, text
       character(:), allocatable :: res
       call subroutine__regex(pattern, text, res)

@@ -66,6 +66,9 @@ int fxamd_program_from_blob(const void* blob, int64_t size, fxamd_program** out)
 /* facts for tests/diagnostics: info[0..7] = mode, flags, nA, nR, n_classes, status, total_bytes, n_bounds */
 int fxamd_program_info(const fxamd_program* p, int32_t* info8);
 const char* fxamd_strerror(int32_t status);
+/* the same message copied (without a terminator) into the caller's buffer; returns its length (<= capacity).  For hosts that
+ * cannot turn a C string into their own without an impure intrinsic (Fortran `pure` procedures: c_f_pointer is impure). */
+int64_t fxamd_strerror_copy(int32_t status, char* buf, int64_t capacity);
 
 /* ---- match (HIP device required) --------------------------------------------------------------------- */
 /* Upload the tables to the current HIP device (idempotent; done lazily by the match calls otherwise). */

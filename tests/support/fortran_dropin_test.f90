@@ -9,7 +9,8 @@ program fortran_dropin_test
    character(256) :: msg
    character(8) :: rows(4)
    character(16) :: texts(3)
-   logical :: flags4(4)
+   logical :: flags4(4), flags22(2, 2)
+   character(12) :: pats(4)
    integer :: f3(3), t3(3)
 
    ok = .true.
@@ -29,6 +30,15 @@ program fortran_dropin_test
    ok = ok .and. all(flags4 .eqv. [.true., .false., .true., .false.])
    flags4 = '\d' .in. rows
    ok = ok .and. all(flags4 .eqv. [.true., .true., .true., .false.])
+
+   ! an ARRAY of patterns against an array of rows, element by element (the operators are elemental in the reference): every
+   ! distinct pattern is compiled once (`.in.` trims the pattern: reference forgex.F90:95)
+   pats = [character(12) :: '\d{3}-\d{4}', '[a-z]+', '\d{3}-\d{4}', 'abc']
+   flags4 = pats .in. rows
+   ok = ok .and. all(flags4 .eqv. [.true., .false., .true., .true.])
+   ! rank-2 arrays still resolve to the elemental specifics
+   flags22 = '\d' .in. reshape(rows, [2, 2])
+   ok = ok .and. all(flags22 .eqv. reshape([.true., .true., .true., .false.], [2, 2]))
 
    ! regex subroutine, scalar
    call regex('foo(bar|baz)', 'xxfoobarbaz', res, length=length, from=from, to=to, status=status, err_msg=msg)
