@@ -17,6 +17,20 @@
 #pragma once
 #include "fx_tile.hpp"
 
+// row accessors of the general procedure: the row in global memory / in lane r's cells of the LDS tile
+struct FxGlobalRow {
+   const uint8_t* p;
+   __device__ __forceinline__ uint32_t operator[](int j) const { return p[j]; }
+};
+struct FxTileRow {
+   const uint8_t* tb;
+   uint32_t lane;
+   __device__ __forceinline__ uint32_t operator[](int j) const {
+      const uint32_t k = (uint32_t)j >> 4;
+      return tb[(tile_cell(lane, k) << 4) + ((uint32_t)j & 15u)];
+   }
+};
+
 template <int SCH_, bool BYTES_, bool DECODED_>
 struct FxScanCfg {
    static constexpr int sch = SCH_;
@@ -26,12 +40,16 @@ struct FxScanCfg {
 // SCH: scheme of the class-level tables (0 v_perm, 1 chain, 2 wide); BSCH: scheme of the byte-level tables (0 = none in this
 // launch, 1 chain, 2 wide).  SCH == 0 && BSCH != 0: per-tile selection.  SCH != 0 && BSCH != 0: the byte-level tables take every
 // tile (the class-level ones are no faster on ASCII), the class-level tables only serve the exception rows.
-template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED>
+// GEN: the program's class-level tables cannot decode UTF-8 (candidate-list driver: a prefix literal proven equal to brute force on
+// pure-ASCII rows only, FXP_F_OVERLAP_SINK programs): rows the tables cannot answer -- exception rows of the byte-level tables,
+// rows with a byte >= 0x80 when there are no byte-level tables, overlap rows of a bordered prefix -- are queued the same way and
+// the gathered rows go through the GENERAL row procedure (fxrow::run_row, the body of fx_general) instead of the decode + scan.
+template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN>
 __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                        uint32_t class_map_in_lds, uint32_t Lr) {
    static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
-   constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0;
+   constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0, POOL = HAS_B || GEN;
    const uint32_t L = RAGGED ? Lr : 16u * CH;
    constexpr bool ragged = RAGGED;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
@@ -40,7 +58,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    __shared__ uint4 wideA[SCH == 2 ? 256 : 1];
    __shared__ uint4 bwideR[BSCH == 2 ? 256 : 1];
    __shared__ uint4 bwideA[BSCH == 2 ? 256 : 1];
-   __shared__ uint32_t pool_q[HAS_B ? 4 * 64 : 1];   // per-wave queues of exception rows
+   __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
    __shared__ uint32_t pool_cnt[4];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
-   uint32_t* myq = pool_q + (HAS_B ? wave * 64u : 0u);
+   uint32_t* myq = pool_q + (POOL ? wave * 64u : 0u);
 
    // ---- one scan of the tile in LDS: backward pass (leftmost start), forward pass (longest end), results -----------------------
    // cfg: table scheme; bytes = byte-level tables on raw bytes; decoded = the tile was rewritten into symbol ids (every byte value
@@ -156,8 +174,13 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             __builtin_amdgcn_sched_barrier(0);
          }
       }
-      // a class-level scan of raw bytes that met a byte >= 0x80: the tile is redone with the byte-level tables / after a decode
-      if (!BYTES && !DECODED && !raw && __builtin_amdgcn_ballot_w64((na & 0x80808080u) != 0) != 0) return true;
+      // a class-level scan of raw bytes that met a byte >= 0x80: the tile is redone with the byte-level tables / after a decode;
+      // a program that has neither (GEN without byte-level tables) hands just those ROWS to the general procedure
+      bool row_hi = false;
+      if (!BYTES && !DECODED && !raw) {
+         row_hi = (na & 0x80808080u) != 0;
+         if ((HAS_B || !GEN) && __builtin_amdgcn_ballot_w64(row_hi) != 0) return true;
+      }
       uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
       {
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
@@ -177,7 +200,8 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          s = state >= P.hit_min ? 1u : s;
       }
       // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8: the row is queued for the decode pass
-      except = BYTES && state == P.inv;
+      // (GEN, class-level tables: a row that ended in the overlap state of a bordered prefix literal, or that holds a byte >= 0x80)
+      except = (BYTES && state == P.inv) || (GEN && !BYTES && !DECODED && ((P.inv_on != 0 && state == P.inv) || row_hi));
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
       uint32_t cur = (s != 0 && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
       uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
@@ -289,17 +313,17 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       bool is_tile = false;
       uint32_t take = 0, take_base = 0;
       if (phase == 0) {
-         if (HAS_B && pend_mask != 0 && pool_n + (uint32_t)__builtin_popcountll(pend_mask) <= 64u) {
+         if (POOL && pend_mask != 0 && pool_n + (uint32_t)__builtin_popcountll(pend_mask) <= 64u) {
             if ((pend_mask >> lane) & 1ull) myq[pool_n + (uint32_t)__builtin_popcountll(pend_mask & ((1ull << lane) - 1ull))] = pend_row;
             pool_n += (uint32_t)__builtin_popcountll(pend_mask);
             pend_mask = 0;
          }
-         if (HAS_B && pend_mask != 0) {
+         if (POOL && pend_mask != 0) {
             take = pool_n;   // the queue has to be drained before the pending rows fit
          } else if (t < n_tiles) {
             is_tile = true;
          } else {
-            if (!HAS_B) break;
+            if (!POOL) break;
             // end of the wave's tiles: merge the block's four queues; each wave then takes every fourth gathered tile
             if (lane == 0) pool_cnt[wave] = pool_n;
             __syncthreads();
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       if (is_tile) {
          row = (t << 6) + lane;
          row_ok = row < n;
-         if (!ALLB && !raw) {
+         if (!ALLB && !raw && (HAS_B || !GEN)) {
             const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
             hint = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
          }
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
          row_ok = lane < take;
          uint32_t ridx = 0;
-         if (HAS_B && row_ok) {
+         if (POOL && row_ok) {
             if (phase == 0) ridx = myq[lane];
             else {
                const uint32_t g = take_base + lane;
@@ -350,8 +374,9 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          row = (int64_t)ridx;
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
          // (four loads in flight: the staging registers hold the next tile's loads and stay untouched)
+         // (ragged rows -- GEN only -- start at any byte: the general procedure reads them from global memory instead)
 #pragma unroll 1
-         for (int k0 = 0; k0 < CH; k0 += 4) {
+         for (int k0 = 0; k0 < (RAGGED ? 0 : CH); k0 += 4) {
             uint4 g4[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) g4[i] = (row_ok && k0 + i < CH) ? src[k0 + i < CH ? k0 + i : 0] : make_uint4(0, 0, 0, 0);
@@ -363,7 +388,13 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       }
       bool except = false;
       bool redo = false;
-      if (is_tile && !ALLB && !hint) redo = scan(FxScanCfg<SCH, false, false>{}, row, row_ok, except);
+      if (is_tile && !ALLB && !hint) {
+         redo = scan(FxScanCfg<SCH, false, false>{}, row, row_ok, except);
+         if (GEN && !redo) {
+            pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
+            pend_row = (uint32_t)row;
+         }
+      }
       const bool nonascii = !is_tile || hint || redo;   // (gathered rows always take the decode)
       if constexpr (HAS_B) {
          if (is_tile && (ALLB || nonascii)) {
@@ -372,7 +403,27 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             pend_row = (uint32_t)row;
          }
       }
-      if ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii)) {
+      if constexpr (GEN) {
+         if (!is_tile && row_ok) {
+            // the general row procedure (every mode, candidate-list driver, UTF-8 decode in both directions): one lane = one queued row
+            fxrow::ProgView pv(prog);
+            fxrow::DfaSim sim(pv);
+            fxrow::Result res;
+            if (RAGGED) {
+               FxGlobalRow gr{rows + row * (int64_t)L};
+               fxrow::run_row(pv, sim, gr, (int)L, res);
+            } else {
+               FxTileRow tr{tb, lane};
+               fxrow::run_row(pv, sim, tr, (int)L, res);
+            }
+            flags[row] = (uint8_t)res.flag;
+            if (SPANS) {
+               from[row] = res.from;
+               to[row] = res.to;
+            }
+         }
+      }
+      if (!GEN && ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii))) {
          // On-device UTF-8 decode, in place in LDS, into fast-path symbol ids (fxrow::translate_cell16); the 4 bytes before / after
          // a cell are taken from the ORIGINAL neighbours.
          if (HAS_B && !is_tile) {
@@ -417,7 +468,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
 }
 
 // FastParams of the class-level tables (fp) and of the byte-level tables (fpb) are prepared by the host (fxamd.hip)
-template <int CH, int SCH, int BSCH>
+template <int CH, int SCH, int BSCH, bool GEN>
 hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
                       uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st) {
    const int64_t n_tiles = (n + 63) >> 6;
@@ -425,11 +476,11 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
    const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 8192 : 0)) + (BSCH == 2 ? 8192 : 0) + 1024 + 64;
-   const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;
-   // Grid: with byte-level tables every block ends with one merged pass over its exception rows, so the grid is sized to what is
+   // Grid: with exception queues every block ends with one merged pass over its queued rows, so the grid is sized to what is
    // RESIDENT (one tail per CU slot, not one per 1/8 of it); without them the usual cap with grid-stride beyond it.
    {
       static const int env_mult = std::getenv("FXAMD_ONE_GRID") ? std::atoi(std::getenv("FXAMD_ONE_GRID")) : 0;
@@ -437,35 +488,36 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       int64_t resident = per_block > 0 ? (int64_t)((160 * 1024) / per_block) : 8;   // blocks per CU by LDS (the binding resource of these kernels)
       if (resident < 1) resident = 1;
       if (resident > 8) resident = 8;
-      const int64_t cap = 256 * (env_mult > 0 ? env_mult : (BSCH != 0 ? resident : 8));
+      const int64_t cap = 256 * (env_mult > 0 ? env_mult : ((BSCH != 0 || GEN) ? resident : 8));
       if (blocks > cap) blocks = cap;
    }
    if (ragged) {
       if constexpr (BSCH == 0) {
-         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true>);
+         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true, GEN>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN>);
          if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
-         if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
-         else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+         if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+         else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
          return hipGetLastError();
       } else {
          return hipErrorInvalidValue;   // (never dispatched: byte-level tables need whole chunks)
       }
    }
-   const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, BSCH, false>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, BSCH, false>);
+   const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, BSCH, false, GEN>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, BSCH, false, GEN>);
    if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
-   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
-   else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+   else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
    return hipGetLastError();
 }
 
-// every (CH, SCH, BSCH) the dispatch code of fxamd.hip can ask for
-#define FX_ONE_COMBOS(X, CH) X(CH, 0, 0) X(CH, 1, 0) X(CH, 2, 0) X(CH, 0, 1) X(CH, 0, 2) X(CH, 1, 1) X(CH, 1, 2) X(CH, 2, 1) X(CH, 2, 2)
+// every (CH, SCH, BSCH, GEN) the dispatch code of fxamd.hip can ask for
+#define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)
+#define FX_ONE_COMBOS(X, CH) FX_ONE_COMBOS_G(X, CH, false) FX_ONE_COMBOS_G(X, CH, true)
 #define FX_ONE_ALL(X) \
    FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 3) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 6) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)
 #define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t)

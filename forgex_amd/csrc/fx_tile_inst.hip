@@ -8,6 +8,6 @@
 FX_TILE_COMBOS(FX_X, FX_INST_CH)
 #undef FX_X
 
-#define FX_Y(CH, S, B) template hipError_t launch_one<CH, S, B> FX_ONE_SIG;
+#define FX_Y(CH, S, B, G) template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_COMBOS(FX_Y, FX_INST_CH)
 #undef FX_Y

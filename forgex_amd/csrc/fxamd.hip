@@ -19,7 +19,7 @@
    extern template hipError_t launch_match<CH, M, S> FX_TILE_SIG_MATCH;
 FX_TILE_ALL(FX_X)
 #undef FX_X
-#define FX_X(CH, S, B) extern template hipError_t launch_one<CH, S, B> FX_ONE_SIG;
+#define FX_X(CH, S, B, G) extern template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_ALL(FX_X)
 #undef FX_X
 #endif
@@ -466,9 +466,13 @@ static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
       fp.hit_min = h.chain_hit_min;
       fp.acc_min = h.chain_acc_min;
    }
+   if (!bytes && (h.flags & FXP_F_OVERLAP_SINK)) {   // bordered prefix literal: rows whose backward pass ends in R's overlap state
+      fp.inv_on = 1u;
+      fp.inv = sch == 2 ? (h.R_inv < 8u ? h.R_inv : 0x80u + h.R_inv - 8u) * 0x01010101u : (sch == 1 ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
+   }
    return fp;
 }
-template <int SCH, int BSCH>
+template <int SCH, int BSCH, bool GEN>
 static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                                 int32_t* d_from, int32_t* d_to, hipStream_t st) {
    const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -477,21 +481,23 @@ static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const
                                 (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
    const uint32_t Lr = (uint32_t)row_len;
    switch (tile_chunks(row_len)) {
-      case 1: return launch_one<1, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 2: return launch_one<2, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 3: return launch_one<3, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 4: return launch_one<4, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 6: return launch_one<6, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 8: return launch_one<8, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 12: return launch_one<12, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      default: return launch_one<16, SCH, BSCH>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 4: return launch_one<4, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 6: return launch_one<6, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 8: return launch_one<8, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 12: return launch_one<12, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      default: return launch_one<16, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
    }
 }
 // bsch: 0 = no byte-level tables for these rows, 1 chain, 2 wide
-static hipError_t launch_one_any(int sch, int bsch, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
+static hipError_t launch_one_any(int sch, int bsch, bool gen, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                  uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
-#define FX_ONE_CASE(S, B) \
-   if (sch == S && bsch == B) return launch_one_ch<S, B>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st);
+#define FX_ONE_CASE(S, B)                                                                                                        \
+   if (sch == S && bsch == B)                                                                                                     \
+      return gen ? launch_one_ch<S, B, true>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st)                           \
+                 : launch_one_ch<S, B, false>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st);
    FX_ONE_CASE(0, 0) FX_ONE_CASE(1, 0) FX_ONE_CASE(2, 0) FX_ONE_CASE(0, 1) FX_ONE_CASE(0, 2) FX_ONE_CASE(1, 1) FX_ONE_CASE(1, 2) FX_ONE_CASE(2, 1) FX_ONE_CASE(2, 2)
 #undef FX_ONE_CASE
    return hipErrorInvalidValue;
@@ -578,6 +584,16 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
       const bool keep_multipass = !is_match && half_rows(scheme, row_len);
       first.half = keep_multipass && d_from != nullptr;
+      if (!is_match && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !keep_multipass && !std::getenv("FXAMD_MULTIPASS")) {
+         // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
+         // the in-LDS decode on the others, exception rows through per-wave queues -- decoded in LDS, or, for programs whose tables
+         // cannot decode, through the general row procedure); last_path 9 / 10 / 11 (12 / 13 / 14: general procedure for the queued rows)
+         const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
+         const bool gen = !utf8_tables;
+         FX_HIP(launch_one_any(scheme, ob, gen, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
+         p->last_path = (ob == 0 ? 9 : (scheme == 0 ? 10 : 11)) + (gen ? 3 : 0);
+         return FXAMD_OK;
+      }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
       if (bytes || !utf8_tables) {
@@ -613,14 +629,6 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
          FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          p->last_path = 1 + big;
-         return FXAMD_OK;
-      }
-      if (!is_match && utf8_tables && !keep_multipass && !std::getenv("FXAMD_MULTIPASS")) {
-         // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
-         // the in-LDS decode on the others, exception rows through per-wave queues); last_path 9 / 10 / 11
-         const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
-         FX_HIP(launch_one_any(scheme, ob, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
-         p->last_path = ob == 0 ? 9 : (scheme == 0 ? 10 : 11);
          return FXAMD_OK;
       }
       if (bytes && scheme != 0) {

@@ -84,7 +84,7 @@ def test_config_rows_vs_oracle(fx, cfg, n):
     _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
     assert np.array_equal(f2, of)
     if cfg in ("cfg2", "cfg3", "cfg5"):
-        assert prog.last_path() in (1, 3, 8, 9, 10, 11)   # tile kernels (9-11: the one-launch kernel)
+        assert prog.last_path() in (1, 3, 8, 9, 10, 11, 12, 13, 14)   # tile kernels (9-11: the one-launch kernel)
 
 
 def test_fast_and_general_kernels_agree(fx):
@@ -95,7 +95,7 @@ def test_fast_and_general_kernels_agree(fx):
     pat = synth.PATTERNS["cfg3"]
     p = fx.Program(pat, fx.OP_SEARCH)
     f1, a1, b1 = p.match_device(rows)
-    assert p.last_path() in (1, 3, 8, 9, 10, 11)
+    assert p.last_path() in (1, 3, 8, 9, 10, 11, 12, 13, 14)
     # the same rows at a base address that is not 16-byte aligned: the tile kernels decline, the general kernel takes them
     buf = torch.empty(rows.numel() + 1, dtype=torch.uint8, device=rows.device)
     wide = buf[1:].view(rows.shape)
@@ -313,7 +313,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
         rows_m = np.stack(mixed)
         for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]])):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11), (pat, L)   # (2: chain tables too large for LDS next to the tiles)
+            assert prog.last_path() in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14), (pat, L)   # (2: chain tables too large for LDS next to the tiles)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -351,9 +351,9 @@ def test_utf8_rows_byte_tables_and_decode_pass(fx, monkeypatch):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             if bytes_on:
                 assert prog.info()["flags"] & 4096, pat
-                assert prog.last_path() in (7, 8, 10, 11), (pat, prog.last_path())
+                assert prog.last_path() in (7, 8, 10, 11, 13, 14), (pat, prog.last_path())
             else:
-                assert prog.last_path() in (1, 3, 5, 6, 9), (pat, prog.last_path())
+                assert prog.last_path() in (1, 3, 5, 6, 9, 12), (pat, prog.last_path())
             assert np.array_equal(f, of), (pat, bytes_on)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, bytes_on)
             _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
@@ -388,7 +388,7 @@ def test_chain_scheme_patterns_vs_oracle(fx, wide, monkeypatch):
                 off = int(nrng.integers(0, L - len(sd)))
                 rows[i, off:off + len(sd)] = sd
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (5, 6, 7, 9, 11), (pat, L, prog.last_path())
+            assert prog.last_path() in (5, 6, 7, 9, 11, 12, 14), (pat, L, prog.last_path())
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -587,7 +587,7 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
         for pat in (rb"--[a-z]+", rb"aa[bc]", rb"abab\d", rb"zz\d+", rb"aba[a-z]+", rb"aba[a-z]*y", rb"aa.*b0", rb"--[a-z ]+--"):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             assert prog.info()["flags"] & 0x20000, pat
-            assert prog.last_path() in (3, 6), (pat, L, prog.last_path())
+            assert prog.last_path() in (3, 6, 12), (pat, L, prog.last_path())
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -604,7 +604,7 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
     rows[1::2, 9] = 0xE9
     rows[1::4, 20:23] = np.frombuffer(b"aab", dtype=np.uint8)
     prog, f, a, b = _device_run(fx, rb"aa[bc]", fx.OP_SEARCH, rows)
-    assert prog.last_path() == 3
+    assert prog.last_path() in (3, 12)
     of, oa, ob = oracle_lib.batch(2, rb"aa[bc]", rows, NT)
     assert np.array_equal(f, of) and np.array_equal(a, oa) and np.array_equal(b, ob)
     assert 0 < int(of.sum()) < n
@@ -789,7 +789,7 @@ def test_one_launch_kernel_exception_queues_vs_multipass_and_oracle(fx, bad_frac
             prog = fx.Program(pat, fx.OP_SEARCH)
             f1, a1, b1 = prog.match_device(rows)
             torch.cuda.synchronize()
-            assert prog.last_path() in (9, 10, 11), (pat, prog.last_path())
+            assert prog.last_path() in (9, 10, 11, 12, 13, 14), (pat, prog.last_path())
             ff, _, _ = prog.match_device(rows, spans=False)
             torch.cuda.synchronize()
             monkeypatch.setenv("FXAMD_MULTIPASS", "1")
@@ -797,7 +797,7 @@ def test_one_launch_kernel_exception_queues_vs_multipass_and_oracle(fx, bad_frac
             ref = fx.Program(pat, fx.OP_SEARCH)
             f2, a2, b2 = ref.match_device(rows)
             torch.cuda.synchronize()
-            assert ref.last_path() in (1, 5, 7, 8), (pat, ref.last_path())
+            assert ref.last_path() in (1, 3, 5, 6, 7, 8), (pat, ref.last_path())
             bad = torch.nonzero((f1 != f2) | (a1 != a2) | (b1 != b2))
             assert bad.numel() == 0, (cfg, pat, bad_frac, wide, int(bad[0]), int(f1[bad[0]]), int(a1[bad[0]]), int(b1[bad[0]]), int(f2[bad[0]]), int(a2[bad[0]]), int(b2[bad[0]]))
             assert torch.equal(ff, f2), (cfg, pat, bad_frac, "flags only")
