@@ -1187,12 +1187,17 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       h.off_chain_TA = bl.put(cta.data(), cta.size() * 2);
    }
 
-   // ---- 8b. 16-state v_perm tables for automata with 9..16 states (same conditions as the 8-state fast tables) ----------------------
-   auto enc16 = [](int i) -> uint8_t { return static_cast<uint8_t>(i < 8 ? i : 0x80 + i - 8); };
+   // ---- 8b. 16-state nibble tables for automata with 9..16 states (same conditions as the 8-state fast tables) ----------------------
+   // NIBBLE format: per symbol 8 bytes = 16 nibbles, nibble j = next state of state j (states are plain ids 0..15)
+   auto enc16 = [](int i) -> uint8_t { return static_cast<uint8_t>(i); };
    auto min16 = [&](int first_out, int n) -> uint32_t { return first_out >= n ? 0xFFu : enc16(first_out); };   // "no such state": never reached
+   auto put_nib = [](std::vector<uint8_t>& t, uint32_t sym, int st, int next) {
+      uint8_t& b = t[sym * 8u + static_cast<uint32_t>(st >> 1)];
+      b = static_cast<uint8_t>((st & 1) ? ((b & 0x0F) | (next << 4)) : ((b & 0xF0) | (next & 15)));
+   };
    {
       const bool w16 = !fast && (is_match ? A.n <= 16 : (brute_equiv && A.n <= 16 && R.n <= 16));
-      std::vector<uint8_t> wa(256 * 16, 0), wr(256 * 16, 0);
+      std::vector<uint8_t> wa(256 * 8, 0), wr(256 * 8, 0);
       if (w16) {
          auto put = [&](uint32_t sym, int c_or_neg, bool skip) {   // one symbol row of both tables; c < 0: all-dead (KILL)
             for (int st = 0; st < 16; ++st) {
@@ -1204,8 +1209,8 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                   ta = st < A.n ? TA(st, c_or_neg) : 0;
                   tr = (!is_match && st < R.n) ? TR(st, c_or_neg) : 0;
                }
-               wa[sym * 16 + static_cast<uint32_t>(st)] = enc16(ta);
-               wr[sym * 16 + static_cast<uint32_t>(st)] = enc16(tr);
+               put_nib(wa, sym, st, ta);
+               put_nib(wr, sym, st, tr);
             }
          };
          for (uint32_t b = 0; b < 128; ++b) put(b, ac[b], false);
@@ -1308,12 +1313,12 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                h.byte_inv_R = is_match ? 0u : static_cast<uint32_t>(Rb.inv) * row_bytes;
                // the same automata in the 16-state v_perm format, indexed by the raw byte
                if (Ab.d.n <= 16 && (is_match || Rb.d.n <= 16)) {
-                  bwa.assign(256 * 16, 0);
-                  bwr.assign(256 * 16, 0);
+                  bwa.assign(256 * 8, 0);
+                  bwr.assign(256 * 8, 0);
                   for (int b = 0; b < 256; ++b)
                      for (int st2 = 0; st2 < 16; ++st2) {
-                        bwa[static_cast<size_t>(b) * 16 + st2] = enc16(st2 < Ab.d.n ? Ab.d.T[static_cast<size_t>(st2) * 256 + b] : 0);
-                        bwr[static_cast<size_t>(b) * 16 + st2] = enc16((!is_match && st2 < Rb.d.n) ? Rb.d.T[static_cast<size_t>(st2) * 256 + b] : 0);
+                        put_nib(bwa, static_cast<uint32_t>(b), st2, st2 < Ab.d.n ? Ab.d.T[static_cast<size_t>(st2) * 256 + b] : 0);
+                        put_nib(bwr, static_cast<uint32_t>(b), st2, (!is_match && st2 < Rb.d.n) ? Rb.d.T[static_cast<size_t>(st2) * 256 + b] : 0);
                      }
                   h.flags |= FXP_F_BYTE_W16;
                   h.bw16_acc_min = min16(accmin, Ab.d.n);
@@ -1524,7 +1529,7 @@ int validate_blob(const uint8_t* b, size_t size) {
       } else if (h.chain_TR_bytes != 0 && !inside(h.off_chain_TR, h.chain_TR_bytes)) return 57;
    } else if (h.flags & FXP_F_CHAIN_UTF8) return 58;
    if (h.flags & FXP_F_W16_OK) {
-      if (!inside(h.off_w16A, 4096) || !inside(h.off_w16R, 4096)) return 60;
+      if (!inside(h.off_w16A, 2048) || !inside(h.off_w16R, 2048)) return 60;
    } else if (h.flags & FXP_F_W16_UTF8) return 61;
    if (h.flags & FXP_F_BYTE_DFA) {
       const uint32_t bc = h.byte_n_classes;
@@ -1535,7 +1540,7 @@ int validate_blob(const uint8_t* b, size_t size) {
          if (!chain_ok(h.off_byte_cls, h.off_byte_TR, h.byte_TR_bytes, bc, h.byte_row_bytes, true)) return 65;
          if (!state_ok(h.byte_R_start, h.byte_TR_bytes, h.byte_row_bytes)) return 66;
       } else if (h.byte_TR_bytes != 0 && !inside(h.off_byte_TR, h.byte_TR_bytes)) return 67;
-      if ((h.flags & FXP_F_BYTE_W16) && (!inside(h.off_bw16A, 4096) || !inside(h.off_bw16R, 4096))) return 68;
+      if ((h.flags & FXP_F_BYTE_W16) && (!inside(h.off_bw16A, 2048) || !inside(h.off_bw16R, 2048))) return 68;
    } else if (h.flags & FXP_F_BYTE_W16) return 69;
    return 0;
 }

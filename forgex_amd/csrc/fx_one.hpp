@@ -54,10 +54,10 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    constexpr bool ragged = RAGGED;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
    __shared__ uint2 permA[SCH == 0 ? 256 : 1];
-   __shared__ uint4 wideR[SCH == 2 ? 256 : 1];
-   __shared__ uint4 wideA[SCH == 2 ? 256 : 1];
-   __shared__ uint4 bwideR[BSCH == 2 ? 256 : 1];
-   __shared__ uint4 bwideA[BSCH == 2 ? 256 : 1];
+   __shared__ fx_nib wideR[SCH == 2 ? 256 : 1];
+   __shared__ fx_nib wideA[SCH == 2 ? 256 : 1];
+   __shared__ fx_nib bwideR[BSCH == 2 ? 256 : 1];
+   __shared__ fx_nib bwideA[BSCH == 2 ? 256 : 1];
    __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
    __shared__ uint32_t pool_cnt[4];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const uint32_t nr = c_tr / 2, na = c_ta / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else if (SCH == 2) {
-      wideR[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_w16R)[threadIdx.x];
-      wideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_w16A)[threadIdx.x];
+      wideR[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_w16R)[threadIdx.x];
+      wideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_w16A)[threadIdx.x];
    } else {
       permR[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastR)[threadIdx.x];
       permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const uint32_t nr = b_tr / 2, na = b_ta / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) bmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else if (BSCH == 2) {
-      bwideR[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_bw16R)[threadIdx.x];
-      bwideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + h->off_bw16A)[threadIdx.x];
+      bwideR[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16R)[threadIdx.x];
+      bwideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16A)[threadIdx.x];
    }
    // BMP class map (page index + pages) of the in-LDS UTF-8 decode, behind the tables when it fits
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       constexpr int S_ = C::sch;
       constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2, BYTES = C::bytes, DECODED = C::decoded;
       using F = typename FxF<S_>::type;
-      using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+      using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, fx_nib, uint2>::type>::type;
       const FastParams& P = BYTES ? fpb : fp;
       const uint16_t* cm = BYTES ? bmap : cmap;
       const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideR : wideR) : reinterpret_cast<const TabT*>(permR));
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
          uint32_t o[8];
          fetch32<RAGGED, false>(o, tb, lane, j, (uint32_t)L);
-         constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
+         constexpr int GB = 4;   // 8-symbol groups whose lookups are issued together
          uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
          for (int gb = 0; gb < 4; gb += GB) {
@@ -475,7 +475,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
-   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 8192 : 0)) + (BSCH == 2 ? 8192 : 0) + 1024 + 64;
+   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + (BSCH == 2 ? 4096 : 0) + 1024 + 64;
    const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;

@@ -203,7 +203,7 @@ struct FastParams {
 
 // 8 independent table lookups for 8 bytes.  Three table schemes share the kernels (template parameter SCH):
 //   0 v_perm       (<= 8 states): F = uint2 = the 8 next-state bytes of the symbol; step = ONE v_perm_b32.
-//   2 wide v_perm  (<= 16 states): F = uint4 = 16 encoded next-state bytes; step = two v_perm_b32 and an AND (see fxstep below).
+//   2 wide         (<= 16 states): F = fx_nib = 16 next-state nibbles; step = a 64-bit shift by 4*state and a mask (see fxstep below).
 //   1 chain        (larger automata): F = 2 * column of the symbol's class (uint16 map, state-independent, pipelined the same
 //                  way); the state is the byte offset of its row in a class-indexed uint16 table held in LDS and the step is a
 //                  dependent ds_read_u16 of T[state + F] (the destination's row offset).
@@ -213,15 +213,19 @@ __device__ __forceinline__ void lookup8(F* __restrict__ f, uint32_t lo, uint32_t
    for (int i = 0; i < 8; ++i) f[i] = tab[((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu];
 }
 __device__ __forceinline__ uint32_t fxstep(uint2 f, uint32_t st, const uint8_t*) { return __builtin_amdgcn_perm(f.y, f.x, st); }
-// wide scheme: F = 16 encoded next-state bytes (states 0..7 in x,y; 8..15 in z,w); the state byte is i (i < 8) or 0x80 + i - 8.
-// v_perm_b32 delivers 0xFF for a selector byte >= 13, so the half that does not hold the current state drops out of the AND.
-__device__ __forceinline__ uint32_t fxstep(uint4 f, uint32_t st, const uint8_t*) {
-   return __builtin_amdgcn_perm(f.y, f.x, st) & __builtin_amdgcn_perm(f.w, f.z, st ^ 0x80808080u);
+// 16-state scheme ("wide"): F = 16 next-state NIBBLES (8 bytes, one ds_read_b64); the state is a plain id 0..15 and one step is
+// (entry >> 4*state) & 15 -- v_lshlrev_b32, v_lshrrev_b64, v_and_b32.  (A 16-byte-per-symbol v_perm format -- two v_perm_b32 and
+// an AND -- moved twice the LDS bytes per input byte and ran at 0.55x the steps per second: tools/ubench/step_rate.hip.)
+struct __attribute__((aligned(8))) fx_nib {
+   uint32_t x, y;
+};
+__device__ __forceinline__ uint32_t fxstep(fx_nib f, uint32_t st, const uint8_t*) {
+   return (uint32_t)(((((uint64_t)f.y) << 32) | f.x) >> (st << 2)) & 15u;
 }
 __device__ __forceinline__ uint32_t fxstep(uint32_t f, uint32_t st, const uint8_t* T) {
    return *reinterpret_cast<const uint16_t*>(T + st + f);
 }
-// table scheme SCH: 0 = v_perm (<= 8 states), 1 = LDS chain, 2 = wide v_perm (<= 16 states, two v_perm_b32 per byte)
+// table scheme SCH: 0 = v_perm (<= 8 states), 1 = LDS chain, 2 = wide (<= 16 states, nibble tables: one 64-bit shift per byte)
 template <int SCH>
 struct FxF {
    using type = uint2;
@@ -232,7 +236,7 @@ struct FxF<1> {
 };
 template <>
 struct FxF<2> {
-   using type = uint4;
+   using type = fx_nib;
 };
 
 // Right-to-left state chain over 8 bytes.  All four bytes of `state` carry the same state id (v_perm_b32 advances four
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    using F = typename FxF<SCH>::type;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
    __shared__ uint2 permA[SCH == 0 ? 256 : 1];
-   __shared__ uint4 wideR[WIDE ? 256 : 1];
-   __shared__ uint4 wideA[WIDE ? 256 : 1];
+   __shared__ fx_nib wideR[WIDE ? 256 : 1];
+   __shared__ fx_nib wideA[WIDE ? 256 : 1];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       const uint32_t nr = tr_bytes / 2, na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else if (WIDE) {
-      const uint4* gR = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16R : h->off_w16R));
-      const uint4* gA = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16A : h->off_w16A));
+      const fx_nib* gR = reinterpret_cast<const fx_nib*>(prog + (BYTES ? h->off_bw16R : h->off_w16R));
+      const fx_nib* gA = reinterpret_cast<const fx_nib*>(prog + (BYTES ? h->off_bw16A : h->off_w16A));
       wideR[threadIdx.x] = gR[threadIdx.x];
       wideA[threadIdx.x] = gA[threadIdx.x];
    } else {
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    }
    __syncthreads();
    // symbol -> F tables of the two directions (the chain scheme shares one class map)
-   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, fx_nib, uint2>::type>::type;
    const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideR) : reinterpret_cast<const TabT*>(permR));
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) return;
       uint32_t o[8];
       fetch32<RAGGED, FG>(o, src, lane, j, Lx);
-      constexpr int GB = WIDE ? 2 : 4;   // 8-symbol groups whose lookups are issued together (wide entries are 4 registers each)
+      constexpr int GB = 4;   // 8-symbol groups whose lookups are issued together
       uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
       for (int gb = 0; gb < 4; gb += GB) {
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
    }
    using F = typename FxF<SCH>::type;
    __shared__ uint2 permA[SCH == 0 ? 256 : 1];
-   __shared__ uint4 wideA[WIDE ? 256 : 1];
+   __shared__ fx_nib wideA[WIDE ? 256 : 1];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * CH);
@@ -961,12 +965,12 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
       const uint32_t na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + na; i += 256u) cmap[i] = i < 256u ? g[i] : ga[i - 256u];
    } else if (WIDE) {
-      wideA[threadIdx.x] = reinterpret_cast<const uint4*>(prog + (BYTES ? h->off_bw16A : h->off_w16A))[threadIdx.x];
+      wideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + (BYTES ? h->off_bw16A : h->off_w16A))[threadIdx.x];
    } else {
       permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
    }
    __syncthreads();
-   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, uint4, uint2>::type>::type;
+   using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, fx_nib, uint2>::type>::type;
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const bool utf8 = !BYTES && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
@@ -1113,8 +1117,8 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
       uint32_t fin;
       if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * ((BYTES ? h->byte_n_classes : h->n_classes) + 2u));   // FINAL column
       else if (WIDE) {
-         const uint32_t* fm = BYTES ? h->bw16_finalM : h->w16_finalM;
-         fin = fxstep(make_uint4(fm[0], fm[1], fm[2], fm[3]), st, nullptr) & 3u;
+         const uint32_t* fm = BYTES ? h->bw16_finalM : h->w16_finalM;   // byte j = verdict of state j
+         fin = (fm[(st >> 2) & 3u] >> ((st & 3u) * 8u)) & 3u;
       } else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
       uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin == 1u ? 1u : 0u));
       const bool row_hi = MODE == 0 && (na & 0x80808080u) != 0;

@@ -356,8 +356,8 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, 0u, po.defer_tiles, po.gate_word, 0};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
-      fp.A_init = (BYTES ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
-      fp.inv = BYTES ? h.bw16_inv_A * 0x01010101u : 0u;
+      fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
+      fp.inv = BYTES ? h.bw16_inv_A : 0u;
    }
    switch (chunks_of(row_len)) {
       case 1: return launch_match<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -410,11 +410,11 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
                  0u, 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
-      fp.R_start = (BYTES ? h.bw16_R_start : h.w16_R_start) * 0x01010101u;
-      fp.A_init = (BYTES ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
-      fp.hit_min = (BYTES ? h.bw16_hit_min : h.w16_hit_min) * 0x01010101u;
-      fp.acc_min = (BYTES ? h.bw16_acc_min : h.w16_acc_min) * 0x01010101u;
-      fp.inv = BYTES ? h.bw16_inv_R * 0x01010101u : 0u;
+      fp.R_start = BYTES ? h.bw16_R_start : h.w16_R_start;
+      fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
+      fp.hit_min = BYTES ? h.bw16_hit_min : h.w16_hit_min;
+      fp.acc_min = BYTES ? h.bw16_acc_min : h.w16_acc_min;
+      fp.inv = BYTES ? h.bw16_inv_R : 0u;
    } else if (BYTES) {
       fp.R_start = h.byte_R_start;
       fp.A_init = h.byte_A_init;
@@ -429,7 +429,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    }
    if (MODE == 0 && (h.flags & FXP_F_OVERLAP_SINK)) {   // bordered prefix literal: rows whose backward pass ends in R's overlap state
       fp.inv_on = 1u;
-      fp.inv = WIDE ? (h.R_inv < 8u ? h.R_inv : 0x80u + h.R_inv - 8u) * 0x01010101u : (CHAIN ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
+      fp.inv = WIDE ? h.R_inv : (CHAIN ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
    switch (po.half ? 8 : chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -449,11 +449,11 @@ static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
                  0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u};
    if (sch == 2) {   // encoded state bytes, replicated like the 8-state scheme's
-      fp.R_start = (bytes ? h.bw16_R_start : h.w16_R_start) * 0x01010101u;
-      fp.A_init = (bytes ? h.bw16_A_init : h.w16_A_init) * 0x01010101u;
-      fp.hit_min = (bytes ? h.bw16_hit_min : h.w16_hit_min) * 0x01010101u;
-      fp.acc_min = (bytes ? h.bw16_acc_min : h.w16_acc_min) * 0x01010101u;
-      fp.inv = bytes ? h.bw16_inv_R * 0x01010101u : 0u;
+      fp.R_start = bytes ? h.bw16_R_start : h.w16_R_start;
+      fp.A_init = bytes ? h.bw16_A_init : h.w16_A_init;
+      fp.hit_min = bytes ? h.bw16_hit_min : h.w16_hit_min;
+      fp.acc_min = bytes ? h.bw16_acc_min : h.w16_acc_min;
+      fp.inv = bytes ? h.bw16_inv_R : 0u;
    } else if (bytes) {
       fp.R_start = h.byte_R_start;
       fp.A_init = h.byte_A_init;
@@ -468,7 +468,7 @@ static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
    }
    if (!bytes && (h.flags & FXP_F_OVERLAP_SINK)) {   // bordered prefix literal: rows whose backward pass ends in R's overlap state
       fp.inv_on = 1u;
-      fp.inv = sch == 2 ? (h.R_inv < 8u ? h.R_inv : 0x80u + h.R_inv - 8u) * 0x01010101u : (sch == 1 ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
+      fp.inv = sch == 2 ? h.R_inv : (sch == 1 ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
    return fp;
 }
@@ -507,8 +507,8 @@ static hipError_t launch_one_any(int sch, int bsch, bool gen, const FxpHeader& h
 static int one_bytes_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, int sch) {
    if (!bytes_ok(h, d_rows, row_len)) return 0;
    const size_t tiles_b = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1);
-   const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 8192 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
-   if (bytes_scheme(h) == 2 && tiles_b + cls_b + 8192 + 2048 <= 80 * 1024) return 2;
+   const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 4096 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
+   if (bytes_scheme(h) == 2 && tiles_b + cls_b + 4096 + 2048 <= 80 * 1024) return 2;
    if (tiles_b + cls_b + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 + 2048 <= 150 * 1024) return 1;
    return 0;
 }

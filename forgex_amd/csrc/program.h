@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 12u
+#define FXP_VERSION 13u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -35,9 +35,9 @@ enum FxpFlags {
    FXP_F_CHAIN_OK = 1u << 8,        // class-indexed LDS chain tables present (automata too large for the v_perm tables)
    FXP_F_CHAIN_UTF8 = 1u << 9,      // ... and they tell SKIP apart: the chain kernel's second pass may decode UTF-8
    FXP_F_BYTE_DFA = 1u << 12,       // byte-level chain tables present (UTF-8 composed into the automata)
-   FXP_F_W16_OK = 1u << 13,         // 16-state v_perm tables present (automata with 9..16 states: two v_perm_b32 per byte instead of the LDS chain)
+   FXP_F_W16_OK = 1u << 13,         // 16-state nibble tables present (automata with 9..16 states: a 64-bit shift per byte instead of the LDS chain)
    FXP_F_W16_UTF8 = 1u << 14,       // ... and they hold the 128+class / SKIP rows (the decode pass may use them)
-   FXP_F_BYTE_W16 = 1u << 15,       // the byte-level automata also exist in the 16-state v_perm format
+   FXP_F_BYTE_W16 = 1u << 15,       // the byte-level automata also exist in the 16-state nibble format
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match
    FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it
@@ -92,14 +92,14 @@ struct FxpHeader {
    uint32_t off_byte_cls;    // uint16 [256]   2 * column of each byte value
    uint32_t off_byte_TR;     // uint16 [nRb][byte_n_classes + 3]
    uint32_t off_byte_TA;     // uint16 [nAb][byte_n_classes + 3]   row 0 = dead
-   // ---- 16-state v_perm tables: per symbol 16 bytes = the ENCODED next state of each of 16 states, enc(i) = i (i < 8) or
-   //      0x80 + i - 8.  One step = v_perm(lo half, e) & v_perm(hi half, e ^ 0x80): a selector byte >= 13 makes v_perm_b32 deliver
-   //      0xFF, so the half that does not hold the current state drops out of the AND.  enc() is monotonic, so "state >= *_min"
-   //      tests work on encoded bytes. ----
+   // ---- 16-state NIBBLE tables: per symbol 8 bytes = 16 nibbles, nibble j (bits 4j..4j+3 of the little-endian 64-bit entry) = the
+   //      next state of state j; states are plain ids 0..15.  One step = (entry >> 4*state) & 15: a 64-bit shift and a mask
+   //      (3 VALU with the shift amount) on ONE ds_read_b64 -- half the LDS bytes of a 16-byte-per-symbol v_perm format, which is
+   //      what bounds these automata (tools/ubench/step_rate.hip: 1.7-2x the steps per second on UTF-8-like byte spreads). ----
    uint32_t w16_R_start, w16_A_init, w16_hit_min, w16_acc_min;                               // class-level (fast-path symbol ids)
    uint32_t bw16_R_start, bw16_A_init, bw16_hit_min, bw16_acc_min, bw16_inv_R, bw16_inv_A;   // byte-level (raw bytes)
-   uint32_t off_w16A, off_w16R;     // uint8 [256][16]
-   uint32_t off_bw16A, off_bw16R;   // uint8 [256][16]
+   uint32_t off_w16A, off_w16R;     // uint8 [256][8]   (16 nibbles per symbol)
+   uint32_t off_bw16A, off_bw16R;   // uint8 [256][8]
    uint32_t w16_finalM[4], bw16_finalM[4];   // `.match.`: byte j = verdict of state j after the last text byte (byte-level: 2 = redo by the decode path)
    uint32_t R_inv;        // FXP_F_OVERLAP_SINK: that state of R (a row that ends its backward pass there is left to the general engine)
    uint32_t checksum;     // FNV-1a of the whole image with this field read as zero (fxc::blob_checksum); checked by fxamd_program_from_blob

@@ -630,7 +630,7 @@ FX_HD void run_row(const ProgView& pv, Sim& sim, const Row& r, int L, Result& ou
 // (backward pass of R over the raw bytes for the leftmost start, forward pass of A for the longest end; `.match.`: one
 // forward pass and the FINAL column).  Returns 0 = `out` is the row's result, 1 = the row must be redone by the decode
 // path (structurally invalid UTF-8), -1 = the program has no byte tables / the row is outside the tile kernels' domain.
-// `w16`: walk the 16-state v_perm format of the same automata instead (states are encoded bytes: i < 8 -> i, else 0x80 + i - 8)
+// `w16`: walk the 16-state nibble format of the same automata instead (states are plain ids; 16 nibbles per byte value)
 template <class Row>
 FX_HD int byte_tables_row(const uint8_t* base, const Row& r, int L, Result& out, bool w16 = false) {
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(base);
@@ -639,7 +639,7 @@ FX_HD int byte_tables_row(const uint8_t* base, const Row& r, int L, Result& out,
    const uint16_t* cmap = reinterpret_cast<const uint16_t*>(base + h->off_byte_cls);
    const uint8_t *TRp = base + (w16 ? h->off_bw16R : h->off_byte_TR), *TAp = base + (w16 ? h->off_bw16A : h->off_byte_TA);
    auto step = [&](const uint8_t* T, uint32_t st, uint32_t byte) -> uint32_t {
-      if (w16) return T[byte * 16u + (st < 8u ? st : st - 0x80u + 8u)];
+      if (w16) return (uint32_t)(T[byte * 8u + (st >> 1)] >> ((st & 1u) * 4u)) & 15u;
       return *reinterpret_cast<const uint16_t*>(T + st + cmap[byte]);
    };
    const uint32_t A_init = w16 ? h->bw16_A_init : h->byte_A_init, R_start = w16 ? h->bw16_R_start : h->byte_R_start;
@@ -653,7 +653,7 @@ FX_HD int byte_tables_row(const uint8_t* base, const Row& r, int L, Result& out,
       const uint32_t gate = match_gate(h, base, row, static_cast<uint32_t>(L));
       uint32_t st = A_init;
       for (int j = 0; j < L; ++j) st = step(TAp, st, r[j]);
-      const uint32_t fin = w16 ? reinterpret_cast<const uint8_t*>(h->bw16_finalM)[st < 8u ? st : st - 0x80u + 8u]
+      const uint32_t fin = w16 ? reinterpret_cast<const uint8_t*>(h->bw16_finalM)[st & 15u]
                                : *reinterpret_cast<const uint16_t*>(TAp + st + 2u * (h->byte_n_classes + 2u));
       if (gate == 2u) out.flag = 1;
       else if (gate == 0u) out.flag = 0;

@@ -55,6 +55,15 @@ def test_byte_level_tables_equal_oracle_on_utf8_fuzz(built, monkeypatch):
     out = golden.run_protocol(HW, [c for c, _ in pairs])
     bad = [(c, e, x) for (c, e), x in zip(pairs, out) if not x.startswith("U") and not golden.line_matches(e, x)]
     assert not bad, bad[:5]
+    # the same automata in the 16-state NIBBLE format (what the tile kernels' wide scheme walks), where a program carries it
+    monkeypatch.setenv("FX_HW_BYTES", "w16")
+    a16 = golden.run_protocol(HW, cases[:2500])
+    diffs = [(c, x, y) for c, x, y in zip(cases[:2500], a16, b[:2500]) if not x.startswith("U") and x != y]
+    assert not diffs, diffs[:5]
+    out = golden.run_protocol(HW, [c for c, _ in pairs])
+    bad = [(c, e, x) for (c, e), x in zip(pairs, out) if not x.startswith("U") and not golden.line_matches(e, x)]
+    assert not bad, bad[:5]
+    monkeypatch.setenv("FX_HW_BYTES", "1")
     # the tables exist for the BASELINE patterns (with a prefilter literal only where it is proven equal to brute force) and are small
     lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
     lib.hw_byte_info.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
