@@ -67,6 +67,12 @@ def lib():
     L.fxamd_program_upload.restype = c.c_int
     L.fxamd_match_batch_device.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp]
     L.fxamd_match_batch_device.restype = c.c_int
+    L.fxamd_packed_layout.argtypes = [i64, i64, c.c_int, c.POINTER(i64), c.POINTER(i64), c.POINTER(i64), i32p]
+    L.fxamd_packed_layout.restype = c.c_int
+    L.fxamd_match_batch_device_packed.argtypes = [vp, vp, i64, i64, c.c_int, vp, vp]
+    L.fxamd_match_batch_device_packed.restype = c.c_int
+    L.fxamd_unpack_results.argtypes = [vp, i64, i64, c.c_int, vp, vp, vp, vp]
+    L.fxamd_unpack_results.restype = c.c_int
     L.fxamd_program_reserve.argtypes = [vp, i64, vp]
     L.fxamd_program_reserve.restype = c.c_int
     L.fxamd_match_multi_device.argtypes = [vp, c.c_int32, vp, i64, i64, vp, vp, vp, vp]
@@ -88,6 +94,6 @@ def lib():
 EXPORTED_SYMBOLS = [
     "fxamd_compile", "fxamd_compile_nfa", "fxamd_program_free", "fxamd_program_status", "fxamd_program_blob_size",
     "fxamd_program_blob", "fxamd_program_from_blob", "fxamd_program_info", "fxamd_strerror", "fxamd_strerror_copy", "fxamd_program_upload", "fxamd_program_reserve",
-    "fxamd_match_batch_device", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
+    "fxamd_match_batch_device", "fxamd_packed_layout", "fxamd_match_batch_device_packed", "fxamd_unpack_results", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
 ]
 BENCH_SYMBOLS = ["fxamd_launch_fast_only"]   # include/forgex_amd_bench.h: measurement hooks, not part of the boundary

@@ -116,6 +116,26 @@ class Program:
             raise RuntimeError("fxamd_match_batch_device failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
         return flags, frm, to
 
+    def match_device_packed(self, rows, spans=True, out=None):
+        """PACKED results of a device-resident batch (what a multi-GPU host gathers): one uint8 CUDA tensor holding 1 bit per row and,
+        with spans, from / to narrowed to the row length (layout: packed_layout).  Rows of up to 256 bytes are packed by the search
+        kernel itself."""
+        import torch
+        if not rows.is_cuda or rows.dtype != torch.uint8 or rows.dim() != 2 or not rows.is_contiguous():
+            raise ValueError("rows must be a contiguous uint8 CUDA tensor of shape [n, row_len]")
+        n, rl = rows.shape
+        spans = bool(spans) and self.op == _lib.OP_SEARCH
+        total = packed_layout(n, rl, spans)[2]
+        packed = out if out is not None else torch.empty(max(total, 16), dtype=torch.uint8, device=rows.device)
+        stream = torch.cuda.current_stream(rows.device).cuda_stream
+        with torch.cuda.device(rows.device):
+            rc = _lib.lib().fxamd_match_batch_device_packed(self._h, rows.data_ptr() if n else None, n, rl, 1 if spans else 0, packed.data_ptr(), stream)
+        if rc == _lib.E_UNSUPPORTED:
+            raise NotImplementedError("pattern %r is valid but not supported by the device path (status %d)" % (self.pattern, self.status))
+        if rc != 0:
+            raise RuntimeError("fxamd_match_batch_device_packed failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
+        return packed
+
     # ---- host batch: numpy uint8 [n, L] -----------------------------------------------------------------------
     def match_host(self, rows, spans=True):
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
@@ -131,6 +151,31 @@ class Program:
         if rc != 0:
             raise RuntimeError("fxamd_match_batch_host failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
         return flags, frm, to
+
+
+def packed_layout(n, row_len, spans=True):
+    """(off_from, off_to, total_bytes, span_bytes) of a packed result image (fxamd_packed_layout)."""
+    a, b, t = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    w = ctypes.c_int32(0)
+    rc = _lib.lib().fxamd_packed_layout(int(n), int(row_len), 1 if spans else 0, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t), ctypes.byref(w))
+    if rc != 0:
+        raise ValueError("fxamd_packed_layout failed: %d" % rc)
+    return a.value, b.value, t.value, w.value
+
+
+def unpack_results(packed, n, row_len, spans=True):
+    """packed image (uint8 CUDA tensor) -> (flags uint8[n], from int32[n], to int32[n]) on the same device."""
+    import torch
+    flags = torch.empty(n, dtype=torch.uint8, device=packed.device)
+    frm = torch.empty(n, dtype=torch.int32, device=packed.device) if spans else None
+    to = torch.empty(n, dtype=torch.int32, device=packed.device) if spans else None
+    stream = torch.cuda.current_stream(packed.device).cuda_stream
+    with torch.cuda.device(packed.device):
+        rc = _lib.lib().fxamd_unpack_results(packed.data_ptr(), n, row_len, 1 if spans else 0, flags.data_ptr(), frm.data_ptr() if spans else None,
+                                             to.data_ptr() if spans else None, stream)
+    if rc != 0:
+        raise RuntimeError("fxamd_unpack_results failed: %d" % rc)
+    return flags, frm, to
 
 
 def match_many(programs, rows, spans=True):

@@ -47,7 +47,10 @@ struct FxScanCfg {
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN>
 __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
-                                                       uint32_t class_map_in_lds, uint32_t Lr) {
+                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode) {
+   // out_mode 0: flags u8[n], from / to int32[n].  out_mode 1 / 2 / 4: PACKED results (what a multi-GPU host gathers):
+   // `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit word i >> 6: the ballot of the tile's wave, one store per tile),
+   // `from` / `to` = arrays of that many bytes per row (uint8 / uint16 / int32).
    static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
    constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0, POOL = HAS_B || GEN;
    const uint32_t L = RAGGED ? Lr : 16u * CH;
@@ -120,11 +123,45 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    uint32_t* myq = pool_q + (POOL ? wave * 64u : 0u);
 
+   // results of one row.  `ordered`: the wave holds 64 consecutive rows (a tile of the batch): the packed flag word is its ballot;
+   // a gathered row (exception queue) sets its bit in the word its tile's wave stored earlier.
+   auto emit = [&](const int64_t row, const bool live, const bool ordered, const uint32_t flag, const int32_t fr, const int32_t tt) {
+      if (out_mode == 0u) {
+         if (live) {
+            flags[row] = (uint8_t)flag;
+            if (SPANS) {
+               from[row] = fr;
+               to[row] = tt;
+            }
+         }
+         return;
+      }
+      if (ordered) {
+         // (rows the queue will redo, and rows behind the batch's end, contribute a zero bit)
+         const uint64_t m = __builtin_amdgcn_ballot_w64(live && flag != 0u);
+         if (lane == 0) reinterpret_cast<uint64_t*>(flags)[__builtin_amdgcn_readfirstlane((uint32_t)(row >> 6))] = m;
+      } else if (live && flag != 0u) {
+         atomicOr(reinterpret_cast<uint32_t*>(flags) + (row >> 5), 1u << ((uint32_t)row & 31u));
+      }
+      if (SPANS && live) {
+         if (out_mode == 1u) {
+            reinterpret_cast<uint8_t*>(from)[row] = (uint8_t)fr;
+            reinterpret_cast<uint8_t*>(to)[row] = (uint8_t)tt;
+         } else if (out_mode == 2u) {
+            reinterpret_cast<uint16_t*>(from)[row] = (uint16_t)fr;
+            reinterpret_cast<uint16_t*>(to)[row] = (uint16_t)tt;
+         } else {
+            from[row] = fr;
+            to[row] = tt;
+         }
+      }
+   };
+
    // ---- one scan of the tile in LDS: backward pass (leftmost start), forward pass (longest end), results -----------------------
    // cfg: table scheme; bytes = byte-level tables on raw bytes; decoded = the tile was rewritten into symbol ids (every byte value
    // means something: no byte >= 0x80 test).  Returns true when a class-level scan of RAW bytes met a byte >= 0x80: nothing was
    // written, the tile has to be redone.  `except` = this lane's row ended the byte-level backward pass in the INVALID state.
-   auto scan = [&](auto cfg, const int64_t row, const bool row_ok, bool& except) -> bool {
+   auto scan = [&](auto cfg, const int64_t row, const bool row_ok, const bool ordered, bool& except) -> bool {
       using C = decltype(cfg);
       constexpr int S_ = C::sch;
       constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2, BYTES = C::bytes, DECODED = C::decoded;
@@ -291,13 +328,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       } else {
          flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
       }
-      if (row_ok && !except) {
-         flags[row] = (uint8_t)flag;
-         if (SPANS) {
-            from[row] = fr;
-            to[row] = tt;
-         }
-      }
+      emit(row, row_ok && !except, ordered, flag, fr, tt);
       return false;
    };
 
@@ -326,6 +357,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             if (!POOL) break;
             // end of the wave's tiles: merge the block's four queues; each wave then takes every fourth gathered tile
             if (lane == 0) pool_cnt[wave] = pool_n;
+            __threadfence();   // (packed results: the tiles' flag words are in L2 before a gathered row ORs its bit into one)
             __syncthreads();
             const uint32_t c0 = pool_cnt[0], c1 = pool_cnt[1], c2 = pool_cnt[2], c3 = pool_cnt[3];
             pre1 = c0;
@@ -360,6 +392,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          else load_tile<CH>(stage, rows, t << 6, n, lane);
       } else {
          // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
+         if (phase == 0 && out_mode != 0u) __threadfence();   // (this wave's own flag words first, see above)
          row_ok = lane < take;
          uint32_t ridx = 0;
          if (POOL && row_ok) {
@@ -389,7 +422,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       bool except = false;
       bool redo = false;
       if (is_tile && !ALLB && !hint) {
-         redo = scan(FxScanCfg<SCH, false, false>{}, row, row_ok, except);
+         redo = scan(FxScanCfg<SCH, false, false>{}, row, row_ok, true, except);
          if (GEN && !redo) {
             pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
             pend_row = (uint32_t)row;
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const bool nonascii = !is_tile || hint || redo;   // (gathered rows always take the decode)
       if constexpr (HAS_B) {
          if (is_tile && (ALLB || nonascii)) {
-            (void)scan(FxScanCfg<(BSCH != 0 ? BSCH : 1), true, false>{}, row, row_ok, except);
+            (void)scan(FxScanCfg<(BSCH != 0 ? BSCH : 1), true, false>{}, row, row_ok, true, except);
             pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
             pend_row = (uint32_t)row;
          }
@@ -416,11 +449,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
                FxTileRow tr{tb, lane};
                fxrow::run_row(pv, sim, tr, (int)L, res);
             }
-            flags[row] = (uint8_t)res.flag;
-            if (SPANS) {
-               from[row] = res.from;
-               to[row] = res.to;
-            }
+            emit(row, true, false, res.flag, res.from, res.to);
          }
       }
       if (!GEN && ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii))) {
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
                cur = nxt;
             }
          }
-         (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, except);
+         (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, is_tile, except);
       }
    }
 }
@@ -470,7 +499,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
 // FastParams of the class-level tables (fp) and of the byte-level tables (fpb) are prepared by the host (fxamd.hip)
 template <int CH, int SCH, int BSCH, bool GEN>
 hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
-                      uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st) {
+                      uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st, uint32_t out_mode) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
@@ -479,7 +508,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
-   const bool spans = from && to;
+   const bool spans = from && to;   // (packed results: `from` / `to` are the narrow arrays)
    // Grid: with exception queues every block ends with one merged pass over its queued rows, so the grid is sized to what is
    // RESIDENT (one tail per CU slot, not one per 1/8 of it); without them the usual cap with grid-stride beyond it.
    {
@@ -498,8 +527,8 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
-         if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
-         else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+         if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
+         else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
          return hipGetLastError();
       } else {
          return hipErrorInvalidValue;   // (never dispatched: byte-level tables need whole chunks)
@@ -510,8 +539,8 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
-   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
-   else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr);
+   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
+   else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
    return hipGetLastError();
 }
 
@@ -520,4 +549,4 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
 #define FX_ONE_COMBOS(X, CH) FX_ONE_COMBOS_G(X, CH, false) FX_ONE_COMBOS_G(X, CH, true)
 #define FX_ONE_ALL(X) \
    FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 3) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 6) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)
-#define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t)
+#define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t)

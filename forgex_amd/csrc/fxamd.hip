@@ -192,6 +192,43 @@ __global__ void fx_fill(uint8_t* flags, int32_t* from, int32_t* to, int64_t n) {
    if (to) to[i] = 0;
 }
 
+// packed results <-> flags u8 + from / to int32 (paths without in-kernel packing, and the gathering root's unpack).  One thread
+// per 64 rows for the bit words, one per row for the spans.
+__global__ void fx_pack(const uint8_t* __restrict__ flags, const int32_t* __restrict__ from, const int32_t* __restrict__ to, int64_t n,
+                        uint64_t* __restrict__ bits, uint8_t* __restrict__ pf, uint8_t* __restrict__ pt, uint32_t span_bytes) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   const uint64_t m = __builtin_amdgcn_ballot_w64(i < n && flags[i] != 0);
+   if ((threadIdx.x & 63u) == 0 && i < n) bits[i >> 6] = m;
+   if (i >= n || span_bytes == 0u) return;
+   if (span_bytes == 1u) {
+      pf[i] = (uint8_t)from[i];
+      pt[i] = (uint8_t)to[i];
+   } else if (span_bytes == 2u) {
+      reinterpret_cast<uint16_t*>(pf)[i] = (uint16_t)from[i];
+      reinterpret_cast<uint16_t*>(pt)[i] = (uint16_t)to[i];
+   } else {
+      reinterpret_cast<int32_t*>(pf)[i] = from[i];
+      reinterpret_cast<int32_t*>(pt)[i] = to[i];
+   }
+}
+__global__ void fx_unpack(const uint64_t* __restrict__ bits, const uint8_t* __restrict__ pf, const uint8_t* __restrict__ pt, int64_t n,
+                          uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to, uint32_t span_bytes) {
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   flags[i] = (uint8_t)((bits[i >> 6] >> (i & 63)) & 1ull);
+   if (span_bytes == 0u || !from) return;
+   if (span_bytes == 1u) {
+      from[i] = pf[i];
+      to[i] = pt[i];
+   } else if (span_bytes == 2u) {
+      from[i] = reinterpret_cast<const uint16_t*>(pf)[i];
+      to[i] = reinterpret_cast<const uint16_t*>(pt)[i];
+   } else {
+      from[i] = reinterpret_cast<const int32_t*>(pf)[i];
+      to[i] = reinterpret_cast<const int32_t*>(pt)[i];
+   }
+}
+
 // =========================================================================================================
 // C ABI
 // =========================================================================================================
@@ -213,6 +250,8 @@ struct DevScratch {
    int64_t worklist_rows = 0;
    uint32_t* d_nfa_scratch = nullptr;   // bitset scratch of the NFA-simulation kernel (FXP_F_NFA_SIM programs)
    size_t nfa_scratch_rows = 0;
+   uint8_t* d_unpacked = nullptr;       // flags + from + to of a packed call that a path without in-kernel packing serves (9 bytes per row)
+   int64_t unpacked_rows = 0;
    uint64_t last_use = 0;
 };
 // host-buffer entry (fxamd_match_batch_host): two chunk slots per device, each with its own stream, device buffers and pinned result
@@ -280,6 +319,7 @@ static void free_scratch(DevScratch& s) {
    if (s.d_counter) (void)hipFree(s.d_counter);
    if (s.d_worklist) (void)hipFree(s.d_worklist);
    if (s.d_nfa_scratch) (void)hipFree(s.d_nfa_scratch);
+   if (s.d_unpacked) (void)hipFree(s.d_unpacked);
    s = DevScratch();
 }
 static int scratch_for(fxamd_program* p, int dev, hipStream_t st, DevScratch** out) {
@@ -474,30 +514,30 @@ static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
 }
 template <int SCH, int BSCH, bool GEN>
 static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
-                                int32_t* d_from, int32_t* d_to, hipStream_t st) {
+                                int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode) {
    const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t table_bytes = (SCH == 1 ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u) +
                                 (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
    const uint32_t Lr = (uint32_t)row_len;
    switch (tile_chunks(row_len)) {
-      case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 4: return launch_one<4, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 6: return launch_one<6, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 8: return launch_one<8, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      case 12: return launch_one<12, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
-      default: return launch_one<16, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st);
+      case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 4: return launch_one<4, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 6: return launch_one<6, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 8: return launch_one<8, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 12: return launch_one<12, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      default: return launch_one<16, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
    }
 }
 // bsch: 0 = no byte-level tables for these rows, 1 chain, 2 wide
 static hipError_t launch_one_any(int sch, int bsch, bool gen, const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
-                                 uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
+                                 uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode) {
 #define FX_ONE_CASE(S, B)                                                                                                        \
    if (sch == S && bsch == B)                                                                                                     \
-      return gen ? launch_one_ch<S, B, true>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st)                           \
-                 : launch_one_ch<S, B, false>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st);
+      return gen ? launch_one_ch<S, B, true>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode)                 \
+                 : launch_one_ch<S, B, false>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode);
    FX_ONE_CASE(0, 0) FX_ONE_CASE(1, 0) FX_ONE_CASE(2, 0) FX_ONE_CASE(0, 1) FX_ONE_CASE(0, 2) FX_ONE_CASE(1, 1) FX_ONE_CASE(1, 2) FX_ONE_CASE(2, 1) FX_ONE_CASE(2, 2)
 #undef FX_ONE_CASE
    return hipErrorInvalidValue;
@@ -535,9 +575,19 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
 }
 
 // ---- the pipeline of one batch call, enqueued on `st` with the scratch set `sc` (p->mu held) ----------------------------------
+// out_mode != 0: PACKED results (d_flags = bit words, d_from / d_to = narrow arrays of out_mode bytes per row).  Only the one-launch
+// kernel writes them itself; for every other path the function returns FX_NOT_PACKED before anything is enqueued and the caller
+// runs the unpacked pipeline into scratch and packs it with one more kernel.
+static constexpr int FX_NOT_PACKED = 1;
 static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
-                         uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st) {
+                         uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode = 0u) {
    const FxpHeader& h = p->prog.hdr();
+   if (out_mode != 0u) {
+      const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
+      const bool one = sc0 >= 0 && h.mode == FXP_MODE_SEARCH_ENGINE && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !half_rows(sc0, row_len) &&
+                       !std::getenv("FXAMD_MULTIPASS");
+      if (!one) return FX_NOT_PACKED;
+   }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
    if (h.flags & FXP_F_NFA_SIM) {
@@ -590,7 +640,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          // cannot decode, through the general row procedure); last_path 9 / 10 / 11 (12 / 13 / 14: general procedure for the queued rows)
          const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
          const bool gen = !utf8_tables;
-         FX_HIP(launch_one_any(scheme, ob, gen, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st));
+         FX_HIP(launch_one_any(scheme, ob, gen, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode));
          p->last_path = (ob == 0 ? 9 : (scheme == 0 ? 10 : 11)) + (gen ? 3 : 0);
          return FXAMD_OK;
       }
@@ -900,6 +950,82 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    rc = scratch_for(p, dev, st, &sc);
    if (rc != FXAMD_OK) return rc;
    return enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags, d_from, d_to, st);
+}
+
+int fxamd_packed_layout(int64_t n, int64_t row_len, int with_spans, int64_t* off_from, int64_t* off_to, int64_t* total_bytes, int32_t* span_bytes) {
+   if (n < 0 || row_len < 0) return FXAMD_E_ARG;
+   const int32_t w = !with_spans ? 0 : (row_len <= 255 ? 1 : (row_len <= 65535 ? 2 : 4));
+   const int64_t nb = (((n + 7) / 8) + 15) & ~int64_t(15);   // (>= 8 bytes per 64 rows: the kernels store whole 64-bit words)
+   const int64_t ns = (n * w + 15) & ~int64_t(15);
+   if (off_from) *off_from = nb;
+   if (off_to) *off_to = nb + ns;
+   if (total_bytes) *total_bytes = nb + 2 * ns;
+   if (span_bytes) *span_bytes = w;
+   return FXAMD_OK;
+}
+
+int fxamd_match_batch_device_packed(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, int with_spans, uint8_t* d_packed,
+                                    void* hip_stream) {
+   if (!p || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || !d_packed || (n > 0 && row_len > 0 && !d_rows)) return FXAMD_E_ARG;
+   if ((reinterpret_cast<uintptr_t>(d_packed) & 15u) != 0) return FXAMD_E_ARG;
+   if (p->prog.status >= 100) return FXAMD_E_UNSUPPORTED;
+   if (n == 0) return FXAMD_OK;
+   hipStream_t st = (hipStream_t)hip_stream;
+   const FxpHeader& h = p->prog.hdr();
+   if (h.mode == FXP_MODE_MATCH_ENGINE) with_spans = 0;   // `.match.` has no span
+   int64_t off_f = 0, off_t = 0, total = 0;
+   int32_t w = 0;
+   (void)fxamd_packed_layout(n, row_len, with_spans, &off_f, &off_t, &total, &w);
+   std::lock_guard<std::mutex> g(p->mu);
+   if (h.mode == FXP_MODE_INVALID) {   // every row: no match, spans 0
+      FX_HIP(hipMemsetAsync(d_packed, 0, (size_t)total, st));
+      p->last_path = 0;
+      return FXAMD_OK;
+   }
+   int dev = -1;
+   FX_HIP(hipGetDevice(&dev));
+   uint8_t* d_blob = nullptr;
+   int rc = blob_for_device(p, dev, &d_blob);
+   if (rc != FXAMD_OK) return rc;
+   DevScratch* sc = nullptr;
+   rc = scratch_for(p, dev, st, &sc);
+   if (rc != FXAMD_OK) return rc;
+   uint8_t* pf = d_packed + off_f;
+   uint8_t* pt = d_packed + off_t;
+   // in-kernel packing: the tile's ballot is the flag word, spans are stored narrow
+   rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_packed, w ? reinterpret_cast<int32_t*>(pf) : nullptr, w ? reinterpret_cast<int32_t*>(pt) : nullptr, st,
+                      w ? (uint32_t)w : 1u);
+   if (rc != FX_NOT_PACKED) return rc;
+   // every other path: unpacked into the handle's scratch, then one packing kernel
+   if (sc->unpacked_rows < n) {
+      if (sc->d_unpacked) (void)hipFree(sc->d_unpacked);
+      sc->d_unpacked = nullptr;
+      sc->unpacked_rows = 0;
+      FX_HIP(hipMalloc((void**)&sc->d_unpacked, (size_t)n * 9 + 64));
+      sc->unpacked_rows = n;
+   }
+   int32_t* uf = reinterpret_cast<int32_t*>(sc->d_unpacked);
+   int32_t* ut = uf + n;
+   uint8_t* ufl = reinterpret_cast<uint8_t*>(ut + n);
+   if (w && h.mode != FXP_MODE_MATCH_ENGINE) FX_HIP(hipMemsetAsync(sc->d_unpacked, 0, (size_t)n * 8, st));
+   rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, ufl, w ? uf : nullptr, w ? ut : nullptr, st, 0u);
+   if (rc != FXAMD_OK) return rc;
+   hipLaunchKernelGGL(fx_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ufl, uf, ut, n, reinterpret_cast<uint64_t*>(d_packed), pf, pt, (uint32_t)w);
+   FX_HIP(hipGetLastError());
+   return FXAMD_OK;
+}
+
+int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, int with_spans, uint8_t* d_flags, int32_t* d_from, int32_t* d_to,
+                         void* hip_stream) {
+   if (!d_packed || n < 0 || !d_flags || (d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
+   if (n == 0) return FXAMD_OK;
+   int64_t off_f = 0, off_t = 0;
+   int32_t w = 0;
+   (void)fxamd_packed_layout(n, row_len, with_spans, &off_f, &off_t, nullptr, &w);
+   hipLaunchKernelGGL(fx_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, reinterpret_cast<const uint64_t*>(d_packed),
+                      d_packed + off_f, d_packed + off_t, n, d_flags, d_from, d_to, (uint32_t)w);
+   FX_HIP(hipGetLastError());
+   return FXAMD_OK;
 }
 
 // m patterns over the same device-resident rows: results pattern-major ([m][n]).  One pass of the pipeline per pattern, enqueued

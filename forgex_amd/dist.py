@@ -1,7 +1,11 @@
 """Multi-GPU plumbing for the batch path: rows are independent units, so the batch shards into contiguous index
 ranges with NO data-path collective; the only exchange is one gather of PACKED results to rank 0
 (1 bit per flag + from/to narrowed to the row length) over RCCL -- a direct gather uses the root's 7 inbound xGMI
-links in parallel.  Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests)."""
+links in parallel.  Works with any torch.distributed backend (nccl on GPUs, gloo in the CPU tests).
+
+On GPUs the packed image comes straight from the match call (Program.match_device_packed: the search kernel stores the
+tile's ballot as the flag word and the spans narrow) and travels with gather_packed; pack_results / unpack_results here are
+the same layout written with torch ops -- the CPU tests' implementation and the cross-check of the kernels' packing."""
 import torch
 import torch.distributed as dist
 
@@ -75,3 +79,29 @@ def gather_results(flags, frm, to, n_total, row_len, dst=0):
         fr.append(x)
         tt.append(y)
     return torch.cat(fl), torch.cat(fr), torch.cat(tt)
+
+
+def gather_packed(packed, n_total, row_len, spans=True, dst=0):
+    """Every rank passes the packed image of its shard (Program.match_device_packed); rank `dst` returns the list of the shards'
+    images (views trimmed to each shard's size) together with the shards' row counts, others None.  ONE collective."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = []
+    for r in range(world):
+        a, b = shard_bounds(n_total, r, world)
+        sizes.append(b - a)
+    w = torch.empty(0, dtype=span_dtype(row_len)).element_size() if spans else 0
+
+    def total(m):
+        nb = ((m + 7) // 8 + 15) & ~15
+        return nb + 2 * ((m * w + 15) & ~15)
+    mx = max(max(total(m) for m in sizes), 16)
+    buf = packed
+    if packed.numel() != mx:
+        buf = torch.zeros(mx, dtype=torch.uint8, device=packed.device)
+        buf[:min(packed.numel(), mx)] = packed[:mx]
+    if rank != dst:
+        dist.gather(buf, None, dst=dst)
+        return None
+    lst = [torch.empty(mx, dtype=torch.uint8, device=packed.device) for _ in range(world)]
+    dist.gather(buf, lst, dst=dst)
+    return [lst[r][:max(total(sizes[r]), 16)] for r in range(world)], sizes

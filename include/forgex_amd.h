@@ -90,6 +90,20 @@ int fxamd_program_reserve(fxamd_program* p, int64_t max_rows, void* hip_stream);
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream);
 
+/* PACKED results -- what a multi-GPU host gathers (one image per shard): 1 bit per row (row i = bit i & 63 of the
+ * little-endian 64-bit word i >> 6), then, with spans, from[n] and to[n] narrowed to uint8 (row_len <= 255), uint16 (<= 65535) or
+ * int32; the sections start at 16-byte multiples (fxamd_packed_layout: offsets of from / to, total size, bytes per span).
+ * d_packed: total_bytes of device memory, 16-byte aligned.  Rows of up to 256 bytes are packed by the search kernel itself (the
+ * flag word is the ballot of the wave that owns the tile: 2.125 bytes per row instead of 9 at row_len <= 255); other shapes run
+ * the usual pipeline into the handle's scratch and are packed by one more kernel.  `.match.` programs: bits only. */
+int fxamd_packed_layout(int64_t n, int64_t row_len, int with_spans, int64_t* off_from, int64_t* off_to, int64_t* total_bytes,
+                        int32_t* span_bytes);
+int fxamd_match_batch_device_packed(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, int with_spans,
+                                    uint8_t* d_packed, void* hip_stream);
+/* packed image -> flags u8[n] (0/1), from / to int32[n] (both NULL: flags only); device pointers, asynchronous on the stream */
+int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, int with_spans, uint8_t* d_flags, int32_t* d_from,
+                         int32_t* d_to, void* hip_stream);
+
 /* m patterns against the same device-resident rows (the reference's elemental operators accept an ARRAY of patterns,
  * src/forgex.F90:74, :163): progs[i] fills d_flags[i*n .. i*n+n) (and d_from / d_to likewise).  One pass of the pipeline per
  * pattern, enqueued back to back on the stream; rows are re-read per pattern. */

@@ -807,3 +807,49 @@ def test_one_launch_kernel_exception_queues_vs_multipass_and_oracle(fx, bad_frac
         k = 4000
         of, oa, ob = oracle_lib.batch(2, pat, rows[:k].cpu().numpy(), NT)
         assert np.array_equal(f1[:k].cpu().numpy(), of) and np.array_equal(a1[:k].cpu().numpy(), oa) and np.array_equal(b1[:k].cpu().numpy(), ob), (cfg, pat, bad_frac)
+
+
+def test_packed_results_equal_unpacked_on_every_config(fx):
+    """packed results (1 bit per flag from the tile's ballot, spans narrowed to the row length) against the plain
+    outputs of the same program on the same rows -- in-kernel packing (one-launch kernel), the packing kernel behind the other
+    paths (256-byte rows on the half-row pipeline, long rows, `.match.`, general kernel), flags only and flags + spans, batch sizes
+    around the 64-row word -- and against the torch implementation of the layout in forgex_amd.dist."""
+    import torch
+    from forgex_amd import synth
+    from forgex_amd import dist as fxdist
+    dev = torch.device("cuda")
+    cases = [("cfg5", synth.PATTERNS["cfg5"].encode(), fx.OP_SEARCH, 200_003), ("cfg4", synth.PATTERNS["cfg4"].encode(), fx.OP_SEARCH, 100_001),
+             ("cfg2", rb"foo(bar|baz)", fx.OP_SEARCH, 100_000), ("cfg3", rb"[a-z]+\d+", fx.OP_SEARCH, 60_001), ("cfg3", rb"\d{3}-\d{4}", fx.OP_SEARCH, 30_000),
+             ("cfg1", rb"\d{3}-\d{4}", fx.OP_MATCH, 1000), ("cfg2", rb"aa[bc]", fx.OP_SEARCH, 50_000), ("cfg5", rb"[a-z]+\d+", fx.OP_SEARCH, 1),
+             ("cfg5", rb"[a-z]+\d+", fx.OP_SEARCH, 63), ("cfg5", rb"[a-z]+\d+", fx.OP_SEARCH, 65), ("cfg5", rb"a(", fx.OP_SEARCH, 100)]
+    in_kernel = 0
+    for cfg, pat, op, n in cases:
+        rows = synth.batch(cfg, 0, n, dev)
+        if cfg == "cfg4":   # broken rows too: their bits arrive through the exception queues (atomic OR into the tile's word)
+            rows[::7, 5] = 0xFF
+        L = rows.shape[1]
+        prog = fx.Program(pat, op)
+        for spans in (True, False):
+            if prog.status != 0:
+                f = torch.zeros(n, dtype=torch.uint8, device=dev)
+                a = b = torch.zeros(n, dtype=torch.int32, device=dev)
+            else:
+                f, a, b = prog.match_device(rows, spans=spans and op == fx.OP_SEARCH)
+            packed = prog.match_device_packed(rows, spans=spans)
+            torch.cuda.synchronize()
+            if prog.status == 0 and prog.last_path() in (9, 10, 11, 12, 13, 14):
+                in_kernel += 1
+            sp = spans and op == fx.OP_SEARCH
+            off_f, off_t, total, w = fx.packed_layout(n, L, sp)
+            assert packed.numel() >= total and w == (0 if not sp else (1 if L <= 255 else 2))
+            uf, ua, ub = fx.unpack_results(packed, n, L, sp)
+            torch.cuda.synchronize()
+            assert torch.equal(uf, f), (cfg, pat, n, spans)
+            if sp:
+                assert torch.equal(ua, a) and torch.equal(ub, b), (cfg, pat, n, spans)
+                # the same image from the torch implementation of the layout
+                bits, a8, b8 = fxdist.pack_results(f, a, b, L)
+                assert torch.equal(packed[:bits.numel()], bits), (cfg, pat, n)
+                assert torch.equal(packed[off_f:off_f + n * w], a8.view(torch.uint8)) and torch.equal(packed[off_t:off_t + n * w], b8.view(torch.uint8))
+                assert fxdist.packed_layout(n, L) == (off_f, off_t, total)
+    assert in_kernel >= 8
