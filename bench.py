@@ -432,22 +432,33 @@ def main():
                 host_path = {"value": None, "error": repr(e)}
     roofline["device_copy_gbs"] = copy_gbs   # bytes read + bytes written per second of a plain device-to-device copy of the batch
 
-    # ---- packed result gather over RCCL (not part of `value`) ---------------------------------------------------
-    gather_ms = None
+    # ---- packed results + gather over RCCL (not part of `value`) -----------------------------------------------------------------
+    # what a multi-GPU host does after the scan: each rank's results as ONE packed image (1 bit per flag + spans narrowed to the row
+    # length, written by the search kernel itself for rows of up to 256 bytes), one gather to rank 0, unpacked there
+    gather_ms = packed_step_ms = None
     if use_dist:
-        f2 = flags
-        a2 = frm if spans else torch.zeros(rows_per_gpu, dtype=torch.int32, device=dev)
-        b2 = to if spans else torch.zeros(rows_per_gpu, dtype=torch.int32, device=dev)
-        fxdist.gather_results(f2, a2, b2, rows_per_gpu * world, row_len)   # warm-up (RCCL connection setup)
+        packed = prog.match_device_packed(rows, spans=spans)
+        for _ in range(5):
+            prog.match_device_packed(rows, spans=spans, out=packed)
+        barrier()
+        p0 = time.perf_counter()
+        for _ in range(20):
+            prog.match_device_packed(rows, spans=spans, out=packed)
+        torch.cuda.synchronize()
+        packed_step_ms = (time.perf_counter() - p0) / 20 * 1e3
+        fxdist.gather_packed(packed, rows_per_gpu * world, row_len, spans)   # warm-up (RCCL connection setup)
         barrier()
         g0 = time.perf_counter()
-        res = fxdist.gather_results(f2, a2, b2, rows_per_gpu * world, row_len)
+        res = fxdist.gather_packed(packed, rows_per_gpu * world, row_len, spans)
+        if rank == 0:
+            shards, sizes = res
+            unpacked = [forgex_amd.unpack_results(img, m, row_len, spans) for img, m in zip(shards, sizes)]
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            assert res[0].shape[0] == rows_per_gpu * world
-            # the gathered shard of rank 0 is what rank 0 computed
-            assert torch.equal(res[0][:rows_per_gpu], flags) and (not spans or torch.equal(res[1][:rows_per_gpu], frm))
+            assert sum(sizes) == rows_per_gpu * world
+            # the gathered shard of rank 0 is what rank 0's plain call computed
+            assert torch.equal(unpacked[0][0], flags) and (not spans or (torch.equal(unpacked[0][1], frm) and torch.equal(unpacked[0][2], to)))
 
     line = None
     if rank == 0:
@@ -463,7 +474,7 @@ def main():
             "frac_of_one_eighth_gpu": total_bytes / dt / 1e9 / (HBM_PEAK_GBS / 8 * world),
             "settled": {"value": total_bytes / dt_settled / 1e9, "ms_per_step": dt_settled / args.steps * 1e3,
                         "note": "the same %d timed steps after %d more untimed launches (clock transient over)" % (args.steps, SETTLE)},
-            "roofline": roofline, "gather_ms": gather_ms, "flags_only": flags_only, "host_path": host_path,
+            "roofline": roofline, "gather_ms": gather_ms, "packed_step_ms": packed_step_ms, "flags_only": flags_only, "host_path": host_path,
         }
         threads = os.cpu_count() or 1
         if not args.no_parity:

@@ -357,7 +357,10 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             if (!POOL) break;
             // end of the wave's tiles: merge the block's four queues; each wave then takes every fourth gathered tile
             if (lane == 0) pool_cnt[wave] = pool_n;
-            __threadfence();   // (packed results: the tiles' flag words are in L2 before a gathered row ORs its bit into one)
+            // packed results: the tiles' flag words must be in L2 before a gathered row ORs its bit into one.  All waves of a block
+            // share one CU (one L2): waiting for the stores' acknowledgements is enough -- a device-scope fence would write the
+            // whole L2 back, once per wave (measured: +50 us on a 1M-row batch)
+            if (out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             const uint32_t c0 = pool_cnt[0], c1 = pool_cnt[1], c2 = pool_cnt[2], c3 = pool_cnt[3];
             pre1 = c0;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          else load_tile<CH>(stage, rows, t << 6, n, lane);
       } else {
          // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
-         if (phase == 0 && out_mode != 0u) __threadfence();   // (this wave's own flag words first, see above)
+         if (phase == 0 && out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's own flag words first, see above)
          row_ok = lane < take;
          uint32_t ridx = 0;
          if (POOL && row_ok) {
