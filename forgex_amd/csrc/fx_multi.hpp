@@ -1,0 +1,144 @@
+// fx_search_multi: m patterns against the same rows in ONE pass over the rows (the reference's operators are
+// elemental over `pattern` too, src/forgex.F90:74,163).  A tile of 64 rows is staged in LDS once; the tables of all m patterns
+// (8-state v_perm scheme: 4 KB each) sit in LDS next to the tiles, and the wave that owns the tile scans it once per pattern
+// (fx_scan_tile), writing pattern p's results to flags[p*n + row] (from / to likewise).  HBM traffic: the rows once plus m result
+// sets, instead of m times the rows.  Rows a pattern's tables cannot answer -- a byte >= 0x80, the overlap state of a bordered
+// prefix literal -- go through the general row procedure (fxrow::run_row) right there, one lane per row.
+// The scans are VALU-bound (about 3.4 instructions per byte per pattern), so the pass costs about m times the compute of one
+// pattern; what is saved is the memory time of the other m-1 passes and their launches.
+#pragma once
+#include "fx_one.hpp"
+
+#define FX_MULTI_MAX 8
+struct FxMultiArgs {
+   const uint8_t* blob[FX_MULTI_MAX];   // the patterns' uploaded program images
+   FastParams fp[FX_MULTI_MAX];         // class-level parameters of each (v_perm scheme)
+   uint32_t slot[FX_MULTI_MAX];         // result slot of each: its flags start at flags + slot * n (from / to likewise)
+   uint32_t m;
+};
+
+template <int CH, bool SPANS, bool RAGGED, int WPB>
+__global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __restrict__ rows, int64_t n, FxMultiArgs a, uint8_t* __restrict__ flags,
+                                                              int32_t* __restrict__ from, int32_t* __restrict__ to, uint32_t Lr) {
+   const uint32_t L = RAGGED ? Lr : 16u * CH;
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // WPB waves x 64*(CH+1) cells, then m x (permR[256], permA[256])
+   uint2* tabs = reinterpret_cast<uint2*>(tiles + WPB * 64 * (CH + 1));
+   for (uint32_t p = 0; p < a.m; ++p) {
+      const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
+      const uint2* gR = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastR);
+      const uint2* gA = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastA);
+      for (uint32_t i = threadIdx.x; i < 256u; i += 64u * WPB) {
+         tabs[p * 512u + i] = gR[i];
+         tabs[p * 512u + 256u + i] = gA[i];
+      }
+   }
+   __syncthreads();
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   uint4* tile = tiles + wave * (64 * (CH + 1));
+   tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);   // end-of-row column (see fx_search_fast)
+   const bool whole = RAGGED && (Lr & 15u) == 0u;
+   if (whole)
+      for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave, wave_stride = (int64_t)gridDim.x * WPB;
+   uint4 stage[CH];
+   if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
+   else load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   for (int64_t t = wave_global; t < n_tiles;) {
+      const int64_t row = (t << 6) + lane;
+      const bool row_ok = row < n;
+      if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(stage, tile, lane, Lr >> 4);
+      else if (RAGGED) store_tile_relayout<CH>(stage, tile, lane, Lr);
+      else store_tile<CH>(stage, tile, lane);
+      t += wave_stride;   // the ONE place the staging registers are reloaded
+      if (RAGGED) load_tile<CH>(stage, rows, t << 6, n, lane, true, Lr);
+      else load_tile<CH>(stage, rows, t << 6, n, lane);
+      // rows that are not whole chunks: pad once, remember the OR of the row's own bytes (every pattern asks for it)
+      FxScanCtx sc{tile, tb, lane, L, Lr, whole, false, 0u};
+      if (RAGGED && !whole) sc.pre_na = pad_rows<CH>(tile, lane, Lr);
+      for (uint32_t p = 0; p < a.m; ++p) {
+         const int64_t base = (int64_t)a.slot[p] * n;
+         auto emit = [&](const int64_t r, const bool live, const bool, const uint32_t flag, const int32_t fr, const int32_t tt) {
+            if (live) {
+               flags[base + r] = (uint8_t)flag;
+               if (SPANS) {
+                  from[base + r] = fr;
+                  to[base + r] = tt;
+               }
+            }
+         };
+         const uint2* tR = tabs + p * 512u;
+         const uint2* tA = tR + 256;
+         const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
+         sc.raw = (h->flags & FXP_F_RAW_BYTES) != 0;
+         bool except = false;
+         if (RAGGED && !whole) (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
+         else (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, false>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
+         if (__builtin_amdgcn_ballot_w64(except && row_ok) != 0) {
+            if (except && row_ok) {   // the general row procedure for the rows these tables cannot answer
+               fxrow::ProgView pv(a.blob[p]);
+               fxrow::DfaSim sim(pv);
+               fxrow::Result res;
+               FxGlobalRow gr{rows + row * (int64_t)L};
+               fxrow::run_row(pv, sim, gr, (int)L, res);
+               flags[base + row] = (uint8_t)res.flag;
+               if (SPANS) {
+                  from[base + row] = res.from;
+                  to[base + row] = res.to;
+               }
+            }
+         }
+      }
+   }
+}
+
+// waves per block: 8 when that keeps more waves on a CU than blocks of 4 (the tables are stored once per block)
+template <int CH>
+hipError_t launch_multi(const uint8_t* rows, int64_t n, const FxMultiArgs& a, uint8_t* flags, int32_t* from, int32_t* to, uint32_t Lr, hipStream_t st) {
+   const size_t tab_b = (size_t)a.m * 4096;
+   const size_t t4 = (size_t)4 * 64 * (CH + 1) * 16 + tab_b, t8 = (size_t)8 * 64 * (CH + 1) * 16 + tab_b;
+   const size_t cap = 160 * 1024;
+   const int w4 = t4 <= cap ? 4 * (int)(cap / t4) : 0, w8 = t8 <= cap ? 8 * (int)(cap / t8) : 0;
+   if (w4 == 0 && w8 == 0) return hipErrorInvalidValue;   // (the caller bounds m by multi_max_patterns)
+   const bool eight = w8 > w4;
+   const int wpb = eight ? 8 : 4;
+   const size_t lds = eight ? t8 : t4;
+   const int64_t n_tiles = (n + 63) >> 6;
+   int64_t blocks = (n_tiles + wpb - 1) / wpb;
+   const int64_t resident = (int64_t)(cap / lds);
+   const int64_t gcap = 256 * resident * 4;
+   if (blocks > gcap) blocks = gcap;
+   const bool ragged = Lr != 16u * CH, spans = from && to;
+#define FX_MULTI_LAUNCH(SP, RG, W)                                                                                                        \
+   {                                                                                                                                      \
+      const void* fn = reinterpret_cast<const void*>(&fx_search_multi<CH, SP, RG, W>);                                                    \
+      if (lds > 64 * 1024) {                                                                                                              \
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+         if (e != hipSuccess) return e;                                                                                                   \
+      }                                                                                                                                   \
+      hipLaunchKernelGGL((fx_search_multi<CH, SP, RG, W>), dim3((unsigned)blocks), dim3(64 * W), lds, st, rows, n, a, flags, from, to, Lr); \
+      return hipGetLastError();                                                                                                           \
+   }
+   if (eight) {
+      if (spans) {
+         if (ragged) FX_MULTI_LAUNCH(true, true, 8) else FX_MULTI_LAUNCH(true, false, 8)
+      } else {
+         if (ragged) FX_MULTI_LAUNCH(false, true, 8) else FX_MULTI_LAUNCH(false, false, 8)
+      }
+   } else {
+      if (spans) {
+         if (ragged) FX_MULTI_LAUNCH(true, true, 4) else FX_MULTI_LAUNCH(true, false, 4)
+      } else {
+         if (ragged) FX_MULTI_LAUNCH(false, true, 4) else FX_MULTI_LAUNCH(false, false, 4)
+      }
+   }
+#undef FX_MULTI_LAUNCH
+}
+// how many patterns one launch can take for rows of this chunk count (tables + at least four tiles in 160 KB of LDS)
+static inline int multi_max_patterns(int ch) {
+   const size_t t4 = (size_t)4 * 64 * (ch + 1) * 16;
+   int m = (int)((160 * 1024 - t4) / 4096);
+   return m > FX_MULTI_MAX ? FX_MULTI_MAX : (m < 0 ? 0 : m);
+}
+#define FX_MULTI_SIG (const uint8_t*, int64_t, const FxMultiArgs&, uint8_t*, int32_t*, int32_t*, uint32_t, hipStream_t)

@@ -37,6 +37,196 @@ struct FxScanCfg {
    static constexpr bool bytes = BYTES_, decoded = DECODED_;
 };
 
+// ---- one scan of a tile in LDS: backward pass (leftmost start), forward pass (longest end), results -----------------------------
+// S_: table scheme; BYTES: byte-level tables on raw bytes; DECODED: the tile was rewritten into symbol ids (every byte value means
+// something: no byte >= 0x80 test).  A class-level scan of RAW bytes that meets a byte >= 0x80 either gives the whole tile back
+// (REDO_TILE: returns true, nothing written -- the caller redoes it with byte-level tables or after a decode) or marks just those
+// rows (ROW_EXC: `except`, as for rows ending in the overlap state of a bordered prefix literal); `except` is also set for rows whose
+// byte-level backward pass ends in the INVALID state.  Excepted rows are not emitted.  PREPAD: ragged rows were padded and their
+// bytes OR-ed by the caller (several scans of one tile: fx_search_multi).
+struct FxScanCtx {
+   uint4* tile;
+   const uint8_t* tb;
+   uint32_t lane, L, Lr;
+   bool whole, raw;
+   uint32_t pre_na;
+};
+template <int CH, bool SPANS, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool PREPAD, class TabT, class Emit>
+__device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __restrict__ tabR, const TabT* __restrict__ tabA, const uint8_t* TRp,
+                                             const uint8_t* TAp, const FastParams& P, const int64_t row, const bool row_ok, const bool ordered,
+                                             bool& except, Emit& emit) {
+   {
+      constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2;
+      (void)CHAIN;
+      (void)WIDE;
+      using F = typename FxF<S_>::type;
+      uint4* const tile = c.tile;
+      const uint8_t* const tb = c.tb;
+      const uint32_t lane = c.lane, L = c.L, Lr = c.Lr;
+      const bool whole = c.whole, raw = c.raw;
+      (void)Lr;
+      (void)whole;
+      uint32_t state = P.R_start;
+      uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
+      uint32_t na = 0;
+      if (PREPAD) na = c.pre_na;
+      else if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);
+      {
+         F fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
+         if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+         lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll
+         for (int k = CH - 1; k >= 0; --k) {
+            if (!PREPAD && (!RAGGED || (whole && !DECODED && (uint32_t)k < (Lr >> 4)))) na |= wk.x | wk.y | wk.z | wk.w;
+            lookup8(fb, wk.x, wk.y, tabR);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fa, state, TRp);
+               gsel = mx >= P.hit_min ? (uint32_t)(2 * k + 1) : gsel;
+               esel = mx >= P.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k >= 1) {
+               wk = wn;
+               lookup8(fa, wk.z, wk.w, tabR);
+               if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back(fb, state, TRp);
+               gsel = mx >= P.hit_min ? (uint32_t)(2 * k) : gsel;
+               esel = mx >= P.hit_min ? entry : esel;
+               asm volatile("" : "+v"(esel));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      }
+      // a class-level scan of raw bytes that met a byte >= 0x80: the tile is redone with the byte-level tables / after a decode;
+      // a program that has neither (GEN without byte-level tables) hands just those ROWS to the general procedure
+      bool row_hi = false;
+      if (!BYTES && !DECODED && !raw) {
+         row_hi = (na & 0x80808080u) != 0;
+         if (REDO_TILE && __builtin_amdgcn_ballot_w64(row_hi) != 0) return true;
+      }
+      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
+      {
+         // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
+         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
+         const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+         F f[8];
+         lookup8(f, rw.x, rw.y, tabR);
+         uint32_t st = esel, loc = 8;
+#pragma unroll
+         for (int i = 7; i >= 0; --i) {
+            st = fxstep(f[i], st, TRp);
+            loc = st >= P.hit_min ? (uint32_t)i : loc;
+         }
+         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
+         const F fz = tabR[0];   // leading NUL
+         state = fxstep(fz, state, TRp);
+         s = state >= P.hit_min ? 1u : s;
+      }
+      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8: the row is queued for the decode pass
+      // (GEN, class-level tables: a row that ended in the overlap state of a bordered prefix literal, or that holds a byte >= 0x80)
+      except = (BYTES && state == P.inv) || (ROW_EXC && !BYTES && !DECODED && ((P.inv_on != 0 && state == P.inv) || row_hi));
+      // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
+      uint32_t cur = (s != 0 && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
+      uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
+      uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
+      if (s == 1) {
+         const F f = tabA[0];
+         cur = fxstep(f, cur, TAp);
+         mm = cur >= P.acc_min ? 2u : 0u;
+      }
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         uint32_t o[8];
+         fetch32<RAGGED, false>(o, tb, lane, j, (uint32_t)L);
+         constexpr int GB = 4;   // 8-symbol groups whose lookups are issued together
+         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
+#pragma unroll
+         for (int gb = 0; gb < 4; gb += GB) {
+            F f[8 * GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+               const uint32_t entry = cur;
+               uint32_t st[8];
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f[8 * g + q], cur, TAp);
+                  st[q] = cur;
+               }
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool hit = mx >= P.acc_min;
+               gl = hit ? (uint32_t)(gb + g) : gl;
+               el = hit ? entry : el;
+               blo = hit ? o[2 * (gb + g)] : blo;
+               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
+            }
+         }
+         {
+            F fr8[8];
+            lookup8(fr8, blo, bhi, tabA);
+            uint32_t st = el, loc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+               st = fxstep(fr8[q], st, TAp);
+               loc = st >= P.acc_min ? (uint32_t)q : loc;
+            }
+            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+         }
+         j += 32u;
+         // matches longer than the window: 8 symbols per round trip, the next group read one round ahead (see fx_search_fast)
+         if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+            const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
+            uint32_t gb = j & ~7u;
+            uint32_t t0[2], t1[2];
+            group_words<RAGGED, false>(t0[0], t0[1], tb, lane, gb, (uint32_t)L);
+            group_words<RAGGED, false>(t1[0], t1[1], tb, lane, gb + 8u, (uint32_t)L);
+            do {
+               uint32_t t2[2];
+               group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
+               const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
+               const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
+               F f8[8];
+               lookup8(f8, o0, o1, tabA);
+               uint32_t loc = 8;
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f8[q], cur, TAp);
+                  loc = cur >= P.acc_min ? (uint32_t)q : loc;
+               }
+               mm = loc != 8u ? j + loc + 3u : mm;
+               j += 8u;
+               gb += 8u;
+               t0[0] = t1[0]; t0[1] = t1[1];
+               t1[0] = t2[0]; t1[1] = t2[1];
+            } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
+         }
+      }
+      uint32_t flag = 0;
+      int32_t fr = 0, tt = 0;
+      if (SPANS) {
+         if (s != 0 && mm != 0) {   // api_internal_m.F90:140-148
+            fr = (int32_t)(s - 1);
+            if (fr == 0) fr = 1;
+            tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
+            if (fr > 0 && tt > 0) flag = 1;
+            else { fr = 0; tt = 0; }
+         }
+      } else {
+         flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
+      }
+      emit(row, row_ok && !except, ordered, flag, fr, tt);
+      return false;
+   }
+}
+
 // SCH: scheme of the class-level tables (0 v_perm, 1 chain, 2 wide); BSCH: scheme of the byte-level tables (0 = none in this
 // launch, 1 chain, 2 wide).  SCH == 0 && BSCH != 0: per-tile selection.  SCH != 0 && BSCH != 0: the byte-level tables take every
 // tile (the class-level ones are no faster on ASCII), the class-level tables only serve the exception rows.
@@ -54,7 +244,6 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
    constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0, POOL = HAS_B || GEN;
    const uint32_t L = RAGGED ? Lr : 16u * CH;
-   constexpr bool ragged = RAGGED;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
    __shared__ uint2 permA[SCH == 0 ? 256 : 1];
    __shared__ fx_nib wideR[SCH == 2 ? 256 : 1];
@@ -157,15 +346,12 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       }
    };
 
-   // ---- one scan of the tile in LDS: backward pass (leftmost start), forward pass (longest end), results -----------------------
-   // cfg: table scheme; bytes = byte-level tables on raw bytes; decoded = the tile was rewritten into symbol ids (every byte value
-   // means something: no byte >= 0x80 test).  Returns true when a class-level scan of RAW bytes met a byte >= 0x80: nothing was
-   // written, the tile has to be redone.  `except` = this lane's row ended the byte-level backward pass in the INVALID state.
+   // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
+   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u};
    auto scan = [&](auto cfg, const int64_t row, const bool row_ok, const bool ordered, bool& except) -> bool {
       using C = decltype(cfg);
       constexpr int S_ = C::sch;
       constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2, BYTES = C::bytes, DECODED = C::decoded;
-      using F = typename FxF<S_>::type;
       using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, fx_nib, uint2>::type>::type;
       const FastParams& P = BYTES ? fpb : fp;
       const uint16_t* cm = BYTES ? bmap : cmap;
@@ -173,163 +359,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideA : wideA) : reinterpret_cast<const TabT*>(permA));
       const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cm) + 512;
       const uint8_t* TAp = TRp + (CHAIN ? (BYTES ? b_tr : c_tr) : 0u);
-      uint32_t state = P.R_start;
-      uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
-      uint32_t na = 0;
-      if (ragged && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);
-      {
-         F fa[8], fb[8];
-         uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
-         if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
-         lookup8(fa, wk.z, wk.w, tabR);
-#pragma unroll
-         for (int k = CH - 1; k >= 0; --k) {
-            if (!ragged || (whole && !DECODED && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
-            lookup8(fb, wk.x, wk.y, tabR);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-               const uint32_t entry = state;
-               const uint32_t mx = chain8_back(fa, state, TRp);
-               gsel = mx >= P.hit_min ? (uint32_t)(2 * k + 1) : gsel;
-               esel = mx >= P.hit_min ? entry : esel;
-               asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (k >= 1) {
-               wk = wn;
-               lookup8(fa, wk.z, wk.w, tabR);
-               if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-               const uint32_t entry = state;
-               const uint32_t mx = chain8_back(fb, state, TRp);
-               gsel = mx >= P.hit_min ? (uint32_t)(2 * k) : gsel;
-               esel = mx >= P.hit_min ? entry : esel;
-               asm volatile("" : "+v"(esel));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-         }
-      }
-      // a class-level scan of raw bytes that met a byte >= 0x80: the tile is redone with the byte-level tables / after a decode;
-      // a program that has neither (GEN without byte-level tables) hands just those ROWS to the general procedure
-      bool row_hi = false;
-      if (!BYTES && !DECODED && !raw) {
-         row_hi = (na & 0x80808080u) != 0;
-         if ((HAS_B || !GEN) && __builtin_amdgcn_ballot_w64(row_hi) != 0) return true;
-      }
-      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
-      {
-         // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
-         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
-         const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
-         F f[8];
-         lookup8(f, rw.x, rw.y, tabR);
-         uint32_t st = esel, loc = 8;
-#pragma unroll
-         for (int i = 7; i >= 0; --i) {
-            st = fxstep(f[i], st, TRp);
-            loc = st >= P.hit_min ? (uint32_t)i : loc;
-         }
-         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
-         const F fz = tabR[0];   // leading NUL
-         state = fxstep(fz, state, TRp);
-         s = state >= P.hit_min ? 1u : s;
-      }
-      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8: the row is queued for the decode pass
-      // (GEN, class-level tables: a row that ended in the overlap state of a bordered prefix literal, or that holds a byte >= 0x80)
-      except = (BYTES && state == P.inv) || (GEN && !BYTES && !DECODED && ((P.inv_on != 0 && state == P.inv) || row_hi));
-      // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
-      uint32_t cur = (s != 0 && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
-      uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
-      uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
-      if (s == 1) {
-         const F f = tabA[0];
-         cur = fxstep(f, cur, TAp);
-         mm = cur >= P.acc_min ? 2u : 0u;
-      }
-      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-         uint32_t o[8];
-         fetch32<RAGGED, false>(o, tb, lane, j, (uint32_t)L);
-         constexpr int GB = 4;   // 8-symbol groups whose lookups are issued together
-         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
-#pragma unroll
-         for (int gb = 0; gb < 4; gb += GB) {
-            F f[8 * GB];
-#pragma unroll
-            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
-#pragma unroll
-            for (int g = 0; g < GB; ++g) {
-               const uint32_t entry = cur;
-               uint32_t st[8];
-#pragma unroll
-               for (int q = 0; q < 8; ++q) {
-                  cur = fxstep(f[8 * g + q], cur, TAp);
-                  st[q] = cur;
-               }
-               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-               const bool hit = mx >= P.acc_min;
-               gl = hit ? (uint32_t)(gb + g) : gl;
-               el = hit ? entry : el;
-               blo = hit ? o[2 * (gb + g)] : blo;
-               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
-            }
-         }
-         {
-            F fr8[8];
-            lookup8(fr8, blo, bhi, tabA);
-            uint32_t st = el, loc = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-               st = fxstep(fr8[q], st, TAp);
-               loc = st >= P.acc_min ? (uint32_t)q : loc;
-            }
-            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
-         }
-         j += 32u;
-         // matches longer than the window: 8 symbols per round trip, the next group read one round ahead (see fx_search_fast)
-         if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-            const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
-            uint32_t gb = j & ~7u;
-            uint32_t t0[2], t1[2];
-            group_words<RAGGED, false>(t0[0], t0[1], tb, lane, gb, (uint32_t)L);
-            group_words<RAGGED, false>(t1[0], t1[1], tb, lane, gb + 8u, (uint32_t)L);
-            do {
-               uint32_t t2[2];
-               group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
-               const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
-               const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
-               F f8[8];
-               lookup8(f8, o0, o1, tabA);
-               uint32_t loc = 8;
-#pragma unroll
-               for (int q = 0; q < 8; ++q) {
-                  cur = fxstep(f8[q], cur, TAp);
-                  loc = cur >= P.acc_min ? (uint32_t)q : loc;
-               }
-               mm = loc != 8u ? j + loc + 3u : mm;
-               j += 8u;
-               gb += 8u;
-               t0[0] = t1[0]; t0[1] = t1[1];
-               t1[0] = t2[0]; t1[1] = t2[1];
-            } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
-         }
-      }
-      uint32_t flag = 0;
-      int32_t fr = 0, tt = 0;
-      if (SPANS) {
-         if (s != 0 && mm != 0) {   // api_internal_m.F90:140-148
-            fr = (int32_t)(s - 1);
-            if (fr == 0) fr = 1;
-            tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
-            if (fr > 0 && tt > 0) flag = 1;
-            else { fr = 0; tt = 0; }
-         }
-      } else {
-         flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
-      }
-      emit(row, row_ok && !except, ordered, flag, fr, tt);
-      return false;
+      return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered, except, emit);
    };
 
    // ---- the wave's loop: tiles of the batch, and -- when its queue would overflow, and at the end -- gathered tiles of exception rows

@@ -13,6 +13,7 @@
 #include <type_traits>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/forgex_amd_bench.h"

@@ -1,6 +1,6 @@
 // Explicit instantiation of the tile-kernel launchers (and with them the kernels) for ONE chunk count: compiled once per
 // -DFX_INST_CH=<1|2|3|4|6|8|12|16> so that the variants build in parallel (forgex_amd/csrc/Makefile).
-#include "fx_one.hpp"
+#include "fx_multi.hpp"
 
 #define FX_X(CH, M, S)                                           \
    template hipError_t launch_fast<CH, M, S> FX_TILE_SIG_FAST;   \
@@ -11,3 +11,5 @@ FX_TILE_COMBOS(FX_X, FX_INST_CH)
 #define FX_Y(CH, S, B, G) template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_COMBOS(FX_Y, FX_INST_CH)
 #undef FX_Y
+
+template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;

@@ -11,7 +11,7 @@
 //   fx_general           one lane = one row through fxrow::run_row (row_engine.hpp): every mode, UTF-8 decode
 //                        on device, candidate-list driver, literal search, `.match.`; also the fix-up pass for
 //                        rows the fast kernel flags as non-ASCII.
-#include "fx_one.hpp"
+#include "fx_multi.hpp"
 
 #ifndef FX_SINGLE_TU   // the launcher instantiations live in fx_tile_inst.hip (one object per chunk count)
 #define FX_X(CH, M, S)                                                  \
@@ -22,6 +22,14 @@ FX_TILE_ALL(FX_X)
 #define FX_X(CH, S, B, G) extern template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_ALL(FX_X)
 #undef FX_X
+extern template hipError_t launch_multi<1> FX_MULTI_SIG;
+extern template hipError_t launch_multi<2> FX_MULTI_SIG;
+extern template hipError_t launch_multi<3> FX_MULTI_SIG;
+extern template hipError_t launch_multi<4> FX_MULTI_SIG;
+extern template hipError_t launch_multi<6> FX_MULTI_SIG;
+extern template hipError_t launch_multi<8> FX_MULTI_SIG;
+extern template hipError_t launch_multi<12> FX_MULTI_SIG;
+extern template hipError_t launch_multi<16> FX_MULTI_SIG;
 #endif
 
 // =========================================================================================================
@@ -1028,13 +1036,63 @@ int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, in
    return FXAMD_OK;
 }
 
-// m patterns over the same device-resident rows: results pattern-major ([m][n]).  One pass of the pipeline per pattern, enqueued
-// back to back on the stream (the elemental operators with an ARRAY of patterns, forgex.F90:74 / :163, against one batch).
+// m patterns over the same device-resident rows: results pattern-major ([m][n]) -- the elemental operators with an ARRAY of patterns
+// (forgex.F90:74 / :163) against one batch.  Patterns on the 8-state tile tables (rows of up to 256 bytes) share ONE pass over the
+// rows, a group of up to multi_max_patterns() per launch of fx_search_multi; every other pattern runs its own pipeline.
 int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream) {
-   if (!progs || m < 0 || n < 0 || !d_flags || (d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
-   for (int32_t i = 0; i < m; ++i) {
+   if (!progs || m < 0 || n < 0 || row_len < 0 || !d_flags || (d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
+   for (int32_t i = 0; i < m; ++i)
       if (!progs[i]) return FXAMD_E_ARG;
+   if (n == 0 || m == 0) return FXAMD_OK;
+   hipStream_t st = (hipStream_t)hip_stream;
+   std::vector<int32_t> fused;
+   if (!long_row(row_len) && !std::getenv("FXAMD_NO_MULTI"))
+      for (int32_t i = 0; i < m; ++i) {
+         const FxpHeader& h = progs[i]->prog.hdr();
+         if (progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&
+             fast_scheme(h, d_rows, row_len) == 0)
+            fused.push_back(i);
+      }
+   const int ch = tile_chunks(row_len);
+   const int gmax = ch > 0 ? multi_max_patterns(ch) : 0;
+   if ((int)fused.size() < 2 || gmax < 2) fused.clear();
+   std::vector<char> done((size_t)m, 0);
+   int dev = -1;
+   if (!fused.empty()) FX_HIP(hipGetDevice(&dev));
+   for (size_t g0 = 0; g0 < fused.size(); g0 += (size_t)gmax) {
+      FxMultiArgs a;
+      std::memset(&a, 0, sizeof(a));
+      const size_t g1 = std::min(fused.size(), g0 + (size_t)gmax);
+      if (g1 - g0 < 2) break;   // a single leftover pattern takes its own (faster) pipeline
+      for (size_t k = g0; k < g1; ++k) {
+         fxamd_program* p = progs[fused[k]];
+         std::lock_guard<std::mutex> g(p->mu);
+         uint8_t* d_blob = nullptr;
+         const int rc = blob_for_device(p, dev, &d_blob);
+         if (rc != FXAMD_OK) return rc;
+         a.blob[a.m] = d_blob;
+         a.fp[a.m] = params_of(p->prog.hdr(), 0, false);
+         a.slot[a.m] = (uint32_t)fused[k];
+         ++a.m;
+         p->last_path = 15;   // one pass shared with other patterns
+      }
+      hipError_t e = hipErrorInvalidValue;
+      switch (ch) {
+         case 1: e = launch_multi<1>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         case 2: e = launch_multi<2>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         case 3: e = launch_multi<3>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         case 4: e = launch_multi<4>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         case 6: e = launch_multi<6>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         case 8: e = launch_multi<8>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         case 12: e = launch_multi<12>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         default: e = launch_multi<16>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+      }
+      FX_HIP(e);
+      for (size_t k = g0; k < g1; ++k) done[(size_t)fused[k]] = 1;
+   }
+   for (int32_t i = 0; i < m; ++i) {
+      if (done[(size_t)i]) continue;
       const int rc = fxamd_match_batch_device(progs[i], d_rows, n, row_len, d_flags + (int64_t)i * n, d_from ? d_from + (int64_t)i * n : nullptr,
                                               d_to ? d_to + (int64_t)i * n : nullptr, hip_stream);
       if (rc != FXAMD_OK) return rc;

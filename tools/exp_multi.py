@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""m patterns over one batch: fx_search_multi (one pass over the rows) against one pipeline per pattern (FXAMD_NO_MULTI=1 in a
+second process), and against a single pattern.  Usage: python tools/exp_multi.py [cfg] [rows]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import forgex_amd as fx
+from forgex_amd import synth
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else synth.SHAPES[cfg][0]
+rows = synth.batch(cfg, 0, n, torch.device("cuda"))
+sets = {
+    "6 mixed (test_many_patterns)": [rb"[a-z]+\d+", rb"\d{3}-\d{4}", rb"zz+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d"],
+    "6 on the 8-state tables": [rb"[a-z]+\d+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d", rb"x[yz]+\d", rb"[a-f]+ [g-z]"],
+    "2 on the 8-state tables": [rb"[a-z]+\d+", rb"(ab|cd)+\d"],
+}
+
+
+def rate(fn, reps=20):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+single = fx.Program(rb"[a-z]+\d+", fx.OP_SEARCH)
+out1 = single.match_device(rows)
+t1 = rate(lambda: single.match_device(rows, out=out1))
+print("%s %d rows: single pattern %.3f ms (path %d)  [FXAMD_NO_MULTI=%s]" % (cfg, n, t1 * 1e3, single.last_path(), os.environ.get("FXAMD_NO_MULTI", "")), flush=True)
+for name, pats in sets.items():
+    progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+    tm = rate(lambda: fx.match_many(progs, rows), reps=10)
+    print("  %-30s %.3f ms = %.2f x single   paths %s" % (name, tm * 1e3, tm / t1, [p.last_path() for p in progs]), flush=True)
