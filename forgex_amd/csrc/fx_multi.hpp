@@ -2,10 +2,14 @@
 // elemental over `pattern` too, src/forgex.F90:74,163).  A tile of 64 rows is staged in LDS once; the tables of all m patterns
 // (8-state v_perm scheme: 4 KB each) sit in LDS next to the tiles, and the wave that owns the tile scans it once per pattern
 // (fx_scan_tile), writing pattern p's results to flags[p*n + row] (from / to likewise).  HBM traffic: the rows once plus m result
-// sets, instead of m times the rows.  Rows a pattern's tables cannot answer -- a byte >= 0x80, the overlap state of a bordered
-// prefix literal -- go through the general row procedure (fxrow::run_row) right there, one lane per row.
+// sets, instead of m times the rows.
+// The kernel is the FIRST PASS of every pattern's multi-pass pipeline (what fx_search_fast's MODE 0 does), sharing the staging:
+// a tile with a byte >= 0x80 is deferred for the patterns that have a later pass for such tiles (its rows are marked
+// FX_NEEDS_GENERAL in that pattern's flags, the pattern's "deferred" word is set), and rows a pattern's tables cannot answer -- a
+// byte >= 0x80 when the pattern has no such pass, the overlap state of a bordered prefix literal -- are appended to that
+// pattern's worklist.  The host then enqueues each pattern's own (gated, usually empty) follow-up passes.
 // The scans are VALU-bound (about 3.4 instructions per byte per pattern), so the pass costs about m times the compute of one
-// pattern; what is saved is the memory time of the other m-1 passes and their launches.
+// pattern; what is saved is the memory time of the other m-1 passes.
 #pragma once
 #include "fx_one.hpp"
 
@@ -14,6 +18,9 @@ struct FxMultiArgs {
    const uint8_t* blob[FX_MULTI_MAX];   // the patterns' uploaded program images
    FastParams fp[FX_MULTI_MAX];         // class-level parameters of each (v_perm scheme)
    uint32_t slot[FX_MULTI_MAX];         // result slot of each: its flags start at flags + slot * n (from / to likewise)
+   uint32_t* ctr[FX_MULTI_MAX];         // this call's counter group of each ([0] tiles deferred, [1] rows in its worklist)
+   uint32_t* worklist[FX_MULTI_MAX];    // rows left to each pattern's fix-up
+   uint32_t defer_tiles[FX_MULTI_MAX];  // 1: a later pass of this pattern takes whole tiles that hold a byte >= 0x80
    uint32_t m;
 };
 
@@ -32,6 +39,14 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
          tabs[p * 512u + 256u + i] = gA[i];
       }
    }
+   // the counter words of consecutive calls alternate: this call zeroes the other group of every pattern (see fx_search_fast)
+   if (blockIdx.x == 0 && threadIdx.x < a.m) {
+      uint32_t* other = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(a.ctr[threadIdx.x]) ^ 16u);
+      other[0] = 0u;
+      other[1] = 0u;
+      other[2] = 0u;
+      other[3] = 0u;
+   }
    __syncthreads();
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    uint4* tile = tiles + wave * (64 * (CH + 1));
@@ -42,6 +57,7 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave, wave_stride = (int64_t)gridDim.x * WPB;
+   uint32_t deferred_any = 0;   // bit p: this wave deferred a tile for pattern p
    uint4 stage[CH];
    if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
    else load_tile<CH>(stage, rows, wave_global << 6, n, lane);
@@ -54,11 +70,30 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
       t += wave_stride;   // the ONE place the staging registers are reloaded
       if (RAGGED) load_tile<CH>(stage, rows, t << 6, n, lane, true, Lr);
       else load_tile<CH>(stage, rows, t << 6, n, lane);
-      // rows that are not whole chunks: pad once, remember the OR of the row's own bytes (every pattern asks for it)
+      // once per tile: pad rows that are not whole chunks, and the OR of the row's own bytes (every pattern asks for it)
       FxScanCtx sc{tile, tb, lane, L, Lr, whole, false, 0u};
       if (RAGGED && !whole) sc.pre_na = pad_rows<CH>(tile, lane, Lr);
+      else {
+         uint32_t na = 0;
+#pragma unroll
+         for (int k = 0; k < CH; ++k) {
+            if (!RAGGED || (uint32_t)k < (Lr >> 4)) {
+               const uint4 c = tile[tile_cell(lane, k)];
+               na |= c.x | c.y | c.z | c.w;
+            }
+         }
+         sc.pre_na = na;
+      }
+      const bool tile_hi = __builtin_amdgcn_ballot_w64((sc.pre_na & 0x80808080u) != 0) != 0;
       for (uint32_t p = 0; p < a.m; ++p) {
          const int64_t base = (int64_t)a.slot[p] * n;
+         const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
+         sc.raw = (h->flags & FXP_F_RAW_BYTES) != 0;
+         if (tile_hi && !sc.raw && a.defer_tiles[p] != 0u) {   // left whole to this pattern's pass over deferred tiles
+            if (row_ok) flags[base + row] = FX_NEEDS_GENERAL;
+            deferred_any |= 1u << p;
+            continue;
+         }
          auto emit = [&](const int64_t r, const bool live, const bool, const uint32_t flag, const int32_t fr, const int32_t tt) {
             if (live) {
                flags[base + r] = (uint8_t)flag;
@@ -70,27 +105,26 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
          };
          const uint2* tR = tabs + p * 512u;
          const uint2* tA = tR + 256;
-         const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
-         sc.raw = (h->flags & FXP_F_RAW_BYTES) != 0;
          bool except = false;
-         if (RAGGED && !whole) (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
-         else (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, false>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
-         if (__builtin_amdgcn_ballot_w64(except && row_ok) != 0) {
-            if (except && row_ok) {   // the general row procedure for the rows these tables cannot answer
-               fxrow::ProgView pv(a.blob[p]);
-               fxrow::DfaSim sim(pv);
-               fxrow::Result res;
-               FxGlobalRow gr{rows + row * (int64_t)L};
-               fxrow::run_row(pv, sim, gr, (int)L, res);
-               flags[base + row] = (uint8_t)res.flag;
-               if (SPANS) {
-                  from[base + row] = res.from;
-                  to[base + row] = res.to;
-               }
+         (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
+         // rows these tables cannot answer: marked, and listed for the pattern's row-level fix-up (one atomic per tile that has any)
+         const bool listed = except && row_ok;
+         const uint64_t em = __builtin_amdgcn_ballot_w64(listed);
+         if (em != 0) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&a.ctr[p][1], (uint32_t)__builtin_popcountll(em));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (listed) {
+               a.worklist[p][wbase + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+               flags[base + row] = FX_NEEDS_GENERAL;
             }
          }
       }
    }
+   // one plain store per wave and pattern (the value only gates the pattern's pass over deferred tiles)
+   if (lane == 0)
+      for (uint32_t p = 0; p < a.m; ++p)
+         if ((deferred_any >> p) & 1u) a.ctr[p][0] = 1u;
 }
 
 // waves per block: 8 when that keeps more waves on a CU than blocks of 4 (the tables are stored once per block)

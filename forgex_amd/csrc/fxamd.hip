@@ -587,8 +587,18 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
 // kernel writes them itself; for every other path the function returns FX_NOT_PACKED before anything is enqueued and the caller
 // runs the unpacked pipeline into scratch and packs it with one more kernel.
 static constexpr int FX_NOT_PACKED = 1;
+// first_pass: FX_FP_OWN = the usual call; FX_FP_PREPARE = a shared first pass (fx_search_multi) is about to run for this pattern:
+// flip the counter group, make the worklist, report what the shared kernel needs in *shared -- nothing is enqueued;
+// FX_FP_DONE = the shared first pass has been enqueued: only this pattern's follow-up passes.
+enum { FX_FP_OWN = 0, FX_FP_PREPARE = 1, FX_FP_DONE = 2 };
+struct SharedFirstPass {
+   uint32_t* ctr = nullptr;
+   uint32_t* worklist = nullptr;
+   uint32_t defer_tiles = 0;
+};
 static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
-                         uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode = 0u) {
+                         uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode = 0u, int first_pass = FX_FP_OWN,
+                         SharedFirstPass* shared = nullptr) {
    const FxpHeader& h = p->prog.hdr();
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
@@ -629,7 +639,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    const int scheme = fast_scheme(h, d_rows, row_len);
    if (scheme >= 0) {
       const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
-      sc->parity ^= 1u;
+      if (first_pass != FX_FP_DONE) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
       const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
@@ -642,7 +652,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
       const bool keep_multipass = !is_match && half_rows(scheme, row_len);
       first.half = keep_multipass && d_from != nullptr;
-      if (!is_match && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !keep_multipass && !std::getenv("FXAMD_MULTIPASS")) {
+      if (first_pass == FX_FP_OWN && !is_match && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !keep_multipass && !std::getenv("FXAMD_MULTIPASS")) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
          // the in-LDS decode on the others, exception rows through per-wave queues -- decoded in LDS, or, for programs whose tables
          // cannot decode, through the general row procedure); last_path 9 / 10 / 11 (12 / 13 / 14: general procedure for the queued rows)
@@ -654,12 +664,18 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
-      if (bytes || !utf8_tables) {
+      if (bytes || !utf8_tables || first_pass != FX_FP_OWN) {
          const int rc = grow_worklist(sc, n);
          if (rc != FXAMD_OK) return rc;
          first.worklist = marked.worklist = listp.worklist = sc->d_worklist;
          listp.gate_word = 1;
          listp.grid_tiles = (n + 63) >> 6;
+      }
+      if (first_pass == FX_FP_PREPARE) {
+         shared->ctr = ctr;
+         shared->worklist = sc->d_worklist;
+         shared->defer_tiles = first.defer_tiles;
+         return FXAMD_OK;
       }
       // exception rows of a byte-level pass: the decode pass over the gathered worklist when the class-level tables can decode,
       // else the row-level fix-up through the general engine
@@ -685,11 +701,11 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          return FXAMD_OK;
       };
       if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
-         FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+         if (first_pass == FX_FP_OWN) FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          p->last_path = 1 + big;
          return FXAMD_OK;
       }
-      if (bytes && scheme != 0) {
+      if (bytes && scheme != 0 && first_pass == FX_FP_OWN) {
          // no 8-state class-level tables to be faster with on ASCII: the byte-level tables take every tile, UTF-8 or not, in one pass
          if (is_match) FX_HIP(match_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
          else FX_HIP(fast_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
@@ -697,7 +713,9 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          return exceptions();
       }
       // first pass with the class-level tables: pure-ASCII tiles are finished here
-      if (is_match) FX_HIP(match_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
+      if (first_pass == FX_FP_DONE) {
+         // (done by the shared kernel)
+      } else if (is_match) FX_HIP(match_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
       else FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
       if (bytes) {
          // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
@@ -1069,13 +1087,23 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          fxamd_program* p = progs[fused[k]];
          std::lock_guard<std::mutex> g(p->mu);
          uint8_t* d_blob = nullptr;
-         const int rc = blob_for_device(p, dev, &d_blob);
+         int rc = blob_for_device(p, dev, &d_blob);
+         if (rc != FXAMD_OK) return rc;
+         DevScratch* sc = nullptr;
+         rc = scratch_for(p, dev, st, &sc);
+         if (rc != FXAMD_OK) return rc;
+         SharedFirstPass sh;
+         const int64_t slot = fused[k];
+         rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr, d_to ? d_to + slot * n : nullptr, st, 0u,
+                            FX_FP_PREPARE, &sh);
          if (rc != FXAMD_OK) return rc;
          a.blob[a.m] = d_blob;
          a.fp[a.m] = params_of(p->prog.hdr(), 0, false);
-         a.slot[a.m] = (uint32_t)fused[k];
+         a.slot[a.m] = (uint32_t)slot;
+         a.ctr[a.m] = sh.ctr;
+         a.worklist[a.m] = sh.worklist;
+         a.defer_tiles[a.m] = sh.defer_tiles;
          ++a.m;
-         p->last_path = 15;   // one pass shared with other patterns
       }
       hipError_t e = hipErrorInvalidValue;
       switch (ch) {
@@ -1089,7 +1117,23 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          default: e = launch_multi<16>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
       }
       FX_HIP(e);
-      for (size_t k = g0; k < g1; ++k) done[(size_t)fused[k]] = 1;
+      // every pattern's own follow-up passes (tiles it deferred, rows it listed): gated kernels, empty on pure-ASCII batches
+      for (size_t k = g0; k < g1; ++k) {
+         fxamd_program* p = progs[fused[k]];
+         std::lock_guard<std::mutex> g(p->mu);
+         uint8_t* d_blob = nullptr;
+         int rc = blob_for_device(p, dev, &d_blob);
+         if (rc != FXAMD_OK) return rc;
+         DevScratch* sc = nullptr;
+         rc = scratch_for(p, dev, st, &sc);
+         if (rc != FXAMD_OK) return rc;
+         const int64_t slot = fused[k];
+         rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr, d_to ? d_to + slot * n : nullptr, st, 0u,
+                            FX_FP_DONE, nullptr);
+         if (rc != FXAMD_OK) return rc;
+         p->last_path = 15;   // first pass shared with other patterns
+         done[(size_t)slot] = 1;
+      }
    }
    for (int32_t i = 0; i < m; ++i) {
       if (done[(size_t)i]) continue;
