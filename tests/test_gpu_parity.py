@@ -530,20 +530,40 @@ def test_prefix_and_suffix_literal_patterns_on_tile_kernel(fx):
                 assert int(of.sum()) > 0, pat
 
 
-def test_many_patterns_over_one_batch(fx):
-    """fxamd_match_multi_device: an array of patterns against the same rows, results pattern-major."""
+@pytest.mark.parametrize("shape", ["cfg3", "cfg4", "cfg2-ragged", "cfg5-many"])
+def test_many_patterns_over_one_batch(fx, shape):
+    """fxamd_match_multi_device: an array of patterns against the same rows, results pattern-major.  Patterns on the 8-state tile
+    tables share ONE pass over the rows (fx_search_multi, last_path 15) -- pure-ASCII rows, UTF-8 rows with broken sequences (tiles
+    deferred to each pattern's own passes), ragged row lengths, bordered prefix literals (rows listed for the fix-up), more patterns
+    than one launch takes -- the others run their own pipeline; every result against the oracle."""
     import torch
     from forgex_amd import synth
-    rows = synth.batch("cfg3", 0, 20000, torch.device("cuda"))
+    dev = torch.device("cuda")
     pats = [rb"[a-z]+\d+", rb"\d{3}-\d{4}", rb"zz+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d"]
+    if shape == "cfg3":
+        rows = synth.batch("cfg3", 0, 20000, dev)
+    elif shape == "cfg4":
+        rows = synth.batch("cfg4", 0, 12000, dev)
+        rows[::9, 7] = 0xFF
+        pats = [synth.PATTERNS["cfg4"].encode(), "[ぁ-ん]+".encode(), rb"[a-z]+", rb"aa[bc]", "ω[α-ω]".encode(), rb"\w+x"]
+    elif shape == "cfg2-ragged":
+        rows = synth.batch("cfg2", 0, 30000, dev).reshape(-1)[:19200 * 100].reshape(19200, 100).contiguous()
+        pats = [rb"foo(bar|baz)", rb"[a-z]+\d+", rb"aa[bc]", rb"q[u-z]+", b"foobar", rb"(ab|cd)+e"]
+    else:
+        rows = synth.batch("cfg5", 0, 15000, dev)
+        pats = [rb"[a-z]+\d+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d", rb"x[yz]+\d", rb"[a-f]+ [g-z]", rb"q\d", rb"[0-9]+", rb"k+ ", rb"a.c\d", rb"zz+", rb"\d{3}-\d{4}"]
     progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
     f, a, b = fx.match_many(progs, rows)
+    torch.cuda.synchronize()
+    assert sum(1 for p in progs if p.last_path() == 15) >= 4, [p.last_path() for p in progs]
+    f2, _, _ = fx.match_many(progs, rows, spans=False)
     torch.cuda.synchronize()
     host = rows.cpu().numpy()
     for i, p in enumerate(pats):
         of, oa, ob = oracle_lib.batch(2, p, host, NT)
-        assert np.array_equal(f[i].cpu().numpy(), of), p
-        assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), p
+        assert np.array_equal(f[i].cpu().numpy(), of), (shape, p, progs[i].last_path())
+        assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), (shape, p)
+        assert np.array_equal(f2[i].cpu().numpy(), of), (shape, p, "flags only")
 
 
 def test_batch_shapes_and_handle_reuse(fx):
