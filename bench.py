@@ -294,7 +294,6 @@ def main():
     rows_per_gpu = args.rows or (n_cfg if cfg != "cfg5" else n_cfg // 8)
     pattern = synth.PATTERNS[cfg]
     start = rank * rows_per_gpu
-    rows = synth.batch(cfg, start, rows_per_gpu, dev)
     prog = forgex_amd.Program(pattern, forgex_amd.OP_SEARCH)
     assert prog.status == 0
     spans = not args.flags_only
@@ -302,6 +301,8 @@ def main():
     frm = torch.empty(rows_per_gpu, dtype=torch.int32, device=dev) if spans else None
     to = torch.empty(rows_per_gpu, dtype=torch.int32, device=dev) if spans else None
     out = (flags, frm, to)
+    # the batch is generated on the GPU LAST (seconds of generator kernels), so that the warm-up steps follow a busy GPU, not an idle gap
+    rows = synth.batch(cfg, start, rows_per_gpu, dev)
 
     def step():
         prog.match_device(rows, spans=spans, out=out)

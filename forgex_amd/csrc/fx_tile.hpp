@@ -1152,7 +1152,9 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    int64_t blocks = (n_tiles + 3) / 4;
    // grid-stride beyond the cap (guide §6 G11); a whole number of rounds of what is resident (two blocks per CU at 256-byte rows,
    // three with half-row staging), so that the last round fills the chip too
-   const int64_t cap = MODE == 4 ? 256 : ((CH == 8 && Lr > 16u * CH) ? 256 * 9 : 256 * 8);
+   // (the gated passes -- marked tiles, worklist -- usually find nothing to do: a grid of what is resident, so that an empty pass is
+   //  one round of blocks that leave at once)
+   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH == 8 && Lr > 16u * CH) ? 256 * 9 : 256 * 8));
    if (blocks > cap) blocks = cap;
    // decode passes: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
