@@ -281,13 +281,34 @@ struct HostPipe {
    int device = -1;
    HostSlot slot[2];
 };
+// The pipes are shared by all handles of the process (a scalar `pattern .in. text` of the Fortran module compiles a fresh handle per
+// call: per-handle streams, events and pinned buffers would cost more than the match): a caller takes a free pipe of its device, or
+// makes one, and hands it back.  They live until the process ends.
+static std::mutex g_pipe_mu;
+static std::vector<HostPipe*> g_free_pipes;
+static HostPipe* acquire_pipe(int dev) {
+   std::lock_guard<std::mutex> g(g_pipe_mu);
+   for (size_t i = 0; i < g_free_pipes.size(); ++i)
+      if (g_free_pipes[i]->device == dev) {
+         HostPipe* hp = g_free_pipes[i];
+         g_free_pipes.erase(g_free_pipes.begin() + (long)i);
+         return hp;
+      }
+   HostPipe* hp = new (std::nothrow) HostPipe();
+   if (hp) hp->device = dev;
+   return hp;
+}
+static void release_pipe(HostPipe* hp) {
+   std::lock_guard<std::mutex> g(g_pipe_mu);
+   g_free_pipes.push_back(hp);
+}
 struct fxamd_program {
+   int refs = 1;                 // (guarded by g_cache_mu) handles given out + the compile cache's own reference
+   std::string cache_key;        // non-empty: this program sits in the compile cache
    fxc::Program prog;
    std::mutex mu;        // guards everything below and serialises enqueueing on this handle
-   std::mutex host_mu;   // one fxamd_match_batch_host call at a time per handle (it owns the chunk slots)
    std::vector<DevBlob> blobs;
    std::vector<DevScratch> scratch;
-   std::vector<HostPipe> pipes;
    uint64_t use_clock = 0;
    int last_path = 0;
 };
@@ -303,6 +324,27 @@ static int hip_fail(hipError_t e) {
       hipError_t _e = (call);                         \
       if (_e != hipSuccess) return hip_fail(_e);      \
    } while (0)
+
+// ---- compile cache -------------------------------------------------------------------------------------------------------
+// The reference's operators are elemental and recompile the pattern per element; a Fortran loop of scalar `pattern .in. text`
+// calls does the same through fxamd_compile.  Compiled programs (with their uploaded tables and scratch) are therefore shared:
+// fxamd_compile hands out the cached handle of an identical (op, pattern) and fxamd_program_free only drops a reference.  Handles
+// are thread-safe (p->mu), so sharing one between callers is what the header already promises.  FXAMD_NO_CACHE=1 turns it off.
+static std::mutex g_cache_mu;
+static std::vector<fxamd_program*> g_cache;   // most recently used last
+static constexpr size_t FX_CACHE_MAX = 64;
+static void destroy_program(fxamd_program* p);
+static void trim_scratch(fxamd_program* p);
+static void release_program(fxamd_program* p) {
+   bool dead = false, idle = false;
+   {
+      std::lock_guard<std::mutex> g(g_cache_mu);
+      dead = --p->refs == 0;
+      idle = p->refs == 1 && !p->cache_key.empty();   // only the cache holds it now
+   }
+   if (dead) destroy_program(p);
+   else if (idle) trim_scratch(p);   // a cached program keeps its tables and counter words, not the per-batch buffers of a large call
+}
 
 // (callers hold p->mu)
 static int blob_for_device(fxamd_program* p, int dev, uint8_t** out) {
@@ -747,6 +789,33 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    return FXAMD_OK;
 }
 
+static void trim_scratch(fxamd_program* p) {
+   std::lock_guard<std::mutex> g(p->mu);
+   for (DevScratch& s : p->scratch) {
+      if (s.d_worklist && s.worklist_rows * 4 > (int64_t(1) << 20)) {
+         (void)hipFree(s.d_worklist);
+         s.d_worklist = nullptr;
+         s.worklist_rows = 0;
+      }
+      if (s.d_unpacked) {
+         (void)hipFree(s.d_unpacked);
+         s.d_unpacked = nullptr;
+         s.unpacked_rows = 0;
+      }
+      if (s.d_nfa_scratch) {
+         (void)hipFree(s.d_nfa_scratch);
+         s.d_nfa_scratch = nullptr;
+         s.nfa_scratch_rows = 0;
+      }
+   }
+}
+static void destroy_program(fxamd_program* p) {
+   for (DevBlob& b : p->blobs)
+      if (b.d_blob) (void)hipFree(b.d_blob);
+   for (DevScratch& s : p->scratch) free_scratch(s);
+   delete p;
+}
+
 static void free_slot(HostSlot& s) {
    if (s.stream) (void)hipStreamDestroy(s.stream);
    if (s.done) (void)hipEventDestroy(s.done);
@@ -772,16 +841,47 @@ int fxamd_device_count(void) {
 int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status) {
    if (!out || pattern_len < 0 || (!pattern && pattern_len > 0) || (op != FXAMD_OP_SEARCH && op != FXAMD_OP_MATCH)) return FXAMD_E_ARG;
    fxamd_program* p = nullptr;
+   std::vector<fxamd_program*> evicted;
    try {   // nothing may cross the C boundary: the library never aborts the process
-      p = new fxamd_program();
-      p->prog = fxc::compile(std::string(pattern ? pattern : "", (size_t)pattern_len), op);
+      const bool cached = pattern_len <= 4096 && !std::getenv("FXAMD_NO_CACHE");
+      std::string key;
+      if (cached) {
+         key.assign(1, (char)('0' + op));
+         key.append(pattern ? pattern : "", (size_t)pattern_len);
+         std::lock_guard<std::mutex> g(g_cache_mu);
+         for (size_t i = g_cache.size(); i-- > 0;)
+            if (g_cache[i]->cache_key == key) {
+               p = g_cache[i];
+               g_cache.erase(g_cache.begin() + (long)i);
+               g_cache.push_back(p);
+               ++p->refs;
+               break;
+            }
+      }
+      if (!p) {
+         p = new fxamd_program();
+         p->prog = fxc::compile(std::string(pattern ? pattern : "", (size_t)pattern_len), op);
+         if (cached && p->prog.blob.size() <= (size_t(1) << 20)) {
+            std::lock_guard<std::mutex> g(g_cache_mu);
+            p->cache_key = key;
+            ++p->refs;
+            g_cache.push_back(p);
+            while (g_cache.size() > FX_CACHE_MAX) {
+               fxamd_program* old = g_cache.front();
+               g_cache.erase(g_cache.begin());
+               old->cache_key.clear();
+               if (--old->refs == 0) evicted.push_back(old);
+            }
+         }
+      }
    } catch (const std::bad_alloc&) {
-      delete p;
+      if (p && p->cache_key.empty()) delete p;
       return FXAMD_E_NOMEM;
    } catch (...) {
-      delete p;
+      if (p && p->cache_key.empty()) delete p;
       return FXAMD_E_ARG;
    }
+   for (fxamd_program* e : evicted) destroy_program(e);
    if (status) *status = p->prog.status;
    *out = p;
    return FXAMD_OK;
@@ -839,12 +939,7 @@ int fxamd_compile_nfa(int32_t n_states, int32_t entry, int32_t exit_state, int64
 
 void fxamd_program_free(fxamd_program* p) {
    if (!p) return;
-   for (DevBlob& b : p->blobs)
-      if (b.d_blob) (void)hipFree(b.d_blob);
-   for (DevScratch& s : p->scratch) free_scratch(s);
-   for (HostPipe& hp : p->pipes)
-      for (HostSlot& s : hp.slot) free_slot(s);
-   delete p;
+   release_program(p);
 }
 int32_t fxamd_program_status(const fxamd_program* p) { return p ? p->prog.status : FXAMD_E_ARG; }
 int64_t fxamd_program_blob_size(const fxamd_program* p) { return p ? (int64_t)p->prog.blob.size() : FXAMD_E_ARG; }
@@ -1160,20 +1255,14 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
       h_to = nullptr;
    }
    const bool spans = h_from != nullptr;
-   std::lock_guard<std::mutex> hg(p->host_mu);
    int dev = -1;
    FX_HIP(hipGetDevice(&dev));
-   HostPipe* hp = nullptr;
-   {
-      std::lock_guard<std::mutex> g(p->mu);
-      for (HostPipe& q : p->pipes)
-         if (q.device == dev) hp = &q;
-      if (!hp) {
-         p->pipes.emplace_back();
-         hp = &p->pipes.back();
-         hp->device = dev;
-      }
-   }
+   HostPipe* hp = acquire_pipe(dev);
+   if (!hp) return FXAMD_E_NOMEM;
+   struct PipeReturn {
+      HostPipe* hp;
+      ~PipeReturn() { release_pipe(hp); }
+   } pipe_return{hp};
    // chunk size: about 64 MB of rows (a multiple of 64 rows: whole tiles), at least one row
    const size_t rl = (size_t)(row_len > 0 ? row_len : 1);
    int64_t chunk_rows = (int64_t)((size_t(64) << 20) / rl) & ~int64_t(63);

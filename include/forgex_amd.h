@@ -48,6 +48,9 @@ typedef struct fxamd_program fxamd_program;
 #define FXAMD_INVALID_CHAR_INDEX (-9999)
 
 /* ---- compile (host only; works without a GPU) -------------------------------------------------------- */
+/* Identical (op, pattern) pairs share one compiled program: the library keeps the 64 most recently compiled ones, so a loop of
+ * scalar calls -- the elemental operators recompile per element -- pays for the compile, the table upload and the device scratch
+ * once.  Every handle returned must still be released with fxamd_program_free (it drops a reference). */
 int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status);
 
 /* Range-NFA hand-over.  States are 1..n_states; transition t goes src[t] -> dst[t] and carries the segments
@@ -112,8 +115,9 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
                              uint8_t* d_flags, int32_t* d_from, int32_t* d_to, void* hip_stream);
 
 /* Host-buffer entry used by the Fortran module; synchronous.  The batch flows through two chunk slots (about 64 MB of rows each,
- * own stream, device buffers and pinned result staging kept in the handle): the H2D copy of one chunk overlaps the kernels and
- * the D2H copy of the other.  `.match.` programs leave h_from / h_to untouched.  One call at a time per handle (further callers wait). */
+ * own stream, device buffers and pinned result staging, taken from a process-wide pool of such pipes and handed back): the H2D
+ * copy of one chunk overlaps the kernels and the D2H copy of the other.  `.match.` programs leave h_from / h_to untouched.
+ * Callable from several threads at once, on one handle or many (each call works with its own pipe). */
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
                            int32_t* h_from, int32_t* h_to);
 
