@@ -681,7 +681,12 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    const int scheme = fast_scheme(h, d_rows, row_len);
    if (scheme >= 0) {
       const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
-      if (first_pass != FX_FP_DONE) sc->parity ^= 1u;
+      // The counter groups alternate between calls, and it is a call's FIRST-PASS kernel that zeroes the other group for the call
+      // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
+      // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
+      const bool one_launch = first_pass == FX_FP_OWN && !is_match && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !half_rows(scheme, row_len) &&
+                              !std::getenv("FXAMD_MULTIPASS");
+      if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
       const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
@@ -694,7 +699,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
       const bool keep_multipass = !is_match && half_rows(scheme, row_len);
       first.half = keep_multipass && d_from != nullptr;
-      if (first_pass == FX_FP_OWN && !is_match && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !keep_multipass && !std::getenv("FXAMD_MULTIPASS")) {
+      if (one_launch) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
          // the in-LDS decode on the others, exception rows through per-wave queues -- decoded in LDS, or, for programs whose tables
          // cannot decode, through the general row procedure); last_path 9 / 10 / 11 (12 / 13 / 14: general procedure for the queued rows)

@@ -873,3 +873,39 @@ def test_packed_results_equal_unpacked_on_every_config(fx):
                 assert torch.equal(packed[off_f:off_f + n * w], a8.view(torch.uint8)) and torch.equal(packed[off_t:off_t + n * w], b8.view(torch.uint8))
                 assert fxdist.packed_layout(n, L) == (off_f, off_t, total)
     assert in_kernel >= 8
+
+
+def test_one_handle_alternating_between_pipelines(fx):
+    """One handle (the compile cache shares them) used in turn on shapes that take the multi-pass pipeline (256-byte rows: counter
+    words, worklist) and the one-launch kernel (no counters): the counter group may only flip when a first-pass kernel runs, or the
+    third call meets the first call's worklist count."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    pat = rb"[a-z]+\d+"
+    prog = fx.Program(pat, fx.OP_SEARCH)
+
+    def broken(cfg, n, every):
+        rows = synth.batch(cfg, 0, n, dev)
+        rows[::every, 9] = 0xE3   # a lead byte without its continuation bytes: exception rows
+        rows[1::every, 17] = 0x80
+        return rows
+    seq = [("cfg3", 60000, 3), ("cfg5", 2000, 5), ("cfg3", 300, 2), ("cfg5", 70000, 3), ("cfg3", 64, 1), ("cfg2", 5000, 4), ("cfg3", 9000, 7)]
+    for rep in range(2):
+        for cfg, n, every in seq:
+            rows = broken(cfg, n, every)
+            for spans in (True, False):
+                f, a, b = prog.match_device(rows, spans=spans)
+                torch.cuda.synchronize()
+                k = min(n, 3000)
+                of, oa, ob = oracle_lib.batch(2, pat, rows[:k].cpu().numpy(), NT)
+                assert np.array_equal(f[:k].cpu().numpy(), of), (cfg, n, spans, prog.last_path())
+                if spans:
+                    assert np.array_equal(a[:k].cpu().numpy(), oa) and np.array_equal(b[:k].cpu().numpy(), ob), (cfg, n)
+    # the same rows through a fresh, uncached handle give the same results everywhere (not only on the oracle's slice)
+    rows = broken("cfg3", 60000, 3)
+    f1, a1, b1 = prog.match_device(rows)
+    q = fx.Program.from_blob(prog.blob(), fx.OP_SEARCH)
+    f2, a2, b2 = q.match_device(rows)
+    torch.cuda.synchronize()
+    assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2)
