@@ -143,12 +143,15 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          mm = cur >= P.acc_min ? 2u : 0u;
       }
       if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-         uint32_t o[8];
-         fetch32<RAGGED, false>(o, tb, lane, j, (uint32_t)L);
-         constexpr int GB = 4;   // 8-symbol groups whose lookups are issued together
+         // first window: 32 symbols from j (16 for rows of up to 64 bytes, where the window is a large share of the tile's work),
+         // all lookups issued before the chain
+         constexpr int NG = CH <= 4 ? 2 : 4;
+         uint32_t o[2 * NG];
+         fetch_groups<RAGGED, NG>(o, tb, lane, j, (uint32_t)L);
+         constexpr int GB = NG;   // 8-symbol groups whose lookups are issued together
          uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
-         for (int gb = 0; gb < 4; gb += GB) {
+         for (int gb = 0; gb < NG; gb += GB) {
             F f[8 * GB];
 #pragma unroll
             for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
@@ -180,7 +183,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             }
             mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
          }
-         j += 32u;
+         j += 8u * NG;
          // matches longer than the window: 8 symbols per round trip, the next group read one round ahead (see fx_search_fast)
          if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);

@@ -333,6 +333,20 @@ __device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uin
 #pragma unroll
    for (int k = 0; k < 8; ++k) o[k] = __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u);
 }
+// the same for NG 8-symbol groups (a shorter first window for short rows)
+template <bool RAGGED, int NG>
+__device__ __forceinline__ void fetch_groups(uint32_t (&o)[2 * NG], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
+   const uint32_t base = j & ~7u, sh = j & 7u;
+   uint32_t d[2 * NG + 2];
+#pragma unroll
+   for (int g = 0; g < NG + 1; ++g) group_words<RAGGED, false>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
+   const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
+   uint32_t e[2 * NG + 1];
+#pragma unroll
+   for (int k = 0; k < 2 * NG + 1; ++k) e[k] = (up & d[k + 1]) | (~up & d[k]);
+#pragma unroll
+   for (int k = 0; k < 2 * NG; ++k) o[k] = __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u);
+}
 template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
    const uint32_t base = j & ~7u, sh = j & 7u;

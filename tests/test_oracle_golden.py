@@ -58,7 +58,7 @@ def test_appendix_a_quirks(built):
     assert out == [e for _, e in cases]
 
 
-@pytest.mark.skipif(not os.path.exists(golden.REF_DRIVER), reason="real reference (oracle/_ref) only exists in the build container")
+@pytest.mark.skipif(not os.path.exists(golden.REF_DRIVER), reason="the real reference (oracle/_ref, built from /root/reference by oracle/Makefile) is absent here; NOTE the oracle and the product share frontend.cpp, so without this test a front-end bug is caught only by the golden vectors (validate / error / prefix / suffix records)")
 def test_oracle_equals_real_reference_on_fuzz(built):
     cases = fuzz_diff.gen_cases(101, 3000)
     a = golden.run_protocol(golden.ORACLE_CLI, cases)

@@ -3,6 +3,7 @@
 //   perm8   ds_read_b64  + v_perm_b32                                (<= 8 states)
 //   wide16  ds_read_b128 + 2 v_perm_b32 + v_xor + v_and              (<= 16 states, bytes)
 //   nib16   ds_read_b64  + v_lshlrev_b32 + v_lshrrev_b64 + v_and     (<= 16 states, nibbles)
+//   perm4   ds_read_b32  + v_perm_b32                                (<= 4 states)
 // Input bytes come from a per-lane xorshift stream restricted to `spread` distinct values (LDS bank conflicts depend on it).
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -13,11 +14,13 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_step(uint32_t* out, int iters, uint32_t seed, uint32_t mask) {
    __shared__ uint2 t8[256];
    __shared__ uint4 t16[256];
+   __shared__ uint32_t t4[256];
+   t4[threadIdx.x] = (threadIdx.x * 0x9E3779B9u + seed) & 0x03030303u;
    t8[threadIdx.x] = make_uint2((threadIdx.x * 0x9E3779B9u + seed) & 0x07070707u, (threadIdx.x * 0x85EBCA6Bu) & 0x07070707u);
    t16[threadIdx.x] = make_uint4(threadIdx.x * 0x9E3779B9u & 0x07070707u, threadIdx.x * 0x85EBCA6Bu & 0x07070707u, 0x80808080u | (threadIdx.x * 77u & 0x07070707u), 0x80808080u | (threadIdx.x * 131u & 0x07070707u));
    __syncthreads();
    uint32_t x = threadIdx.x * 2654435761u + seed + blockIdx.x;
-   uint32_t st = KIND == 2 ? (x & 15u) : (x & 7u) * 0x01010101u;
+   uint32_t st = KIND == 2 ? (x & 15u) : (KIND == 3 ? (x & 3u) * 0x01010101u : (x & 7u) * 0x01010101u);
    for (int i = 0; i < iters; ++i) {
       x ^= x << 13; x ^= x >> 17; x ^= x << 5;
       const uint32_t lo = x & mask, hi = (x * 0x01000193u) & mask;
@@ -33,12 +36,18 @@ __global__ __launch_bounds__(256) void k_step(uint32_t* out, int iters, uint32_t
          for (int k = 0; k < 8; ++k) f[k] = t16[((k < 4 ? lo : hi) >> ((k & 3) * 8)) & 0xFFu];
 #pragma unroll
          for (int k = 0; k < 8; ++k) st = __builtin_amdgcn_perm(f[k].y, f[k].x, st) & __builtin_amdgcn_perm(f[k].w, f[k].z, st ^ 0x80808080u);
-      } else {
+      } else if (KIND == 2) {
          uint2 f[8];
 #pragma unroll
          for (int k = 0; k < 8; ++k) f[k] = t8[((k < 4 ? lo : hi) >> ((k & 3) * 8)) & 0xFFu];
 #pragma unroll
          for (int k = 0; k < 8; ++k) st = (uint32_t)(((((uint64_t)f[k].y) << 32) | f[k].x) >> (st << 2)) & 15u;
+      } else {
+         uint32_t f[8];   // <= 4 states: 4 next-state bytes per symbol, ds_read_b32 + v_perm_b32
+#pragma unroll
+         for (int k = 0; k < 8; ++k) f[k] = t4[((k < 4 ? lo : hi) >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+         for (int k = 0; k < 8; ++k) st = __builtin_amdgcn_perm(f[k], f[k], st);
       }
    }
    out[blockIdx.x * blockDim.x + threadIdx.x] = st;
@@ -53,7 +62,7 @@ int main() {
    const int iters = 20000;
    const uint32_t masks[3] = {0x0F0F0F0Fu, 0x3F3F3F3Fu, 0xFFFFFFFFu};
    for (int m = 0; m < 3; ++m)
-      for (int kind = 0; kind < 3; ++kind)
+      for (int kind = 0; kind < 4; ++kind)
          for (int bpc = 2; bpc <= 4; bpc += 2) {
             const int blocks = 256 * bpc;
             for (int rep = 0; rep < 2; ++rep) {
@@ -61,6 +70,7 @@ int main() {
                if (kind == 0) hipLaunchKernelGGL(k_step<0>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
                if (kind == 1) hipLaunchKernelGGL(k_step<1>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
                if (kind == 2) hipLaunchKernelGGL(k_step<2>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
+               if (kind == 3) hipLaunchKernelGGL(k_step<3>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
                CK(hipEventRecord(b));
                CK(hipEventSynchronize(b));
             }
@@ -68,7 +78,7 @@ int main() {
             CK(hipEventElapsedTime(&ms, a, b));
             const double bytes = (double)blocks * 256 * iters * 8;   // input bytes stepped over
             printf("%-6s distinct byte values %3u, %d waves/SIMD: %.3f ms  %.2f T steps/s  (%.2f cycles per wave-step per CU at 2.4 GHz)\n",
-                   kind == 0 ? "perm8" : kind == 1 ? "wide16" : "nib16", (masks[m] & 0xFF) + 1, bpc, ms, bytes / (ms * 1e-3) / 1e12,
+                   kind == 0 ? "perm8" : kind == 1 ? "wide16" : kind == 2 ? "nib16" : "perm4", (masks[m] & 0xFF) + 1, bpc, ms, bytes / (ms * 1e-3) / 1e12,
                    ms * 1e-3 * 2.4e9 / ((double)iters * 8 * bpc * 4));
          }
    return 0;
