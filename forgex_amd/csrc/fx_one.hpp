@@ -191,6 +191,9 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             uint32_t t0[2], t1[2];
             group_words<RAGGED, false>(t0[0], t0[1], tb, lane, gb, (uint32_t)L);
             group_words<RAGGED, false>(t1[0], t1[1], tb, lane, gb + 8u, (uint32_t)L);
+            // per round only "any accept" (one max tree) + the entry state and the round's symbols are kept; the last accepting round
+            // is re-walked afterwards for the exact symbol (as in the window above) -- 4 instructions per round instead of 16
+            uint32_t jl = 0xFFFFFFFFu, el2 = 0, lo2 = 0, hi2 = 0;
             do {
                uint32_t t2[2];
                group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
@@ -198,18 +201,35 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
                F f8[8];
                lookup8(f8, o0, o1, tabA);
-               uint32_t loc = 8;
+               const uint32_t entry = cur;
+               uint32_t st[8];
 #pragma unroll
                for (int q = 0; q < 8; ++q) {
                   cur = fxstep(f8[q], cur, TAp);
-                  loc = cur >= P.acc_min ? (uint32_t)q : loc;
+                  st[q] = cur;
                }
-               mm = loc != 8u ? j + loc + 3u : mm;
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool hit = mx >= P.acc_min;
+               jl = hit ? j : jl;
+               el2 = hit ? entry : el2;
+               lo2 = hit ? o0 : lo2;
+               hi2 = hit ? o1 : hi2;
                j += 8u;
                gb += 8u;
                t0[0] = t1[0]; t0[1] = t1[1];
                t1[0] = t2[0]; t1[1] = t2[1];
             } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
+            if (__builtin_amdgcn_ballot_w64(jl != 0xFFFFFFFFu) != 0) {
+               F fr8[8];
+               lookup8(fr8, lo2, hi2, tabA);
+               uint32_t st = el2, loc = 0;
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  st = fxstep(fr8[q], st, TAp);
+                  loc = st >= P.acc_min ? (uint32_t)q : loc;
+               }
+               mm = jl != 0xFFFFFFFFu ? jl + loc + 3u : mm;
+            }
          }
       }
       uint32_t flag = 0;
