@@ -194,52 +194,30 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             // per round only "any accept" (one max tree) + the entry state and the round's symbols are kept; the last accepting round
             // is re-walked afterwards for the exact symbol (as in the window above) -- 4 instructions per round instead of 16
             uint32_t jl = 0xFFFFFFFFu, el2 = 0, lo2 = 0, hi2 = 0;
-            // SIXTEEN symbols per round trip: the second group's lookups are in flight while the first group's chain runs
             do {
-               uint32_t t2[2], t3[2];
+               uint32_t t2[2];
                group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
-               group_words<RAGGED, false>(t3[0], t3[1], tb, lane, gb + 24u, (uint32_t)L);
                const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
-               const uint32_t e3 = (up & t2[0]) | (~up & t1[1]), e4 = (up & t2[1]) | (~up & t2[0]);
                const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
-               const uint32_t o2 = __builtin_amdgcn_alignbyte(e3, e2, sh & 3u), o3 = __builtin_amdgcn_alignbyte(e4, e3, sh & 3u);
-               F f8[8], g8[8];
+               F f8[8];
                lookup8(f8, o0, o1, tabA);
-               lookup8(g8, o2, o3, tabA);
-               {
-                  const uint32_t entry = cur;
-                  uint32_t st[8];
+               const uint32_t entry = cur;
+               uint32_t st[8];
 #pragma unroll
-                  for (int q = 0; q < 8; ++q) {
-                     cur = fxstep(f8[q], cur, TAp);
-                     st[q] = cur;
-                  }
-                  const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-                  const bool hit = mx >= P.acc_min;
-                  jl = hit ? j : jl;
-                  el2 = hit ? entry : el2;
-                  lo2 = hit ? o0 : lo2;
-                  hi2 = hit ? o1 : hi2;
+               for (int q = 0; q < 8; ++q) {
+                  cur = fxstep(f8[q], cur, TAp);
+                  st[q] = cur;
                }
-               {
-                  const uint32_t entry = cur;
-                  uint32_t st[8];
-#pragma unroll
-                  for (int q = 0; q < 8; ++q) {
-                     cur = fxstep(g8[q], cur, TAp);
-                     st[q] = cur;
-                  }
-                  const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-                  const bool hit = mx >= P.acc_min;
-                  jl = hit ? j + 8u : jl;
-                  el2 = hit ? entry : el2;
-                  lo2 = hit ? o2 : lo2;
-                  hi2 = hit ? o3 : hi2;
-               }
-               j += 16u;
-               gb += 16u;
-               t0[0] = t2[0]; t0[1] = t2[1];
-               t1[0] = t3[0]; t1[1] = t3[1];
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool hit = mx >= P.acc_min;
+               jl = hit ? j : jl;
+               el2 = hit ? entry : el2;
+               lo2 = hit ? o0 : lo2;
+               hi2 = hit ? o1 : hi2;
+               j += 8u;
+               gb += 8u;
+               t0[0] = t1[0]; t0[1] = t1[1];
+               t1[0] = t2[0]; t1[1] = t2[1];
             } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
             if (__builtin_amdgcn_ballot_w64(jl != 0xFFFFFFFFu) != 0) {
                F fr8[8];
