@@ -341,7 +341,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
     reps = max(5, min(args.steps, 200))
     one_launch = prog.last_path() in (9, 10, 11, 12, 13, 14)   # fx_search_one: the step IS one kernel launch
-    fast = one_launch or prog.last_path() in (1, 3, 5, 6, 7, 8)
+    fast = one_launch or prog.last_path() in (1, 3, 5, 6, 7, 8, 16)
     whole_step = one_launch or cfg == "cfg4"   # multi-pass pipeline on non-ASCII rows: several passes share the work -> time the whole step
 
     def kernel_events(k):

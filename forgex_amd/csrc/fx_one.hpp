@@ -257,10 +257,14 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
 // pure-ASCII rows only, FXP_F_OVERLAP_SINK programs): rows the tables cannot answer -- exception rows of the byte-level tables,
 // rows with a byte >= 0x80 when there are no byte-level tables, overlap rows of a bordered prefix -- are queued the same way and
 // the gathered rows go through the GENERAL row procedure (fxrow::run_row, the body of fx_general) instead of the decode + scan.
-template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN>
+// MARKED: the follow-up of a multi-pass first pass (the half-row kernel of 256-byte rows): only tiles whose rows that pass marked
+// FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
+// and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
+template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false>
 __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
-                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode) {
+                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr) {
+   if (MARKED && gate[0] == 0u) return;   // nothing was deferred
    // out_mode 0: flags u8[n], from / to int32[n].  out_mode 1 / 2 / 4: PACKED results (what a multi-GPU host gathers):
    // `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit word i >> 6: the ballot of the tile's wave, one store per tile),
    // `from` / `to` = arrays of that many bytes per row (uint8 / uint16 / int32).
@@ -390,9 +394,15 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    uint64_t pend_mask = 0;     // lanes whose row of the last byte-level scan is an exception not yet queued (wave-uniform)
    uint32_t pend_row = 0;      // that row (per lane)
    uint32_t phase = 0, pass = wave, total = 0, pre1 = 0, pre2 = 0, pre3 = 0;
+   // marked-tile mode: does tile t hold a row the first pass left behind (FX_NEEDS_GENERAL)?  wave-uniform
+   auto tile_marked = [&](const int64_t t) -> bool {
+      const int64_t rr = (t << 6) + lane;
+      return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
+   };
+   bool live = MARKED ? tile_marked(wave_global) : true;   // the tile in `stage` is to be scanned
    uint4 stage[CH];
    if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
-   else load_tile<CH>(stage, rows, wave_global << 6, n, lane);
+   else load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
    for (int64_t t = wave_global;;) {
       bool is_tile = false;
       uint32_t take = 0, take_base = 0;
@@ -435,17 +445,24 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       if (is_tile) {
          row = (t << 6) + lane;
          row_ok = row < n;
-         if (!ALLB && !raw && (HAS_B || !GEN)) {
+         const bool process = live;
+         if (MARKED) hint = true;   // (that is why the first pass left the tile)
+         else if (!ALLB && !raw && (HAS_B || !GEN)) {
             const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
             hint = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
          }
-         if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(stage, tile, lane, Lr >> 4);
-         else if (RAGGED) store_tile_relayout<CH>(stage, tile, lane, Lr);
-         else store_tile<CH>(stage, tile, lane);
-         // the ONE place the staging registers are reloaded; a tile behind the last one is "loaded" with zero valid bytes
+         if (process) {
+            if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(stage, tile, lane, Lr >> 4);
+            else if (RAGGED) store_tile_relayout<CH>(stage, tile, lane, Lr);
+            else store_tile<CH>(stage, tile, lane);
+         }
+         // the ONE place the staging registers are reloaded; a tile behind the last one, or one this pass skips, is "loaded" with
+         // zero valid bytes
          t += wave_stride;
+         if (MARKED) live = tile_marked(t);
          if (RAGGED) load_tile<CH>(stage, rows, t << 6, n, lane, true, Lr);
-         else load_tile<CH>(stage, rows, t << 6, n, lane);
+         else load_tile<CH>(stage, rows, t << 6, n, lane, live);
+         if (!process) continue;
       } else {
          // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
          if (phase == 0 && out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's own flag words first, see above)
@@ -599,6 +616,31 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
    return hipGetLastError();
 }
+
+// the gated follow-up of the half-row first pass: 256-byte rows, 8-state class-level tables, marked tiles only
+template <int BSCH>
+hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
+                             uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate) {
+   constexpr int CH = 16;
+   const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
+   const size_t static_b = 4096 + (BSCH == 2 ? 4096 : 0) + 1024 + 64;
+   const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const size_t lds = tiles_b + table_bytes + map_lds;
+   const int64_t n_tiles = (n + 63) >> 6;
+   int64_t blocks = (n_tiles + 3) / 4;
+   if (blocks > 256 * 2) blocks = 256 * 2;   // what is resident: an empty follow-up is one round of blocks that leave at once
+   const bool spans = from && to;
+   const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, 0, BSCH, false, false, true>)
+                          : reinterpret_cast<const void*>(&fx_search_one<CH, false, 0, BSCH, false, false, true>);
+   if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+   }
+   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 256u, 0u, gate);
+   else hipLaunchKernelGGL((fx_search_one<CH, false, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 256u, 0u, gate);
+   return hipGetLastError();
+}
+#define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*)
 
 // every (CH, SCH, BSCH, GEN) the dispatch code of fxamd.hip can ask for
 #define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)

@@ -13,3 +13,9 @@ FX_ONE_COMBOS(FX_Y, FX_INST_CH)
 #undef FX_Y
 
 template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;
+
+#if FX_INST_CH == 16
+template hipError_t launch_one_marked<0> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<1> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<2> FX_ONE_MARKED_SIG;
+#endif

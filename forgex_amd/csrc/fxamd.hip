@@ -22,6 +22,9 @@ FX_TILE_ALL(FX_X)
 #define FX_X(CH, S, B, G) extern template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_ALL(FX_X)
 #undef FX_X
+extern template hipError_t launch_one_marked<0> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<1> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<2> FX_ONE_MARKED_SIG;
 extern template hipError_t launch_multi<1> FX_MULTI_SIG;
 extern template hipError_t launch_multi<2> FX_MULTI_SIG;
 extern template hipError_t launch_multi<3> FX_MULTI_SIG;
@@ -711,7 +714,8 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
-      if (bytes || !utf8_tables || first_pass != FX_FP_OWN) {
+      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && utf8_tables && !std::getenv("FXAMD_MULTIPASS");
+      if ((bytes || !utf8_tables || first_pass != FX_FP_OWN) && !marked_followup) {
          const int rc = grow_worklist(sc, n);
          if (rc != FXAMD_OK) return rc;
          first.worklist = marked.worklist = listp.worklist = sc->d_worklist;
@@ -758,6 +762,21 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          else FX_HIP(fast_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          p->last_path = 7;
          return exceptions();
+      }
+      // 256-byte rows on the 8-state tables whose tables can decode: the first pass (half-row staging when spans are asked for) and
+      // ONE gated follow-up -- the one-launch kernel over the tiles that pass marked (byte-level tables or in-LDS decode, exception
+      // queues inside) -- instead of a pass over marked tiles plus a pass over a worklist
+      if (marked_followup) {
+         FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+         const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
+         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
+         const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
+         const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
+         if (ob == 2) FX_HIP(launch_one_marked<2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
+         else if (ob == 1) FX_HIP(launch_one_marked<1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
+         else FX_HIP(launch_one_marked<0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
+         p->last_path = 16;
+         return FXAMD_OK;
       }
       // first pass with the class-level tables: pure-ASCII tiles are finished here
       if (first_pass == FX_FP_DONE) {

@@ -121,13 +121,16 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
                            int32_t* h_from, int32_t* h_to);
 
-/* Which kernel path the last fxamd_match_batch_device call on this handle used: 1 = fast kernel (+ second fast pass with
- * on-device UTF-8 decode over the tiles that hold non-ASCII bytes), 2 = general kernel, 3 = fast kernel + general fix-up (over a worklist) of non-ASCII rows and of rows where two occurrences of a bordered prefix literal overlap,
- * 4 = NFA state-set simulation (DFA too large to build), 5 / 6 = like 1 / 3 for automata with more than 8 states (wide v_perm
- * tables up to 16 states, class-indexed LDS chain tables beyond), 7 = byte-level chain tables (UTF-8 composed into the automata) over every tile + row-level
- * fix-up of structurally invalid rows, 8 = fast kernel on the pure-ASCII tiles, byte-level chain tables on the others, same fix-up.
- * (Environment FXAMD_NO_BYTE_DFA=1 disables 7 / 8 and FXAMD_NO_W16=1 the wide v_perm tables: test hooks that keep the decode pass
- * and the chain kernels reachable.) */
+/* Which kernel path the last fxamd_match_batch_device call on this handle used (tests / diagnostics).  Multi-pass pipeline of
+ * fx_search_fast / fx_match_fast (rows longer than 256 bytes, `.match.`, FXAMD_MULTIPASS=1): 1 = first pass + decode pass over deferred
+ * tiles, 3 = first pass + general fix-up over a worklist, 5 / 6 = the same for automata with more than 8 states, 7 = byte-level tables
+ * over every tile + fix-up of structurally invalid rows, 8 = first pass, byte-level tables on deferred tiles, same fix-up.
+ * 2 = general kernel, 4 = NFA state-set simulation (DFA too large to build).
+ * One-launch kernel fx_search_one: 9 = class-level tables + in-LDS decode, 10 = per-tile selection of class-level / byte-level tables,
+ * 11 = byte-level tables on every tile (12 / 13 / 14: the same with the general row procedure for queued rows).
+ * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
+ * one-launch kernel over the tiles that pass left.
+ * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE.) */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);
