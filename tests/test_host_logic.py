@@ -369,3 +369,45 @@ def test_host_compiler_under_address_and_ub_sanitizers(built, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, r.stderr.decode()[-2000:]
     assert len(r.stdout.decode().splitlines()) == len(cases)
+
+
+def test_compile_cache_shares_and_releases_programs(built, monkeypatch):
+    """fxamd_compile hands an identical (op, pattern) the cached, refcounted program (a loop of scalar calls compiles once); every
+    handle is still released with fxamd_program_free; FXAMD_NO_CACHE=1 turns the cache off; programs from blobs are never shared."""
+    import forgex_amd as fx
+    L = fx.lib()
+
+    def compile_(pat, op):
+        h = ctypes.c_void_p()
+        st = ctypes.c_int32(0)
+        assert L.fxamd_compile(pat, len(pat), op, ctypes.byref(h), ctypes.byref(st)) == 0
+        return h, st.value
+    monkeypatch.delenv("FXAMD_NO_CACHE", raising=False)
+    a, sa = compile_(rb"cache[a-z]+\d+", 0)
+    b, sb = compile_(rb"cache[a-z]+\d+", 0)
+    c, _ = compile_(rb"cache[a-z]+\d+", 1)          # the other operator: its own program
+    d, _ = compile_(rb"cache[a-z]+\d+ ", 0)         # (`.in.` trims the pattern, but the cache key is the text as passed)
+    assert a.value == b.value and sa == sb == 0
+    assert c.value != a.value and d.value != a.value
+    for h in (a, b, c, d):
+        L.fxamd_program_free(h)
+    e, _ = compile_(rb"cache[a-z]+\d+", 0)          # still cached after every handle was released
+    assert e.value == a.value
+    L.fxamd_program_free(e)
+    # more distinct patterns than the cache holds: the oldest are evicted, nothing breaks, statuses stay right
+    hs = [compile_(b"evict%d[a-z]" % i, 0) for i in range(100)]
+    assert all(st == 0 for _, st in hs)
+    bad, st = compile_(rb"a(", 0)
+    assert st == 2
+    for h, _ in hs + [(bad, st)]:
+        L.fxamd_program_free(h)
+    monkeypatch.setenv("FXAMD_NO_CACHE", "1")
+    x, _ = compile_(rb"cache[a-z]+\d+", 0)
+    y, _ = compile_(rb"cache[a-z]+\d+", 0)
+    assert x.value != y.value
+    L.fxamd_program_free(x)
+    L.fxamd_program_free(y)
+    monkeypatch.delenv("FXAMD_NO_CACHE", raising=False)
+    p = fx.Program(rb"cache[a-z]+\d+", fx.OP_SEARCH)
+    q = fx.Program.from_blob(p.blob(), fx.OP_SEARCH)
+    assert q._h.value != p._h.value and q.blob() == p.blob()
