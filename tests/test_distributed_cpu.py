@@ -26,6 +26,34 @@ for L in (128, 256, 70000):   # spans narrowed to 1, 2 and 4 bytes (config 5, co
         assert torch.equal(f, flags_all) and torch.equal(x, from_all) and torch.equal(y, to_all), L
     else:
         assert res is None
+# the same through gather_packed: each rank's shard as ONE packed image (what Program.match_device_packed returns on a GPU; built
+# here with the torch implementation of the layout), one collective, unpacked on the root
+for L in (128, 256):
+    g = torch.Generator().manual_seed(7)
+    flags_all = (torch.rand(n_total, generator=g) < 0.4).to(torch.uint8)
+    from_all = (torch.randint(1, L, (n_total,), generator=g) * flags_all).to(torch.int32)
+    to_all = (torch.randint(1, L + 1, (n_total,), generator=g) * flags_all).to(torch.int32)
+    m = b - a
+    off_f, off_t, total = fxdist.packed_layout(m, L)
+    bits, f8, t8 = fxdist.pack_results(flags_all[a:b], from_all[a:b], to_all[a:b], L)
+    img = torch.zeros(max(total, 16), dtype=torch.uint8)
+    img[:bits.numel()] = bits
+    img[off_f:off_f + f8.numel() * f8.element_size()] = f8.view(torch.uint8)
+    img[off_t:off_t + t8.numel() * t8.element_size()] = t8.view(torch.uint8)
+    res = fxdist.gather_packed(img, n_total, L, True, dst=0)
+    if rank == 0:
+        shards, sizes = res
+        assert sizes == [fxdist.shard_bounds(n_total, r, world)[1] - fxdist.shard_bounds(n_total, r, world)[0] for r in range(world)]
+        dt = fxdist.span_dtype(L)
+        w = torch.empty(0, dtype=dt).element_size()
+        fl, fr, tt = [], [], []
+        for im, mm in zip(shards, sizes):
+            o_f, o_t, _ = fxdist.packed_layout(mm, L)
+            f_, x_, y_ = fxdist.unpack_results(im[:(mm + 7) // 8], im[o_f:o_f + mm * w].view(dt), im[o_t:o_t + mm * w].view(dt), mm)
+            fl.append(f_); fr.append(x_); tt.append(y_)
+        assert torch.equal(torch.cat(fl), flags_all) and torch.equal(torch.cat(fr), from_all) and torch.equal(torch.cat(tt), to_all), L
+    else:
+        assert res is None
 # every shard regenerates its own rows: shard rows == the same index range of the full batch
 if rank == 0:
     print("OK", int(f.sum()))
