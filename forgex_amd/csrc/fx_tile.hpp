@@ -70,7 +70,7 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
 // configuration: 8 KB of LDS per wave instead of 16, so that three waves per SIMD fit.
 template <int CH>
 __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
-                                              uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable) {
+                                              uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable, bool short_seg = false) {
    // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
    // (k_lo, k_hi) = (0, CH-1); the short last one has k_hi = its last (possibly partial) chunk and the chunks behind it repeat that
    // one (never walked).  Rows start at any byte: the pieces are unaligned buffer loads.
@@ -90,6 +90,33 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __r
    for (int q = 0; q < CH; ++q) {
       const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)((64 / CH) * q) * Lr, FX_LOAD_AUX);
       v[q] = make_uint4(t.x, t.y, t.z, t.w);
+   }
+   // The short last segment of the tile's LAST row: its final piece may reach past the tile, and the range check works dword by
+   // dword on UNALIGNED dwords (rows start at any byte) -- the dword that holds the row's last bytes is dropped whole when it
+   // straddles the extent (a 257-byte row's byte 256 came back as 0: a NUL to the automaton).  Those up to three bytes are
+   // re-read one by one; nothing behind the tile's own bytes is touched.
+   if (short_seg && enable) {
+      const uint32_t tile_bytes = rows_left >= 64 ? 64u * Lr : (uint32_t)rows_left * Lr;
+      const uint32_t last_row = (rows_left >= 64 ? 64u : (uint32_t)rows_left) - 1u;
+      const uint32_t q_last = last_row / (64u / CH);
+      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+         if ((uint32_t)q != q_last) continue;   // (wave-uniform)
+         const uint32_t ps = voff + s0 + (uint32_t)((64 / CH) * q) * Lr;
+         uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+         for (int i = 0; i < 4; ++i) {
+            const uint32_t o = ps + 4u * (uint32_t)i;
+            if (o < tile_bytes && o + 4u > valid) {
+               uint32_t r = 0;
+               for (uint32_t j = 0; j < 4u; ++j)
+                  if (o + j < tile_bytes) r |= (uint32_t)tb8[o + j] << (8u * j);
+               w[i] = r;
+            }
+         }
+         v[q] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
    }
 }
 
@@ -407,9 +434,9 @@ __device__ unsigned long long fx_stamp_acc[16];
 // segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en))
+   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
-   load_tile_seg<16>(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en))
+   load_tile_seg<16>(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en), (((sg) + 1u) * 256u > Lr))
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise

@@ -909,3 +909,27 @@ def test_one_handle_alternating_between_pipelines(fx):
     f2, a2, b2 = q.match_device(rows)
     torch.cuda.synchronize()
     assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2)
+
+
+def test_long_rows_last_bytes_of_a_tile(fx):
+    """Rows longer than 256 bytes start at any byte; the final piece of the LAST row of a 64-row tile may reach past the tile, and the
+    buffer range check drops an unaligned dword that straddles the extent -- the row's last bytes have to be re-read (a 257-byte
+    row's byte 256 came back as NUL, which `$` matches).  Patterns that look at the end of the row, lengths of every residue mod 4
+    and mod 16, batches that end on and off a tile boundary, `.in.` with spans, flags only and `.match.`."""
+    rng = np.random.default_rng(17)
+    alpha = np.frombuffer(b"abz019 \n", dtype=np.uint8)
+    for L in (257, 258, 259, 260, 261, 271, 273, 300, 511, 513, 1001):
+        for n in (64, 128, 100, 65, 191):
+            rows = alpha[rng.integers(0, len(alpha), size=(n, L))]
+            rows[:, -1] = alpha[rng.integers(0, len(alpha), size=n)]
+            for pat in (rb"${2,}", rb"z$", rb"[0-9]$", rb"a\d$", rb"[a-z]+$"):
+                of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+                prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+                assert np.array_equal(f, of), (pat, L, n, np.flatnonzero(f != of)[:5])
+                assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L, n)
+                _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+                assert np.array_equal(f2, of), (pat, L, n, "flags only", np.flatnonzero(f2 != of)[:5])
+            for pat in (rb"[a-z0-9 ]+\n*[a-z0-9 \n]*z", rb".*[0-9]"):
+                om, _, _ = oracle_lib.batch(1, pat, rows, NT)
+                pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+                assert np.array_equal(fm, om), (pat, L, n, "match", np.flatnonzero(fm != om)[:5])
