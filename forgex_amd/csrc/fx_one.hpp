@@ -8,10 +8,9 @@
 //                                   or, without them (ragged rows, programs without byte-level automata), the in-LDS UTF-8
 //                                   decode (fxrow::translate_cell16) followed by the class-level scan
 //   * exception rows of the byte-level tables (structurally invalid UTF-8: the backward pass ends in the INVALID state) are kept
-//     in a per-wave queue in LDS (64 row indices); when a tile would overflow it, and once more at the end of the kernel after
-//     the block's four queues have been merged, the queued rows are GATHERED into a tile (lane r loads row queue[r] into its
-//     own cells), decoded in LDS and scanned with the class-level tables -- the decode pass of fx_search_fast's MODE 4, inside
-//     the same launch.
+//     in a per-wave queue in LDS (64 row indices); when a tile would overflow it, and once more when the wave has finished its
+//     tiles, the queued rows are GATHERED into a tile (lane r loads row queue[r] into its own cells), decoded in LDS and
+//     scanned with the class-level tables -- the decode pass of fx_search_fast's MODE 4, inside the same launch.
 // Programs whose class-level tables cannot decode UTF-8 (candidate-list driver: prefix literals outside the equivalence proof)
 // and rows longer than 256 bytes stay on fx_search_fast and its worklist fix-up.
 #pragma once
@@ -278,7 +277,6 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    __shared__ fx_nib bwideR[BSCH == 2 ? 256 : 1];
    __shared__ fx_nib bwideA[BSCH == 2 ? 256 : 1];
    __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
-   __shared__ uint32_t pool_cnt[4];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // ---- tables -> LDS ----
@@ -393,7 +391,6 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    uint32_t pool_n = 0;        // rows in this wave's queue (wave-uniform)
    uint64_t pend_mask = 0;     // lanes whose row of the last byte-level scan is an exception not yet queued (wave-uniform)
    uint32_t pend_row = 0;      // that row (per lane)
-   uint32_t phase = 0, pass = wave, total = 0, pre1 = 0, pre2 = 0, pre3 = 0;
    // marked-tile mode: does tile t hold a row the first pass left behind (FX_NEEDS_GENERAL)?  wave-uniform
    auto tile_marked = [&](const int64_t t) -> bool {
       const int64_t rr = (t << 6) + lane;
@@ -405,39 +402,21 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    else load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
    for (int64_t t = wave_global;;) {
       bool is_tile = false;
-      uint32_t take = 0, take_base = 0;
-      if (phase == 0) {
-         if (POOL && pend_mask != 0 && pool_n + (uint32_t)__builtin_popcountll(pend_mask) <= 64u) {
-            if ((pend_mask >> lane) & 1ull) myq[pool_n + (uint32_t)__builtin_popcountll(pend_mask & ((1ull << lane) - 1ull))] = pend_row;
-            pool_n += (uint32_t)__builtin_popcountll(pend_mask);
-            pend_mask = 0;
-         }
-         if (POOL && pend_mask != 0) {
-            take = pool_n;   // the queue has to be drained before the pending rows fit
-         } else if (t < n_tiles) {
-            is_tile = true;
-         } else {
-            if (!POOL) break;
-            // end of the wave's tiles: merge the block's four queues; each wave then takes every fourth gathered tile
-            if (lane == 0) pool_cnt[wave] = pool_n;
-            // packed results: the tiles' flag words must be in L2 before a gathered row ORs its bit into one.  All waves of a block
-            // share one CU (one L2): waiting for the stores' acknowledgements is enough -- a device-scope fence would write the
-            // whole L2 back, once per wave (measured: +50 us on a 1M-row batch)
-            if (out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            const uint32_t c0 = pool_cnt[0], c1 = pool_cnt[1], c2 = pool_cnt[2], c3 = pool_cnt[3];
-            pre1 = c0;
-            pre2 = c0 + c1;
-            pre3 = c0 + c1 + c2;
-            total = pre3 + c3;
-            phase = 1;
-            continue;
-         }
+      uint32_t take = 0;
+      if (POOL && pend_mask != 0 && pool_n + (uint32_t)__builtin_popcountll(pend_mask) <= 64u) {
+         if ((pend_mask >> lane) & 1ull) myq[pool_n + (uint32_t)__builtin_popcountll(pend_mask & ((1ull << lane) - 1ull))] = pend_row;
+         pool_n += (uint32_t)__builtin_popcountll(pend_mask);
+         pend_mask = 0;
+      }
+      if (POOL && pend_mask != 0) {
+         take = pool_n;   // the queue has to be drained before the pending rows fit
+      } else if (t < n_tiles) {
+         is_tile = true;
       } else {
-         if (pass * 64u >= total) break;
-         take_base = pass * 64u;
-         take = total - take_base < 64u ? total - take_base : 64u;
-         pass += 4u;
+         // end of the wave's tiles: what is left in its queue (no merging across the block's waves: waiting for the slowest wave
+         // behind a barrier cost more than the three partial passes it saved -- config 4: 126.8 -> 118.7 us)
+         if (!POOL || pool_n == 0u) break;
+         take = pool_n;
       }
       int64_t row;
       bool row_ok;
@@ -465,18 +444,12 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          if (!process) continue;
       } else {
          // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
-         if (phase == 0 && out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's own flag words first, see above)
+         // packed results: the flag words of this wave's own tiles must be in L2 before a gathered row ORs its bit into one (a wave's
+         // queue only ever holds rows of its own tiles): waiting for the stores' acknowledgements is enough -- a device-scope fence
+         // would write the whole L2 back (measured: +50 us on a 1M-row batch when every wave did that once)
+         if (out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
          row_ok = lane < take;
-         uint32_t ridx = 0;
-         if (POOL && row_ok) {
-            if (phase == 0) ridx = myq[lane];
-            else {
-               const uint32_t g = take_base + lane;
-               const uint32_t w = g >= pre3 ? 3u : (g >= pre2 ? 2u : (g >= pre1 ? 1u : 0u));
-               const uint32_t pb = w == 3u ? pre3 : (w == 2u ? pre2 : (w == 1u ? pre1 : 0u));
-               ridx = pool_q[w * 64u + (g - pb)];
-            }
-         }
+         const uint32_t ridx = (POOL && row_ok) ? myq[lane] : 0u;
          row = (int64_t)ridx;
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
          // (four loads in flight: the staging registers hold the next tile's loads and stay untouched)
@@ -490,7 +463,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             for (int i = 0; i < 4; ++i)
                if (k0 + i < CH) tile[tile_cell(lane, k0 + i)] = g4[i];
          }
-         if (phase == 0) pool_n = 0;
+         pool_n = 0;
       }
       bool except = false;
       bool redo = false;
