@@ -452,15 +452,18 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          const uint32_t ridx = (POOL && row_ok) ? myq[lane] : 0u;
          row = (int64_t)ridx;
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
-         // (four loads in flight: the staging registers hold the next tile's loads and stay untouched)
+         // (up to twelve loads in flight -- the whole row when it has that many chunks, two rounds of eight at 256 bytes: each round
+         //  is a trip to L2 / HBM that the end of the kernel waits for; the staging registers hold the next tile's loads and stay
+         //  untouched)
          // (ragged rows -- GEN only -- start at any byte: the general procedure reads them from global memory instead)
+         constexpr int GD = CH <= 12 ? CH : 8;
 #pragma unroll 1
-         for (int k0 = 0; k0 < (RAGGED ? 0 : CH); k0 += 4) {
-            uint4 g4[4];
+         for (int k0 = 0; k0 < (RAGGED ? 0 : CH); k0 += GD) {
+            uint4 g4[GD];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g4[i] = (row_ok && k0 + i < CH) ? src[k0 + i < CH ? k0 + i : 0] : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < GD; ++i) g4[i] = (row_ok && k0 + i < CH) ? src[k0 + i < CH ? k0 + i : 0] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < GD; ++i)
                if (k0 + i < CH) tile[tile_cell(lane, k0 + i)] = g4[i];
          }
          pool_n = 0;
