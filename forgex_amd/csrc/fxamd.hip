@@ -840,19 +840,6 @@ static void destroy_program(fxamd_program* p) {
    delete p;
 }
 
-static void free_slot(HostSlot& s) {
-   if (s.stream) (void)hipStreamDestroy(s.stream);
-   if (s.done) (void)hipEventDestroy(s.done);
-   if (s.d_rows) (void)hipFree(s.d_rows);
-   if (s.d_flags) (void)hipFree(s.d_flags);
-   if (s.d_from) (void)hipFree(s.d_from);
-   if (s.d_to) (void)hipFree(s.d_to);
-   if (s.h_flags) (void)hipHostFree(s.h_flags);
-   if (s.h_from) (void)hipHostFree(s.h_from);
-   if (s.h_to) (void)hipHostFree(s.h_to);
-   s = HostSlot();
-}
-
 extern "C" {
 
 int fxamd_last_hip_error(void) { return g_last_hip_error; }
