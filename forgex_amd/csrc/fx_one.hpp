@@ -3,16 +3,17 @@
 // fx_search_fast needs up to three launches per call when rows may hold bytes >= 0x80 (first pass that DEFERS such tiles, a second
 // pass over them, a third over the exception rows), reads deferred tiles twice and pays for the empty gate launches on pure-ASCII
 // batches.  Here every tile is finished by the wave that staged it, with the scheme its bytes ask for:
-//   * pure-ASCII tile            -> class-level tables (v_perm / wide v_perm / chain), exactly the first pass of fx_search_fast
-//   * tile with a byte >= 0x80   -> byte-level tables (FXP_F_BYTE_DFA; chain or wide format) on the RAW bytes of the same LDS tile,
+//   * pure-ASCII tile            -> class-level tables (v_perm / nibble / chain), exactly the first pass of fx_search_fast
+//   * tile with a byte >= 0x80   -> byte-level tables (FXP_F_BYTE_DFA; chain or nibble format) on the RAW bytes of the same LDS tile,
 //                                   or, without them (ragged rows, programs without byte-level automata), the in-LDS UTF-8
 //                                   decode (fxrow::translate_cell16) followed by the class-level scan
 //   * exception rows of the byte-level tables (structurally invalid UTF-8: the backward pass ends in the INVALID state) are kept
 //     in a per-wave queue in LDS (64 row indices); when a tile would overflow it, and once more when the wave has finished its
 //     tiles, the queued rows are GATHERED into a tile (lane r loads row queue[r] into its own cells), decoded in LDS and
 //     scanned with the class-level tables -- the decode pass of fx_search_fast's MODE 4, inside the same launch.
-// Programs whose class-level tables cannot decode UTF-8 (candidate-list driver: prefix literals outside the equivalence proof)
-// and rows longer than 256 bytes stay on fx_search_fast and its worklist fix-up.
+// Programs whose class-level tables cannot decode UTF-8 (candidate-list driver programs) queue the rows their tables cannot answer
+// the same way and walk them with the general row procedure (GEN).  Rows longer than 256 bytes and `.match.` stay on
+// fx_search_fast / fx_match_fast and their multi-pass pipeline.
 #pragma once
 #include "fx_tile.hpp"
 
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          // On-device UTF-8 decode, in place in LDS, into fast-path symbol ids (fxrow::translate_cell16); the 4 bytes before / after
          // a cell are taken from the ORIGINAL neighbours.
          if (HAS_B && !is_tile) {
-            // gathered tile: usually a handful of rows (one merged pass per block), and a single wave's serial decode of a row is
+            // gathered tile: usually a handful of rows (what a wave's queue holds at the end), and a single lane's serial decode of a row is
             // what the end of the kernel waits for -- so FOUR lanes share a row (a quarter of its cells each), sixteen rows per round.
             // All reads of a round are issued before its writes (one wave: its LDS operations complete in order).
             constexpr int CQ = (CH + 3) / 4;
@@ -558,7 +559,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
    const bool spans = from && to;   // (packed results: `from` / `to` are the narrow arrays)
-   // Grid: with exception queues every block ends with one merged pass over its queued rows, so the grid is sized to what is
+   // Grid: with exception queues every wave ends with one pass over its queued rows, so the grid is sized to what is
    // RESIDENT (one tail per CU slot, not one per 1/8 of it); without them the usual cap with grid-stride beyond it.
    {
       static const int env_mult = std::getenv("FXAMD_ONE_GRID") ? std::atoi(std::getenv("FXAMD_ONE_GRID")) : 0;
