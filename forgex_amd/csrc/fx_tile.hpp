@@ -95,7 +95,9 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __r
    // dword on UNALIGNED dwords (rows start at any byte) -- the dword that holds the row's last bytes is dropped whole when it
    // straddles the extent (a 257-byte row's byte 256 came back as 0: a NUL to the automaton).  Those up to three bytes are
    // re-read one by one; nothing behind the tile's own bytes is touched.
-   if (short_seg && enable) {
+   // (CH = 8 is the half-row staging of 256-byte rows: whole segments only -- the code is left out of that kernel, where its mere
+   //  presence cost 2-3 %)
+   if (CH == 16 && short_seg && enable) {
       const uint32_t tile_bytes = rows_left >= 64 ? 64u * Lr : (uint32_t)rows_left * Lr;
       const uint32_t last_row = (rows_left >= 64 ? 64u : (uint32_t)rows_left) - 1u;
       const uint32_t q_last = last_row / (64u / CH);
