@@ -1170,11 +1170,21 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       if (!progs[i]) return FXAMD_E_ARG;
    if (n == 0 || m == 0) return FXAMD_OK;
    hipStream_t st = (hipStream_t)hip_stream;
+   // the same handle more than once (identical patterns share one cached program): computed once, its results copied to the other slots
+   std::vector<int32_t> first_of((size_t)m);
+   for (int32_t i = 0; i < m; ++i) {
+      first_of[(size_t)i] = i;
+      for (int32_t j = 0; j < i; ++j)
+         if (progs[j] == progs[i]) {
+            first_of[(size_t)i] = j;
+            break;
+         }
+   }
    std::vector<int32_t> fused;
    if (!long_row(row_len) && !std::getenv("FXAMD_NO_MULTI"))
       for (int32_t i = 0; i < m; ++i) {
          const FxpHeader& h = progs[i]->prog.hdr();
-         if (progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&
+         if (first_of[(size_t)i] == i && progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&
              fast_scheme(h, d_rows, row_len) == 0)
             fused.push_back(i);
       }
@@ -1243,6 +1253,15 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
    }
    for (int32_t i = 0; i < m; ++i) {
       if (done[(size_t)i]) continue;
+      const int64_t src = first_of[(size_t)i];
+      if (src != i) {
+         FX_HIP(hipMemcpyAsync(d_flags + (int64_t)i * n, d_flags + src * n, (size_t)n, hipMemcpyDeviceToDevice, st));
+         if (d_from && progs[i]->prog.hdr().mode != FXP_MODE_MATCH_ENGINE) {   // (`.match.` leaves from/to untouched)
+            FX_HIP(hipMemcpyAsync(d_from + (int64_t)i * n, d_from + src * n, (size_t)n * 4u, hipMemcpyDeviceToDevice, st));
+            FX_HIP(hipMemcpyAsync(d_to + (int64_t)i * n, d_to + src * n, (size_t)n * 4u, hipMemcpyDeviceToDevice, st));
+         }
+         continue;
+      }
       const int rc = fxamd_match_batch_device(progs[i], d_rows, n, row_len, d_flags + (int64_t)i * n, d_from ? d_from + (int64_t)i * n : nullptr,
                                               d_to ? d_to + (int64_t)i * n : nullptr, hip_stream);
       if (rc != FXAMD_OK) return rc;

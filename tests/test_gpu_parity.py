@@ -566,6 +566,55 @@ def test_many_patterns_over_one_batch(fx, shape):
         assert np.array_equal(f2[i].cpu().numpy(), of), (shape, p, "flags only")
 
 
+def test_many_patterns_fuzz_groups(fx):
+    """fx_search_multi under random pattern GROUPS: 2..10 generated patterns (whatever path each one qualifies for: shared first pass,
+    own one-launch kernel, general kernel) against the same rows -- ASCII, mixed with valid and broken UTF-8, whole-chunk and ragged
+    row lengths, long rows (no shared pass) -- flags and spans of every pattern vs the oracle, and flags-only calls."""
+    import random
+    import torch
+    import fuzz_diff
+    seed = int(os.environ.get("FX_FUZZ_SEED", "0"))
+    groups = int(os.environ.get("FX_FUZZ_GROUPS", "24"))
+    rng = random.Random(4242 + 1000 * seed)
+    nrng = np.random.default_rng(4242 + seed)
+    ascii_alpha = np.frombuffer(b"abcxyz019 .-\n\tAZ_@", dtype=np.uint8)
+    pieces = [b"a", b"b", b"c", b"x", b"0", b"9", b" ", b".", "あ".encode(), "ん".encode(), "α".encode(), "ω".encode(), "é".encode(),
+              b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
+    dev = torch.device("cuda")
+    shared = 0
+    for _ in range(groups):
+        pats = []
+        while len(pats) < rng.randint(2, 10):
+            pat = fuzz_diff.gen_pattern(rng).encode()
+            if fx.Program(pat, fx.OP_SEARCH).status == 0:
+                pats.append(pat)
+        if rng.random() < 0.3:
+            pats.append(pats[0])   # the same pattern twice: the compile cache hands out ONE handle for both
+        L = rng.choice([16, 32, 64, 96, 128, 192, 256, 20, 52, 100, 200, 252, 17, 75, 255, 5, 11, 300])
+        n = rng.choice([64, 200, 1000])
+        rows_a = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))]
+        mixed = []
+        for _ in range(n // 2):
+            buf = b""
+            while len(buf) < L:
+                buf += rng.choice(pieces)
+            mixed.append(np.frombuffer(buf[:L], dtype=np.uint8))
+        host = np.ascontiguousarray(np.concatenate([rows_a[:n // 2], np.stack(mixed)]))
+        rows = torch.from_numpy(host).to(dev)
+        progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+        f, a, b = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        shared += sum(1 for p in progs if p.last_path() == 15)
+        f2, _, _ = fx.match_many(progs, rows, spans=False)
+        torch.cuda.synchronize()
+        for i, p in enumerate(pats):
+            of, oa, ob = oracle_lib.batch(2, p, host, NT)
+            assert np.array_equal(f[i].cpu().numpy(), of), (pats, i, L, n, progs[i].last_path())
+            assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), (pats, i, L, n, progs[i].last_path())
+            assert np.array_equal(f2[i].cpu().numpy(), of), (pats, i, L, n, "flags only")
+    assert shared >= groups   # the shared pass did run (most generated patterns fit the 8-state tables)
+
+
 def test_batch_shapes_and_handle_reuse(fx):
     """ONE program handle across calls of different batch sizes, row lengths and output sets (the per-handle counter words
     alternate between calls, the worklist grows on demand): tile boundaries (n = 1, 63, 64, 65, ...), ASCII and UTF-8 rows mixed."""
