@@ -547,6 +547,32 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
 }
 
 // FastParams of the class-level tables (fp) and of the byte-level tables (fpb) are prepared by the host (fxamd.hip)
+// Blocks of `fn` (256 threads, `lds` bytes of dynamic LDS) that one CU holds at a time, as the runtime computes it from the code object
+// (registers AND LDS -- config 2's kernel fits five blocks by LDS but four by VGPRs: a grid of 5 x 256 would run a second, quarter-full
+// round).  One query per (kernel, LDS size) and device; `fallback` when the query fails.
+inline int resident_blocks_per_cu(const void* fn, size_t lds, int fallback) {
+   struct Key {
+      const void* fn;
+      size_t lds;
+      int dev;
+      int blocks;
+   };
+   static std::mutex mu;
+   static std::vector<Key> seen;
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) return fallback;
+   std::lock_guard<std::mutex> g(mu);
+   for (const Key& k : seen)
+      if (k.fn == fn && k.lds == lds && k.dev == dev) return k.blocks;
+   int nb = 0;
+   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = fallback;
+   }
+   seen.push_back(Key{fn, lds, dev, nb});
+   return nb;
+}
+
 template <int CH, int SCH, int BSCH, bool GEN>
 hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
                       uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st, uint32_t out_mode) {
@@ -561,15 +587,20 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    const bool spans = from && to;   // (packed results: `from` / `to` are the narrow arrays)
    // Grid: with exception queues every wave ends with one pass over its queued rows, so the grid is sized to what is
    // RESIDENT (one tail per CU slot, not one per 1/8 of it); without them the usual cap with grid-stride beyond it.
-   {
+   auto cap_grid = [&](const void* fn) {
       static const int env_mult = std::getenv("FXAMD_ONE_GRID") ? std::atoi(std::getenv("FXAMD_ONE_GRID")) : 0;
       const size_t per_block = lds + static_b;
-      int64_t resident = per_block > 0 ? (int64_t)((160 * 1024) / per_block) : 8;   // blocks per CU by LDS (the binding resource of these kernels)
-      if (resident < 1) resident = 1;
-      if (resident > 8) resident = 8;
-      const int64_t cap = 256 * (env_mult > 0 ? env_mult : ((BSCH != 0 || GEN) ? resident : 8));
+      int64_t by_lds = per_block > 0 ? (int64_t)((160 * 1024) / per_block) : 8;   // blocks per CU by LDS alone (used when the runtime cannot say)
+      if (by_lds < 1) by_lds = 1;
+      if (by_lds > 8) by_lds = 8;
+      int64_t resident = 8;
+      if (env_mult <= 0 && (BSCH != 0 || GEN)) {
+         resident = resident_blocks_per_cu(fn, lds, (int)by_lds);
+         if (resident > 8) resident = 8;
+      }
+      const int64_t cap = 256 * (env_mult > 0 ? env_mult : resident);
       if (blocks > cap) blocks = cap;
-   }
+   };
    if (ragged) {
       if constexpr (BSCH == 0) {
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true, GEN>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN>);
@@ -577,6 +608,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
+         cap_grid(fn);
          if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
          else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
          return hipGetLastError();
@@ -589,6 +621,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
+   cap_grid(fn);
    if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
    else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
    return hipGetLastError();
