@@ -110,7 +110,8 @@ int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, in
 /* m patterns against the same device-resident rows (the reference's elemental operators accept an ARRAY of patterns,
  * src/forgex.F90:74, :163): progs[i] fills d_flags[i*n .. i*n+n) (and d_from / d_to likewise).  Patterns whose automata fit the
  * 8-state tile tables share ONE pass over rows of up to 256 bytes (up to 8 patterns per launch, their tables side by side in LDS:
- * the rows are read from HBM once); every other pattern runs its own pipeline, enqueued on the same stream. */
+ * the rows are read from HBM once); every other pattern runs its own pipeline, enqueued on the same stream.  A handle may appear more
+ * than once (identical patterns share one cached program): it is computed once and its results are copied to its other slots. */
 int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8_t* d_rows, int64_t n, int64_t row_len,
                              uint8_t* d_flags, int32_t* d_from, int32_t* d_to, void* hip_stream);
 
