@@ -1058,12 +1058,33 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    return FXAMD_OK;
 }
 
+// Rows per enqueue: worklists, exception queues and gate counters hold 32-bit row numbers, so a batch of more rows than this (288 GB
+// of HBM hold 2^34 sixteen-byte rows) is enqueued slice by slice on the same stream.  A multiple of 64: slices are whole tiles and whole
+// words of the packed flags.  (FXAMD_SLICE_ROWS: test hook.)
+static int64_t slice_rows() {
+   static const int64_t v = [] {
+      const char* e = std::getenv("FXAMD_SLICE_ROWS");
+      int64_t r = e ? std::atoll(e) & ~int64_t(63) : int64_t(1) << 30;
+      return r < 64 ? int64_t(64) : r;
+   }();
+   return v;
+}
+
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
                              int32_t* d_to, void* hip_stream) {
    if (!p || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || !d_flags || (n > 0 && row_len > 0 && !d_rows)) return FXAMD_E_ARG;
    if ((d_from == nullptr) != (d_to == nullptr)) return FXAMD_E_ARG;
    if (p->prog.status >= 100) return FXAMD_E_UNSUPPORTED;
    if (n == 0) return FXAMD_OK;
+   if (n > slice_rows()) {
+      for (int64_t o = 0; o < n; o += slice_rows()) {
+         const int64_t m = std::min(slice_rows(), n - o);
+         const int rc = fxamd_match_batch_device(p, d_rows ? d_rows + o * row_len : nullptr, m, row_len, d_flags + o, d_from ? d_from + o : nullptr,
+                                                 d_to ? d_to + o : nullptr, hip_stream);
+         if (rc != FXAMD_OK) return rc;
+      }
+      return FXAMD_OK;
+   }
    hipStream_t st = (hipStream_t)hip_stream;
    const FxpHeader& h = p->prog.hdr();
    std::lock_guard<std::mutex> g(p->mu);
@@ -1096,6 +1117,10 @@ int fxamd_packed_layout(int64_t n, int64_t row_len, int with_spans, int64_t* off
    return FXAMD_OK;
 }
 
+// one slice of a packed call: `d_words` = the slice's flag words, pf / pt = its narrow span arrays (w bytes per row, 0 = none)
+static int packed_slice(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, int32_t w, uint8_t* d_words, uint8_t* pf, uint8_t* pt,
+                        hipStream_t st);
+
 int fxamd_match_batch_device_packed(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, int with_spans, uint8_t* d_packed,
                                     void* hip_stream) {
    if (!p || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || !d_packed || (n > 0 && row_len > 0 && !d_rows)) return FXAMD_E_ARG;
@@ -1108,12 +1133,24 @@ int fxamd_match_batch_device_packed(fxamd_program* p, const uint8_t* d_rows, int
    int64_t off_f = 0, off_t = 0, total = 0;
    int32_t w = 0;
    (void)fxamd_packed_layout(n, row_len, with_spans, &off_f, &off_t, &total, &w);
-   std::lock_guard<std::mutex> g(p->mu);
    if (h.mode == FXP_MODE_INVALID) {   // every row: no match, spans 0
+      std::lock_guard<std::mutex> g(p->mu);
       FX_HIP(hipMemsetAsync(d_packed, 0, (size_t)total, st));
       p->last_path = 0;
       return FXAMD_OK;
    }
+   for (int64_t o = 0; o < n; o += slice_rows()) {
+      const int64_t m = std::min(slice_rows(), n - o);
+      const int rc = packed_slice(p, d_rows ? d_rows + o * row_len : nullptr, m, row_len, w, d_packed + o / 8, d_packed + off_f + o * w, d_packed + off_t + o * w, st);
+      if (rc != FXAMD_OK) return rc;
+   }
+   return FXAMD_OK;
+}
+
+static int packed_slice(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, int32_t w, uint8_t* d_packed, uint8_t* pf, uint8_t* pt,
+                        hipStream_t st) {
+   const FxpHeader& h = p->prog.hdr();
+   std::lock_guard<std::mutex> g(p->mu);
    int dev = -1;
    FX_HIP(hipGetDevice(&dev));
    uint8_t* d_blob = nullptr;
@@ -1122,8 +1159,6 @@ int fxamd_match_batch_device_packed(fxamd_program* p, const uint8_t* d_rows, int
    DevScratch* sc = nullptr;
    rc = scratch_for(p, dev, st, &sc);
    if (rc != FXAMD_OK) return rc;
-   uint8_t* pf = d_packed + off_f;
-   uint8_t* pt = d_packed + off_t;
    // in-kernel packing: the tile's ballot is the flag word, spans are stored narrow
    rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_packed, w ? reinterpret_cast<int32_t*>(pf) : nullptr, w ? reinterpret_cast<int32_t*>(pt) : nullptr, st,
                       w ? (uint32_t)w : 1u);
@@ -1181,7 +1216,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          }
    }
    std::vector<int32_t> fused;
-   if (!long_row(row_len) && !std::getenv("FXAMD_NO_MULTI"))
+   if (!long_row(row_len) && !std::getenv("FXAMD_NO_MULTI") && n <= slice_rows())   // (more rows than one enqueue takes: pattern by pattern, each sliced)
       for (int32_t i = 0; i < m; ++i) {
          const FxpHeader& h = progs[i]->prog.hdr();
          if (first_of[(size_t)i] == i && progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&

@@ -89,7 +89,8 @@ int fxamd_program_reserve(fxamd_program* p, int64_t max_rows, void* hip_stream);
  * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2 bytes .. 64 KiB when
  * d_rows is 16-byte aligned, other shapes run on the general kernel (one lane per row, roughly 20x slower).  The handle keeps its
  * uploaded tables per device and its scratch per (device, stream): the call works on whatever device is current, and calls on
- * one handle may overlap on the device when they use different streams. */
+ * one handle may overlap on the device when they use different streams.  n is not limited by the 32-bit row numbers of the kernels'
+ * work lists: a batch of more than 2^30 rows is enqueued in slices of that many rows on the same stream. */
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                              int32_t* d_from, int32_t* d_to, void* hip_stream);
 

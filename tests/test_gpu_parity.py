@@ -960,6 +960,54 @@ def test_one_handle_alternating_between_pipelines(fx):
     assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2)
 
 
+_SLICE_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import forgex_amd as fx
+from forgex_amd import synth
+import oracle_lib
+dev = torch.device("cuda")
+checked = 0
+for cfg, n, pat, op in (("cfg3", 10000, rb"[a-z]+\d+", fx.OP_SEARCH), ("cfg4", 9000, synth.PATTERNS["cfg4"].encode(), fx.OP_SEARCH),
+                        ("cfg2", 12345, rb"foo(bar|baz)", fx.OP_SEARCH), ("cfg5", 7001, rb"[a-z]+", fx.OP_MATCH)):
+    rows = synth.batch(cfg, 0, n, dev)
+    rows[::11, 5] = 0xFF
+    host = rows.cpu().numpy()
+    prog = fx.Program(pat, op)
+    of, oa, ob = oracle_lib.batch(2 if op == fx.OP_SEARCH else 1, pat, host, 8)
+    f, a, b = prog.match_device(rows, spans=(op == fx.OP_SEARCH))
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy(), of), (cfg, "flags")
+    if op == fx.OP_SEARCH:
+        assert np.array_equal(a.cpu().numpy(), oa) and np.array_equal(b.cpu().numpy(), ob), (cfg, "spans")
+        img = prog.match_device_packed(rows, spans=True)
+        uf, ua, ub = fx.unpack_results(img, n, rows.shape[1], True)
+        torch.cuda.synchronize()
+        assert np.array_equal(uf.cpu().numpy(), of) and np.array_equal(ua.cpu().numpy(), oa) and np.array_equal(ub.cpu().numpy(), ob), (cfg, "packed")
+        progs = [prog, fx.Program(rb"[0-9]$", fx.OP_SEARCH), fx.Program(rb"zz+", fx.OP_SEARCH)]
+        mf, ma, mb = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        assert np.array_equal(mf[0].cpu().numpy(), of) and np.array_equal(ma[0].cpu().numpy(), oa) and np.array_equal(mb[0].cpu().numpy(), ob), (cfg, "many")
+        o2, _, _ = oracle_lib.batch(2, rb"[0-9]$", host, 8)
+        assert np.array_equal(mf[1].cpu().numpy(), o2), (cfg, "many, second pattern")
+    checked += 1
+print("SLICES OK", checked)
+"""
+
+
+def test_batches_larger_than_one_enqueue_are_sliced(fx):
+    """Worklists and exception queues hold 32-bit row numbers, so the entries enqueue a batch of more rows than FXAMD_SLICE_ROWS (2^30
+    by default) slice by slice.  With the slice set to 4096 rows (a fresh process: the value is read once), plain, packed and
+    many-pattern results of every config shape -- broken UTF-8 included, so worklists and queues are in use in every slice -- equal the oracle's."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FXAMD_SLICE_ROWS="4096")
+    r = subprocess.run([sys.executable, "-c", _SLICE_WORKER, os.path.dirname(here), os.path.join(here, "support")], capture_output=True, timeout=600, env=env)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert r.returncode == 0 and "SLICES OK 4" in out, out[-3000:]
+
+
 def test_long_rows_last_bytes_of_a_tile(fx):
     """Rows longer than 256 bytes start at any byte; the final piece of the LAST row of a 64-row tile may reach past the tile, and the
     buffer range check drops an unaligned dword that straddles the extent -- the row's last bytes have to be re-read (a 257-byte
