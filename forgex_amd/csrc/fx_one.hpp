@@ -511,7 +511,20 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             // All reads of a round are issued before its writes (one wave: its LDS operations complete in order).
             constexpr int CQ = (CH + 3) / 4;
             const uint32_t q = lane & 3u;
-            for (uint32_t r0 = 0; r0 < take; r0 += 16u) {
+            // (a few rows only -- the usual end of a wave: ONE cell per lane, 64 / CH whole rows per round, when that takes fewer rounds
+            //  than a lane of the four has cells)
+            constexpr uint32_t RPR = 64u / (uint32_t)CH;   // rows per round
+            const bool one_cell = (take + RPR - 1u) / RPR < (uint32_t)CQ;
+            for (uint32_t r0 = 0; r0 < (one_cell ? take : 0u); r0 += RPR) {
+               const uint32_t r = r0 + lane / (uint32_t)CH, k = lane % (uint32_t)CH;
+               const bool on = lane < RPR * (uint32_t)CH && r < take;
+               const uint32_t prev = (on && k >= 1u) ? tile[tile_cell(r, k - 1u)].w : 0u;
+               const uint4 cur = on ? tile[tile_cell(r, k)] : make_uint4(0, 0, 0, 0);
+               const uint32_t nxt = (on && k + 1u < (uint32_t)CH) ? tile[tile_cell(r, k + 1u)].x : 0u;
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt, ct, sym_ffff);
+               if (on) tile[tile_cell(r, k)] = make_uint4(o.x, o.y, o.z, o.w);
+            }
+            for (uint32_t r0 = 0; r0 < (one_cell ? 0u : take); r0 += 16u) {
                const uint32_t r = r0 + (lane >> 2);
                uint4 outc[CQ];
                uint32_t k = q * CQ;
