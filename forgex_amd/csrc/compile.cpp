@@ -7,6 +7,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <unordered_map>
 
 using namespace fxfe;
 
@@ -39,6 +40,14 @@ struct Dfa {
    bool ok = true;
 };
 
+struct IntVecHash {
+   size_t operator()(const std::vector<int>& v) const {
+      uint64_t h = 1469598103934665603ull;
+      for (int x : v) h = (h ^ static_cast<uint32_t>(x)) * 1099511628211ull;
+      return static_cast<size_t>(h ^ (h >> 29));
+   }
+};
+
 // Moore partition refinement; keeps `keep0` (the dead state of A) as state 0 when >= 0.
 // `labels` (optional) refines the initial partition beyond `out`; `old2new` (optional) receives the state renumbering (-1 = dropped).
 void minimise(Dfa& d, int keep0, const std::vector<int>* labels = nullptr, std::vector<int>* old2new = nullptr) {
@@ -55,18 +64,63 @@ void minimise(Dfa& d, int keep0, const std::vector<int>* labels = nullptr, std::
       }
       nblocks = static_cast<int>(m.size());
    }
-   while (true) {
-      std::map<std::vector<int>, int> m;
-      std::vector<int> nb(static_cast<size_t>(n));
-      std::vector<int> sig(static_cast<size_t>(nc) + 1);
-      for (int s = 0; s < n; ++s) {
-         sig[0] = block[static_cast<size_t>(s)];
-         for (int c = 0; c < nc; ++c) sig[static_cast<size_t>(c) + 1] = block[static_cast<size_t>(d.T[static_cast<size_t>(s) * nc + c])];
-         auto it = m.find(sig);
-         if (it == m.end()) it = m.emplace(sig, static_cast<int>(m.size())).first;
-         nb[static_cast<size_t>(s)] = it->second;
+   // every round: states with the same (block, blocks of the successors) signature share a new block, numbered in order of first
+   // appearance.  The signatures live in one flat array; a hash finds the earlier states to compare with (exact comparison decides).
+   // columns that are equal in every state say the same thing in every signature: one representative each takes part
+   std::vector<int> cols;
+   {
+      std::unordered_multimap<uint64_t, int> col_by_hash;
+      for (int c = 0; c < nc; ++c) {
+         uint64_t hsh = 1469598103934665603ull;
+         for (int s = 0; s < n; ++s) hsh = (hsh ^ static_cast<uint32_t>(d.T[static_cast<size_t>(s) * nc + c])) * 1099511628211ull;
+         bool dup = false;
+         auto range = col_by_hash.equal_range(hsh);
+         for (auto it = range.first; it != range.second && !dup; ++it) {
+            const int c2 = it->second;
+            bool eq = true;
+            for (int s = 0; s < n && eq; ++s) eq = d.T[static_cast<size_t>(s) * nc + c] == d.T[static_cast<size_t>(s) * nc + c2];
+            dup = eq;
+         }
+         if (!dup) {
+            col_by_hash.emplace(hsh, c);
+            cols.push_back(c);
+         }
       }
-      int k = static_cast<int>(m.size());
+   }
+   const size_t w = cols.size() + 1;
+   std::vector<int> sigs(static_cast<size_t>(n) * w);
+   std::vector<int> nb(static_cast<size_t>(n));
+   std::vector<int> first_of;   // new block -> the first state that has its signature
+   std::unordered_multimap<uint64_t, int> by_hash;   // signature hash -> new block
+   while (true) {
+      first_of.clear();
+      by_hash.clear();
+      by_hash.reserve(static_cast<size_t>(n) * 2);
+      for (int s = 0; s < n; ++s) {
+         int* sig = &sigs[static_cast<size_t>(s) * w];
+         sig[0] = block[static_cast<size_t>(s)];
+         uint64_t hsh = (1469598103934665603ull ^ static_cast<uint32_t>(sig[0])) * 1099511628211ull;
+         const int* row = &d.T[static_cast<size_t>(s) * nc];
+         for (size_t ci = 0; ci < cols.size(); ++ci) {
+            const int b = block[static_cast<size_t>(row[cols[ci]])];
+            sig[ci + 1] = b;
+            hsh = (hsh ^ static_cast<uint32_t>(b)) * 1099511628211ull;
+         }
+         int id = -1;
+         auto range = by_hash.equal_range(hsh);
+         for (auto it = range.first; it != range.second; ++it)
+            if (std::memcmp(&sigs[static_cast<size_t>(first_of[static_cast<size_t>(it->second)]) * w], sig, w * sizeof(int)) == 0) {
+               id = it->second;
+               break;
+            }
+         if (id < 0) {
+            id = static_cast<int>(first_of.size());
+            first_of.push_back(s);
+            by_hash.emplace(hsh, id);
+         }
+         nb[static_cast<size_t>(s)] = id;
+      }
+      int k = static_cast<int>(first_of.size());
       block.swap(nb);
       if (k == nblocks) break;
       nblocks = k;
@@ -226,34 +280,65 @@ ByteDfa build_forward_bytes(const ClassDfaView& A, const Sig& full, const std::v
    // arithmetically too, but they are as good as absent from real text and cost states; like structure errors they lead to
    // INVALID and the decode pass answers the row exactly.
    const Sig canon[3] = {sig_restrict(full, 0x80u, 0x800u), sig_restrict(full, 0x800u, 0x10000u), sig_restrict(full, 0x10000u, 0x110000u)};
+   // What a byte >= 0x80 does to the decoder part of a state depends on the node alone, not on q: worked out once per node, when the
+   // first state that carries it is expanded (bytes in ascending order, as the states' own loops run: nodes are numbered in the same
+   // order as if every state did the work itself).  kind 0: INVALID; 1: on to node `val`; 2: the character is complete, class `val`.
+   struct NodeStep {
+      int kind, val;
+   };
+   std::vector<std::array<NodeStep, 128>> node_steps;   // [node][b - 0x80]
+   std::vector<uint8_t> node_done;
+   auto steps_of = [&](int nd) {
+      if (static_cast<size_t>(nd) >= node_done.size()) {
+         node_done.resize(static_cast<size_t>(nd) + 1, 0);
+         node_steps.resize(static_cast<size_t>(nd) + 1);
+      }
+      if (node_done[static_cast<size_t>(nd)]) return;
+      std::array<NodeStep, 128> row;
+      for (int b = 0x80; b < 256; ++b) {
+         NodeStep st{0, 0};
+         if (nd == 0) {
+            if (b >= 0xC0 && b < 0xF8) {
+               const int rem = b < 0xE0 ? 1 : (b < 0xF0 ? 2 : 3);
+               const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
+               const uint32_t span = 1u << (6 * rem);
+               Sig sub = sig_slice(canon[rem - 1], pay * span, (pay + 1) * span);
+               if (!sig_all_invalid(sub)) st = NodeStep{1, intern(rem, std::move(sub))};   // (C0, C1, F5..F7: nothing canonical starts here)
+            }
+         } else if (b < 0xC0) {
+            const int rem = nodes[static_cast<size_t>(nd)].first;
+            const uint32_t v = static_cast<uint32_t>(b) & 0x3Fu, span = 1u << (6 * (rem - 1));
+            Sig sub = sig_slice(nodes[static_cast<size_t>(nd)].second, v * span, (v + 1) * span);
+            if (!sig_all_invalid(sub)) {   // (else: overlong form / beyond U+10FFFF)
+               if (rem == 1) st = NodeStep{2, sub[0].second};
+               else st = NodeStep{1, intern(rem - 1, std::move(sub))};
+            }
+         }
+         row[static_cast<size_t>(b - 0x80)] = st;
+      }
+      if (static_cast<size_t>(nd) >= node_done.size()) {   // (intern may have added nodes; the arrays are indexed by node)
+         node_done.resize(static_cast<size_t>(nd) + 1, 0);
+         node_steps.resize(static_cast<size_t>(nd) + 1);
+      }
+      node_steps[static_cast<size_t>(nd)] = row;
+      node_done[static_cast<size_t>(nd)] = 1;
+   };
+   int ascii_cls[128];
+   for (int b = 0; b < 128; ++b) ascii_cls[b] = sig_eval(full, static_cast<uint32_t>(b));
    std::vector<int> T;
    for (size_t s = 0; s < keys.size(); ++s) {
       if (static_cast<int>(keys.size()) > kMaxByteStates) return r;
       const int q = keys[s].first, nd = keys[s].second;
       T.resize((s + 1) * 256);
+      if (q > 0) steps_of(nd);
       for (int b = 0; b < 256; ++b) {
          int dst;
          if (q == 0) dst = 0;
          else if (q < 0) dst = static_cast<int>(s);
-         else if (nd == 0) {
-            if (b < 0x80) dst = state_of(A.T(q, sig_eval(full, static_cast<uint32_t>(b))), 0);
-            else if (b < 0xC0 || b >= 0xF8) dst = inv;
-            else {
-               const int rem = b < 0xE0 ? 1 : (b < 0xF0 ? 2 : 3);
-               const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
-               const uint32_t span = 1u << (6 * rem);
-               Sig sub = sig_slice(canon[rem - 1], pay * span, (pay + 1) * span);
-               dst = sig_all_invalid(sub) ? inv : state_of(q, intern(rem, std::move(sub)));   // C0, C1, F5..F7: nothing canonical starts here
-            }
-         } else {
-            const int rem = nodes[static_cast<size_t>(nd)].first;
-            if (b < 0x80 || b >= 0xC0) dst = inv;
-            else {
-               const uint32_t v = static_cast<uint32_t>(b) & 0x3Fu, span = 1u << (6 * (rem - 1));
-               Sig sub = sig_slice(nodes[static_cast<size_t>(nd)].second, v * span, (v + 1) * span);
-               if (sig_all_invalid(sub)) dst = inv;   // overlong form / beyond U+10FFFF
-               else dst = rem == 1 ? state_of(A.T(q, sub[0].second), 0) : state_of(q, intern(rem - 1, std::move(sub)));
-            }
+         else if (b < 0x80) dst = nd == 0 ? state_of(A.T(q, ascii_cls[b]), 0) : inv;
+         else {
+            const NodeStep st = node_steps[static_cast<size_t>(nd)][static_cast<size_t>(b - 0x80)];
+            dst = st.kind == 0 ? inv : (st.kind == 2 ? state_of(A.T(q, st.val), 0) : state_of(q, st.val));
          }
          T[s * 256 + static_cast<size_t>(b)] = dst;
       }
@@ -326,29 +411,56 @@ ByteDfa build_reverse_bytes(const ClassDfaView& R, const Sig& full) {
       }
       return std::make_pair(o, any);
    };
+   // The node a continuation byte leads to depends on the node alone, not on q: worked out once per node, when the first state that
+   // carries it is expanded (payloads in ascending order, as the states' own loops run: same node numbering).  -1 = INVALID.
+   std::vector<std::array<int, 64>> cont_next;   // [node][b & 0x3F]
+   std::vector<uint8_t> cont_done;
+   auto cont_of = [&](int nd) {
+      if (static_cast<size_t>(nd) >= cont_done.size()) {
+         cont_done.resize(static_cast<size_t>(nd) + 1, 0);
+         cont_next.resize(static_cast<size_t>(nd) + 1);
+      }
+      if (cont_done[static_cast<size_t>(nd)]) return;
+      std::array<int, 64> row;
+      const int k = nd == 0 ? 0 : nodes[static_cast<size_t>(nd)].first;
+      for (uint32_t v = 0; v < 64u; ++v) {
+         if (k == 3) {
+            row[v] = -1;
+            continue;
+         }
+         auto pr = nd == 0 ? shrink_all(canon, 0, v) : shrink_all(nodes[static_cast<size_t>(nd)].second, k, v);
+         row[v] = pr.second ? intern(k + 1, std::move(pr.first)) : -1;
+      }
+      if (static_cast<size_t>(nd) >= cont_done.size()) {
+         cont_done.resize(static_cast<size_t>(nd) + 1, 0);
+         cont_next.resize(static_cast<size_t>(nd) + 1);
+      }
+      cont_next[static_cast<size_t>(nd)] = row;
+      cont_done[static_cast<size_t>(nd)] = 1;
+   };
+   int ascii_cls[128];
+   for (int b = 0; b < 128; ++b) ascii_cls[b] = sig_eval(full, static_cast<uint32_t>(b));
    std::vector<int> T;
    for (size_t s = 0; s < keys.size(); ++s) {
       if (static_cast<int>(keys.size()) > kMaxByteStates) return r;
       const int q = keys[s].first, nd = keys[s].second;
       T.resize((s + 1) * 256);
+      if (q >= 0) cont_of(nd);
       for (int b = 0; b < 256; ++b) {
          int dst;
          const bool cont = b >= 0x80 && b < 0xC0, lead = b >= 0xC0 && b < 0xF8;
          if (q < 0) dst = static_cast<int>(s);
          else if (nd == 0) {
-            if (b < 0x80) dst = state_of(R.T(q, sig_eval(full, static_cast<uint32_t>(b))), 0);
+            if (b < 0x80) dst = state_of(R.T(q, ascii_cls[b]), 0);
             else if (cont) {
-               auto pr = shrink_all(canon, 0, static_cast<uint32_t>(b) & 0x3Fu);
-               dst = pr.second ? state_of(q, intern(1, std::move(pr.first))) : inv;
+               const int nx = cont_next[0][static_cast<size_t>(b) & 0x3Fu];
+               dst = nx >= 0 ? state_of(q, nx) : inv;
             } else dst = inv;   // a lead byte with nothing behind it, F8..FF
          } else {
             const int k = nodes[static_cast<size_t>(nd)].first;
             if (cont) {
-               if (k == 3) dst = inv;
-               else {
-                  auto pr = shrink_all(nodes[static_cast<size_t>(nd)].second, k, static_cast<uint32_t>(b) & 0x3Fu);
-                  dst = pr.second ? state_of(q, intern(k + 1, std::move(pr.first))) : inv;
-               }
+               const int nx = cont_next[static_cast<size_t>(nd)][static_cast<size_t>(b) & 0x3Fu];
+               dst = nx >= 0 ? state_of(q, nx) : inv;
             } else if (lead) {
                const int len = b < 0xE0 ? 2 : (b < 0xF0 ? 3 : 4);
                const uint32_t pay = static_cast<uint32_t>(b) & (b < 0xE0 ? 0x1Fu : (b < 0xF0 ? 0x0Fu : 0x07u));
@@ -472,14 +584,25 @@ void emit_class_map(Blob& bl, FxpHeader& h, const std::vector<int32_t>& bounds, 
    // instead of a binary search over the interval starts
    std::vector<uint16_t> page_of(1024);
    std::vector<uint16_t> pages;
-   std::map<std::vector<uint16_t>, uint16_t> seen;
+   std::map<std::vector<uint16_t>, uint16_t> seen;   // page contents -> page number, numbered in order of first appearance
+   std::vector<int> uniform_page;                    // class -> number of the page that holds that class 64 times (-1: none yet)
+   std::vector<uint16_t> v(64);
+   int iv = interval_of(0);                          // interval of the code the walk stands on (the pages are walked in order)
    for (int pg = 0; pg < 1024; ++pg) {
-      std::vector<uint16_t> v(64);
-      int iv = interval_of(pg * 64);
+      while (iv + 1 < nI && bounds[static_cast<size_t>(iv) + 1] <= pg * 64) ++iv;
+      // most pages lie inside ONE interval: looked up by class, not by contents
+      const bool one_interval = iv + 1 >= nI || bounds[static_cast<size_t>(iv) + 1] > pg * 64 + 63;
+      const int c0 = cls_of[static_cast<size_t>(iv)];
+      if (one_interval && static_cast<size_t>(c0) < uniform_page.size() && uniform_page[static_cast<size_t>(c0)] >= 0) {
+         page_of[static_cast<size_t>(pg)] = static_cast<uint16_t>(uniform_page[static_cast<size_t>(c0)]);
+         continue;
+      }
+      bool same = true;
       for (int k = 0; k < 64; ++k) {
          int32_t code = pg * 64 + k;
          while (iv + 1 < nI && bounds[static_cast<size_t>(iv) + 1] <= code) ++iv;
          v[static_cast<size_t>(k)] = static_cast<uint16_t>(cls_of[static_cast<size_t>(iv)]);
+         same = same && v[static_cast<size_t>(k)] == v[0];
       }
       auto it = seen.find(v);
       if (it == seen.end()) {
@@ -487,6 +610,10 @@ void emit_class_map(Blob& bl, FxpHeader& h, const std::vector<int32_t>& bounds, 
          pages.insert(pages.end(), v.begin(), v.end());
       }
       page_of[static_cast<size_t>(pg)] = it->second;
+      if (same) {
+         if (uniform_page.size() <= static_cast<size_t>(v[0])) uniform_page.resize(static_cast<size_t>(v[0]) + 1, -1);
+         uniform_page[static_cast<size_t>(v[0])] = it->second;
+      }
    }
    h.n_pages = static_cast<uint32_t>(seen.size());
    h.off_cls_page = bl.put(page_of.data(), page_of.size() * 2);
