@@ -322,6 +322,29 @@ def test_compile_status_and_blob_roundtrip(built):
     assert fx.Program("abc", fx.OP_SEARCH).info()["mode"] == 2            # whole-pattern literal -> INDEX path
 
 
+def test_program_images_equal_the_committed_fixture(built, monkeypatch):
+    """The program image is the wire format between ranks: the compiler's output for a fixed pattern list (bench configs, the GPU
+    tests' patterns, shapes of the reference's tests) must stay byte-identical to tests/golden/program_images.tsv -- status, size,
+    SHA-256.  (A deliberate table change bumps FXP_VERSION and regenerates the file: tests/golden/make_program_images.py.)"""
+    import hashlib
+    import forgex_amd as fx
+    monkeypatch.setenv("FXAMD_NO_CACHE", "1")
+    n = 0
+    with open(os.path.join(golden.GOLDEN, "program_images.tsv")) as f:
+        for ln in f:
+            if ln.startswith("#") or not ln.strip():
+                continue
+            hx, op, status, size, digest = ln.rstrip("\n").split("\t")
+            pat = b"" if hx == "-" else bytes.fromhex(hx)
+            q = fx.Program(pat, int(op))
+            assert q.status == int(status), (pat, op)
+            if q.status == 0:
+                image = q.blob()
+                assert len(image) == int(size) and hashlib.sha256(image).hexdigest()[:16] == digest, (pat, op)
+            n += 1
+    assert n >= 80
+
+
 def test_error_codes_and_messages_match_reference(built):
     import forgex_amd as fx
     n = 0
