@@ -11,6 +11,8 @@
 //   fx_general           one lane = one row through fxrow::run_row (row_engine.hpp): every mode, UTF-8 decode
 //                        on device, candidate-list driver, literal search, `.match.`; also the fix-up pass for
 //                        rows the fast kernel flags as non-ASCII.
+#include <functional>
+
 #include "fx_multi.hpp"
 
 #ifndef FX_SINGLE_TU   // the launcher instantiations live in fx_tile_inst.hip (one object per chunk count)
@@ -338,15 +340,29 @@ static std::vector<fxamd_program*> g_cache;   // most recently used last
 static constexpr size_t FX_CACHE_MAX = 64;
 static void destroy_program(fxamd_program* p);
 static void trim_scratch(fxamd_program* p);
+// Scratch a cached program may keep between calls (worklists, unpacked staging, NFA bitsets).  Trimming means hipFree, and every
+// hipFree synchronises the whole device: a Fortran loop of `pattern .in. strs(:)` does compile -> match -> free per call, so the
+// buffers stay with the cached program unless they exceed this budget (eviction from the cache frees everything anyway).
+static constexpr size_t FX_TRIM_BUDGET = size_t(512) << 20;
 static void release_program(fxamd_program* p) {
    bool dead = false, idle = false;
    {
       std::lock_guard<std::mutex> g(g_cache_mu);
       dead = --p->refs == 0;
       idle = p->refs == 1 && !p->cache_key.empty();   // only the cache holds it now
+      if (idle) ++p->refs;   // pinned while it is trimmed: a concurrent fxamd_compile may evict it from the cache meanwhile
+   }
+   if (dead) {
+      destroy_program(p);
+      return;
+   }
+   if (!idle) return;
+   trim_scratch(p);   // (no-op below FX_TRIM_BUDGET)
+   {
+      std::lock_guard<std::mutex> g(g_cache_mu);
+      dead = --p->refs == 0;   // the cache dropped it while it was pinned
    }
    if (dead) destroy_program(p);
-   else if (idle) trim_scratch(p);   // a cached program keeps its tables and counter words, not the per-batch buffers of a large call
 }
 
 // (callers hold p->mu)
@@ -691,6 +707,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
                               !std::getenv("FXAMD_MULTIPASS");
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
+      if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
       const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
       const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
@@ -815,6 +832,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
 
 static void trim_scratch(fxamd_program* p) {
    std::lock_guard<std::mutex> g(p->mu);
+   size_t held = 0;
+   for (const DevScratch& s : p->scratch)
+      held += (size_t)s.worklist_rows * 4 + (size_t)s.unpacked_rows * 9 + s.nfa_scratch_rows * (size_t)2 * p->prog.hdr().nfa_words * 4;
+   if (held <= FX_TRIM_BUDGET) return;
    for (DevScratch& s : p->scratch) {
       if (s.d_worklist && s.worklist_rows * 4 > (int64_t(1) << 20)) {
          (void)hipFree(s.d_worklist);
@@ -852,8 +873,10 @@ int fxamd_device_count(void) {
 int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status) {
    if (!out || pattern_len < 0 || (!pattern && pattern_len > 0) || (op != FXAMD_OP_SEARCH && op != FXAMD_OP_MATCH)) return FXAMD_E_ARG;
    fxamd_program* p = nullptr;
+   bool inserted = false, from_cache = false;   // p sits in g_cache / was handed out by it: then it is not ours to delete
    std::vector<fxamd_program*> evicted;
    try {   // nothing may cross the C boundary: the library never aborts the process
+      evicted.reserve(2);   // (one insertion evicts at most one entry: the push_back below cannot throw)
       const bool cached = pattern_len <= 4096 && !std::getenv("FXAMD_NO_CACHE");
       std::string key;
       if (cached) {
@@ -866,6 +889,7 @@ int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_progra
                g_cache.erase(g_cache.begin() + (long)i);
                g_cache.push_back(p);
                ++p->refs;
+               from_cache = true;
                break;
             }
       }
@@ -874,9 +898,11 @@ int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_progra
          p->prog = fxc::compile(std::string(pattern ? pattern : "", (size_t)pattern_len), op);
          if (cached && p->prog.blob.size() <= (size_t(1) << 20)) {
             std::lock_guard<std::mutex> g(g_cache_mu);
-            p->cache_key = key;
+            g_cache.reserve(g_cache.size() + 1);   // (may throw: nothing has been changed yet)
+            p->cache_key = key;                    // (may throw: p is not in the cache yet, `inserted` still false)
+            g_cache.push_back(p);                  // (cannot throw after the reserve)
             ++p->refs;
-            g_cache.push_back(p);
+            inserted = true;
             while (g_cache.size() > FX_CACHE_MAX) {
                fxamd_program* old = g_cache.front();
                g_cache.erase(g_cache.begin());
@@ -886,10 +912,12 @@ int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_progra
          }
       }
    } catch (const std::bad_alloc&) {
-      if (p && p->cache_key.empty()) delete p;
+      if (p && !inserted && !from_cache) delete p;
+      for (fxamd_program* e : evicted) destroy_program(e);
       return FXAMD_E_NOMEM;
    } catch (...) {
-      if (p && p->cache_key.empty()) delete p;
+      if (p && !inserted && !from_cache) delete p;
+      for (fxamd_program* e : evicted) destroy_program(e);
       return FXAMD_E_ARG;
    }
    for (fxamd_program* e : evicted) destroy_program(e);
@@ -1234,27 +1262,49 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       std::memset(&a, 0, sizeof(a));
       const size_t g1 = std::min(fused.size(), g0 + (size_t)gmax);
       if (g1 - g0 < 2) break;   // a single leftover pattern takes its own (faster) pipeline
-      for (size_t k = g0; k < g1; ++k) {
+      // The group's handles stay locked from the first PREPARE to the last follow-up (in address order: two threads fusing
+      // overlapping groups cannot deadlock): PREPARE flips a handle's counter group, and nobody else may enqueue on that handle
+      // until the shared first pass -- which zeroes the other group for the call after this one -- is in the stream.
+      std::vector<fxamd_program*> group;
+      for (size_t k = g0; k < g1; ++k) group.push_back(progs[fused[k]]);   // (distinct: `fused` holds first occurrences only)
+      std::sort(group.begin(), group.end(), std::less<fxamd_program*>());
+      std::vector<std::unique_lock<std::mutex>> locks;
+      locks.reserve(group.size());
+      for (fxamd_program* p : group) locks.emplace_back(p->mu);
+      std::vector<SharedFirstPass> shs(g1 - g0);
+      std::vector<DevScratch*> scs(g1 - g0, nullptr);
+      std::vector<uint8_t*> blobs(g1 - g0, nullptr);
+      size_t prepared = 0;   // patterns whose counter group PREPARE has flipped
+      // an error before the shared first pass is enqueued: flip the groups back, so that the next call meets the zeroed group again
+      auto undo = [&]() {
+         for (size_t k = 0; k < prepared; ++k) scs[k]->parity ^= 1u;
+      };
+      int rc = FXAMD_OK;
+      for (size_t k = g0; k < g1 && rc == FXAMD_OK; ++k) {
          fxamd_program* p = progs[fused[k]];
-         std::lock_guard<std::mutex> g(p->mu);
-         uint8_t* d_blob = nullptr;
-         int rc = blob_for_device(p, dev, &d_blob);
-         if (rc != FXAMD_OK) return rc;
-         DevScratch* sc = nullptr;
-         rc = scratch_for(p, dev, st, &sc);
-         if (rc != FXAMD_OK) return rc;
-         SharedFirstPass sh;
+         rc = blob_for_device(p, dev, &blobs[k - g0]);
+         if (rc == FXAMD_OK) rc = scratch_for(p, dev, st, &scs[k - g0]);
+         if (rc != FXAMD_OK) break;
          const int64_t slot = fused[k];
-         rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr, d_to ? d_to + slot * n : nullptr, st, 0u,
-                            FX_FP_PREPARE, &sh);
-         if (rc != FXAMD_OK) return rc;
-         a.blob[a.m] = d_blob;
+         const uint32_t parity_before = scs[k - g0]->parity;
+         rc = enqueue_batch(p, blobs[k - g0], scs[k - g0], d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr,
+                            d_to ? d_to + slot * n : nullptr, st, 0u, FX_FP_PREPARE, &shs[k - g0]);
+         if (rc != FXAMD_OK) {
+            scs[k - g0]->parity = parity_before;   // (a PREPARE that failed half-way)
+            break;
+         }
+         ++prepared;
+         a.blob[a.m] = blobs[k - g0];
          a.fp[a.m] = params_of(p->prog.hdr(), 0, false);
          a.slot[a.m] = (uint32_t)slot;
-         a.ctr[a.m] = sh.ctr;
-         a.worklist[a.m] = sh.worklist;
-         a.defer_tiles[a.m] = sh.defer_tiles;
+         a.ctr[a.m] = shs[k - g0].ctr;
+         a.worklist[a.m] = shs[k - g0].worklist;
+         a.defer_tiles[a.m] = shs[k - g0].defer_tiles;
          ++a.m;
+      }
+      if (rc != FXAMD_OK) {
+         undo();
+         return rc;
       }
       hipError_t e = hipErrorInvalidValue;
       switch (ch) {
@@ -1267,21 +1317,18 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          case 12: e = launch_multi<12>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          default: e = launch_multi<16>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
       }
-      FX_HIP(e);
-      // every pattern's own follow-up passes (tiles it deferred, rows it listed): gated kernels, empty on pure-ASCII batches
+      if (e != hipSuccess) {
+         undo();
+         return hip_fail(e);
+      }
+      // every pattern's own follow-up passes (tiles it deferred, rows it listed): gated kernels, empty on pure-ASCII batches.  They
+      // use the counter words and the worklist PREPARE chose (carried in `shs`, not recomputed).
       for (size_t k = g0; k < g1; ++k) {
          fxamd_program* p = progs[fused[k]];
-         std::lock_guard<std::mutex> g(p->mu);
-         uint8_t* d_blob = nullptr;
-         int rc = blob_for_device(p, dev, &d_blob);
-         if (rc != FXAMD_OK) return rc;
-         DevScratch* sc = nullptr;
-         rc = scratch_for(p, dev, st, &sc);
-         if (rc != FXAMD_OK) return rc;
          const int64_t slot = fused[k];
-         rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr, d_to ? d_to + slot * n : nullptr, st, 0u,
-                            FX_FP_DONE, nullptr);
-         if (rc != FXAMD_OK) return rc;
+         rc = enqueue_batch(p, blobs[k - g0], scs[k - g0], d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr,
+                            d_to ? d_to + slot * n : nullptr, st, 0u, FX_FP_DONE, &shs[k - g0]);
+         if (rc != FXAMD_OK) return rc;   // (the shared first pass ran: the counter groups are consistent)
          p->last_path = 15;   // first pass shared with other patterns
          done[(size_t)slot] = 1;
       }
@@ -1426,6 +1473,28 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
    }
    if (registered) (void)hipHostUnregister(const_cast<uint8_t*>(h_rows));
    return rc;
+}
+
+// ---- subroutine forms for Fortran `pure` hosts ---------------------------------------------------------------------------------
+// A Fortran PURE FUNCTION may only have INTENT(IN) / VALUE dummies (F2018 C1590), and a compiler may merge or drop calls of a pure
+// function whose result it does not need: the module binds these instead -- every output, the return code included, is an INTENT(OUT)
+// argument of a pure SUBROUTINE.
+void fxamd_f_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status, int32_t* rc) {
+   const int r = fxamd_compile(pattern, pattern_len, op, out, status);
+   if (rc) *rc = r;
+}
+void fxamd_f_program_free(fxamd_program* p, int32_t* rc) {
+   fxamd_program_free(p);
+   if (rc) *rc = FXAMD_OK;
+}
+void fxamd_f_strerror_copy(int32_t status, char* buf, int64_t capacity, int64_t* n) {
+   const int64_t r = fxamd_strerror_copy(status, buf, capacity);
+   if (n) *n = r;
+}
+void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags, int32_t* h_from,
+                              int32_t* h_to, int32_t* rc) {
+   const int r = fxamd_match_batch_host(p, h_rows, n, row_len, h_flags, h_from, h_to);
+   if (rc) *rc = r;
 }
 
 #ifdef FX_STAMP

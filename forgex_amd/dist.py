@@ -15,8 +15,28 @@ def shard_bounds(n, rank, world):
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
+def span_bytes(row_len):
+    """Bytes per span entry of the packed layout -- the C ABI's rule (fxamd_packed_layout): 1 up to 255, 2 up to 65535, else 4."""
+    return 1 if row_len <= 255 else (2 if row_len <= 65535 else 4)
+
+
 def span_dtype(row_len):
-    return torch.uint8 if row_len <= 255 else (torch.int16 if row_len <= 32767 else torch.int32)
+    """Storage dtype of a span entry.  Two-byte entries are UNSIGNED 16-bit values kept in int16 storage (torch has no arithmetic
+    on uint16): _narrow / _widen below convert."""
+    return {1: torch.uint8, 2: torch.int16, 4: torch.int32}[span_bytes(row_len)]
+
+
+def _narrow(x, row_len):
+    w = span_bytes(row_len)
+    if w == 2:   # 0..65535 -> the int16 with the same bit pattern
+        x = x.to(torch.int32)
+        return (((x + 32768) % 65536) - 32768).to(torch.int16)
+    return x.to(span_dtype(row_len))
+
+
+def _widen(x):
+    y = x.to(torch.int32)
+    return (y & 0xFFFF) if x.dtype == torch.int16 else y
 
 
 def pack_results(flags, frm, to, row_len):
@@ -26,19 +46,18 @@ def pack_results(flags, frm, to, row_len):
     f = torch.cat([flags, flags.new_zeros(pad)]) if pad else flags
     w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=flags.device)
     bits = (f.view(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8)
-    dt = span_dtype(row_len)
-    return bits, frm.to(dt), to.to(dt)
+    return bits, _narrow(frm, row_len), _narrow(to, row_len)
 
 
 def unpack_results(bits, frm, to, n):
     w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=bits.device)
     flags = ((bits.to(torch.int32)[:, None] & w) != 0).to(torch.uint8).reshape(-1)[:n]
-    return flags, frm.to(torch.int32), to.to(torch.int32)
+    return flags, _widen(frm), _widen(to)
 
 
 def packed_layout(n, row_len):
     """Byte layout of one shard's packed results: [bits | pad to 16][from, narrow][pad to 16][to, narrow] -> (off_from, off_to, total)."""
-    w = torch.empty(0, dtype=span_dtype(row_len)).element_size()
+    w = span_bytes(row_len)
     nb = ((n + 7) // 8 + 15) & ~15
     ns = (n * w + 15) & ~15
     return nb, nb + ns, nb + 2 * ns
@@ -68,7 +87,7 @@ def gather_results(flags, frm, to, n_total, row_len, dst=0):
     lst = [torch.empty(mx, dtype=torch.uint8, device=flags.device) for _ in range(world)]
     dist.gather(buf, lst, dst=dst)
     dt = span_dtype(row_len)
-    w = torch.empty(0, dtype=dt).element_size()
+    w = span_bytes(row_len)
     fl, fr, tt = [], [], []
     for r in range(world):
         m = sizes[r]
@@ -81,27 +100,41 @@ def gather_results(flags, frm, to, n_total, row_len, dst=0):
     return torch.cat(fl), torch.cat(fr), torch.cat(tt)
 
 
-def gather_packed(packed, n_total, row_len, spans=True, dst=0):
-    """Every rank passes the packed image of its shard (Program.match_device_packed); rank `dst` returns the list of the shards'
-    images (views trimmed to each shard's size) together with the shards' row counts, others None.  ONE collective."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = []
-    for r in range(world):
-        a, b = shard_bounds(n_total, r, world)
-        sizes.append(b - a)
-    w = torch.empty(0, dtype=span_dtype(row_len)).element_size() if spans else 0
+def _shard_sizes(n_total, world):
+    return [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
 
-    def total(m):
-        nb = ((m + 7) // 8 + 15) & ~15
-        return nb + 2 * ((m * w + 15) & ~15)
-    mx = max(max(total(m) for m in sizes), 16)
+
+def _packed_total(m, row_len, spans):
+    w = span_bytes(row_len) if spans else 0
+    nb = ((m + 7) // 8 + 15) & ~15
+    return nb + 2 * ((m * w + 15) & ~15)
+
+
+def gather_buffers(n_total, row_len, spans, device, dst=0):
+    """What gather_packed needs besides the shard's image, allocated ONCE (outside any timed gather): the send buffer of the common
+    size and, on rank `dst`, the receive buffers.  Returns (send, recv_list or None)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mx = max(max(_packed_total(m, row_len, spans) for m in _shard_sizes(n_total, world)), 16)
+    send = torch.zeros(mx, dtype=torch.uint8, device=device)
+    recv = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+    return send, recv
+
+
+def gather_packed(packed, n_total, row_len, spans=True, dst=0, buffers=None):
+    """Every rank passes the packed image of its shard (Program.match_device_packed); rank `dst` returns the list of the shards'
+    images (views trimmed to each shard's size) together with the shards' row counts, others None.  ONE collective.
+    `buffers`: gather_buffers(...) made beforehand, so that the call itself allocates nothing."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = _shard_sizes(n_total, world)
+    mx = max(max(_packed_total(m, row_len, spans) for m in sizes), 16)
+    send, recv = buffers if buffers is not None else gather_buffers(n_total, row_len, spans, packed.device, dst)
+    assert send.numel() == mx and (rank != dst or len(recv) == world)
     buf = packed
-    if packed.numel() != mx:
-        buf = torch.zeros(mx, dtype=torch.uint8, device=packed.device)
+    if packed.numel() != mx:   # a shard smaller than the largest one: its image rides in the common-size send buffer
+        buf = send
         buf[:min(packed.numel(), mx)] = packed[:mx]
     if rank != dst:
         dist.gather(buf, None, dst=dst)
         return None
-    lst = [torch.empty(mx, dtype=torch.uint8, device=packed.device) for _ in range(world)]
-    dist.gather(buf, lst, dst=dst)
-    return [lst[r][:max(total(sizes[r]), 16)] for r in range(world)], sizes
+    dist.gather(buf, recv, dst=dst)
+    return [recv[r][:max(_packed_total(sizes[r], row_len, spans), 16)] for r in range(world)], sizes

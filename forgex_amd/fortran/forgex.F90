@@ -7,7 +7,8 @@
 ! include/forgex_amd.h (libforgex_amd.so: host table compiler + HIP kernels for gfx950).
 !
 ! What a maintainer should know (INTEGRATION.md):
-!   * The C entry points are declared PURE in the interface block below.  That is the contract the library keeps: a call's
+!   * The C entry points are bound as PURE SUBROUTINES (the library's fxamd_f_* forms: every output is an INTENT(OUT) argument, which
+!     is what F2018 allows a pure procedure -- gfortran and flang both accept it).  That is the contract the library keeps: a call's
 !     results depend on its arguments only, nothing the caller can observe is modified, handles are thread-safe -- so the
 !     public procedures keep the reference's `pure` / `elemental` attributes and stay callable from pure procedures and
 !     `do concurrent`.  (The reference's own IMPURE switch, src/forgex.F90:10-13, is available here too: -DIMPURE.)
@@ -38,33 +39,37 @@ module forgex
    integer(c_int), parameter :: FXAMD_OP_SEARCH = 0, FXAMD_OP_MATCH = 1
    integer, parameter :: INVALID_CHAR_INDEX = -9999
 
+   ! The library's subroutine forms (include/forgex_amd.h, "Subroutine forms ... for Fortran pure hosts"): a PURE FUNCTION may only
+   ! have INTENT(IN) / VALUE dummies (F2018 C1590 -- gfortran rejects anything else), and a pure function call whose result is not
+   ! needed may be dropped, so every output, the return code included, is an INTENT(OUT) argument of a pure SUBROUTINE.
    interface
-      PURE_ function fxamd_compile(pattern, pattern_len, op, prog, status) bind(C, name='fxamd_compile') result(rc)
+      PURE_ subroutine fxamd_f_compile(pattern, pattern_len, op, prog, status, rc) bind(C, name='fxamd_f_compile')
          import :: c_char, c_int64_t, c_int, c_ptr, c_int32_t
          character(kind=c_char), intent(in) :: pattern(*)
          integer(c_int64_t), value :: pattern_len
          integer(c_int), value :: op
          type(c_ptr), intent(out) :: prog
          integer(c_int32_t), intent(out) :: status
-         integer(c_int) :: rc
-      end function
-      PURE_ subroutine fxamd_program_free(prog) bind(C, name='fxamd_program_free')
-         import :: c_ptr
-         type(c_ptr), value :: prog
+         integer(c_int32_t), intent(out) :: rc
       end subroutine
-      PURE_ function fxamd_match_batch_host(prog, rows, n, row_len, flags, from, to) bind(C, name='fxamd_match_batch_host') result(rc)
-         import :: c_ptr, c_int64_t, c_int
+      PURE_ subroutine fxamd_f_program_free(prog, rc) bind(C, name='fxamd_f_program_free')
+         import :: c_ptr, c_int32_t
+         type(c_ptr), value :: prog
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      PURE_ subroutine fxamd_f_match_batch_host(prog, rows, n, row_len, flags, from, to, rc) bind(C, name='fxamd_f_match_batch_host')
+         import :: c_ptr, c_int64_t, c_int32_t
          type(c_ptr), value :: prog, rows, flags, from, to
          integer(c_int64_t), value :: n, row_len
-         integer(c_int) :: rc
-      end function
-      PURE_ function fxamd_strerror_copy(status, buf, cap) bind(C, name='fxamd_strerror_copy') result(n)
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      PURE_ subroutine fxamd_f_strerror_copy(status, buf, cap, n) bind(C, name='fxamd_f_strerror_copy')
          import :: c_int32_t, c_char, c_int64_t
          integer(c_int32_t), value :: status
          character(kind=c_char), intent(inout) :: buf(*)
          integer(c_int64_t), value :: cap
-         integer(c_int64_t) :: n
-      end function
+         integer(c_int64_t), intent(out) :: n
+      end subroutine
    end interface
 
    interface is_valid_regex
@@ -101,7 +106,7 @@ contains
       character(kind=c_char) :: buf(256)
       integer(c_int64_t) :: n
       integer :: i
-      n = fxamd_strerror_copy(int(code, c_int32_t), buf, int(size(buf), c_int64_t))
+      call fxamd_f_strerror_copy(int(code, c_int32_t), buf, int(size(buf), c_int64_t), n)
       allocate(character(int(n)) :: msg)
       do i = 1, int(n)
          msg(i:i) = buf(i)
@@ -114,18 +119,26 @@ contains
       type(c_ptr), intent(out) :: prog
       integer, intent(out) :: status
       integer(c_int32_t) :: st
-      integer(c_int) :: rc
+      integer(c_int32_t) :: rc
       character(kind=c_char) :: buf(max(1, len(pattern)))
       integer :: i
       do i = 1, len(pattern)
          buf(i) = pattern(i:i)
       end do
-      rc = fxamd_compile(buf, int(len(pattern), c_int64_t), op, prog, st)
+      call fxamd_f_compile(buf, int(len(pattern), c_int64_t), op, prog, st, rc)
       if (rc /= 0) error stop 'forgex (amd): fxamd_compile failed'
       status = int(st)
       ! where the reference itself would `error stop` (tree / NFA / DFA limits, SURVEY.md section 5)
       if (status >= 100) error stop 'forgex (amd): pattern exceeds the limits of the automaton builder (status >= 100)'
    end subroutine compile
+
+   !> drop the handle's reference (the return code is an output, so the call cannot be elided)
+   PURE_ subroutine release(prog)
+      type(c_ptr), intent(in) :: prog
+      integer(c_int32_t) :: rc
+      call fxamd_f_program_free(prog, rc)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_program_free failed'
+   end subroutine release
 
    !> run one batch: rows = storage of character(row_len) :: s(n)
    PURE_ subroutine run_batch(prog, rows, n, row_len, flags, from, to)
@@ -133,12 +146,12 @@ contains
       integer, intent(in) :: n, row_len
       integer(c_int8_t), intent(inout), target :: flags(:)
       integer(c_int32_t), intent(inout), target, optional :: from(:), to(:)
-      integer(c_int) :: rc
+      integer(c_int32_t) :: rc
       if (n == 0) return
       if (present(from) .and. present(to)) then
-         rc = fxamd_match_batch_host(prog, rows, int(n, c_int64_t), int(row_len, c_int64_t), c_loc(flags), c_loc(from), c_loc(to))
+         call fxamd_f_match_batch_host(prog, rows, int(n, c_int64_t), int(row_len, c_int64_t), c_loc(flags), c_loc(from), c_loc(to), rc)
       else
-         rc = fxamd_match_batch_host(prog, rows, int(n, c_int64_t), int(row_len, c_int64_t), c_loc(flags), c_null_ptr, c_null_ptr)
+         call fxamd_f_match_batch_host(prog, rows, int(n, c_int64_t), int(row_len, c_int64_t), c_loc(flags), c_null_ptr, c_null_ptr, rc)
       end if
       if (rc /= 0) error stop 'forgex (amd): fxamd_match_batch_host failed (the match path needs a HIP device; there is no CPU fallback)'
    end subroutine run_batch
@@ -148,16 +161,16 @@ contains
       logical :: res
       type(c_ptr) :: prog
       integer(c_int32_t) :: st
-      integer(c_int) :: rc
+      integer(c_int32_t) :: rc
       character(kind=c_char) :: buf(max(1, len(pattern)))
       integer :: i
       do i = 1, len(pattern)
          buf(i) = pattern(i:i)
       end do
-      rc = fxamd_compile(buf, int(len(pattern), c_int64_t), FXAMD_OP_SEARCH, prog, st)
+      call fxamd_f_compile(buf, int(len(pattern), c_int64_t), FXAMD_OP_SEARCH, prog, st, rc)
       if (rc /= 0) error stop 'forgex (amd): fxamd_compile failed'
       res = st == 0 .or. st >= 100     ! (beyond the builder's limits is still a VALID pattern)
-      call fxamd_program_free(prog)
+      call release(prog)
    end function is_valid_regex_pattern
 
    !---------------------------------------------------------------------------------------------------------------
@@ -192,7 +205,7 @@ contains
          call run_batch(prog, c_loc(str), size(str), len(str), flags)
          res = flags /= 0
       end if
-      call fxamd_program_free(prog)
+      call release(prog)
    end function flags_batch
 
    !---------------------------------------------------------------------------------------------------------------
@@ -332,7 +345,7 @@ contains
          from = int(f)
          to = int(t)
       end if
-      call fxamd_program_free(prog)
+      call release(prog)
    end subroutine subroutine__regex_batch
 
    PURE_ function function__regex(pattern, text) result(res)

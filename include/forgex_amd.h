@@ -123,6 +123,15 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
                            int32_t* h_from, int32_t* h_to);
 
+/* Subroutine forms of four entries above for Fortran `pure` hosts (forgex_amd/fortran/forgex.F90 binds these): a PURE FUNCTION may
+ * only have INTENT(IN) / VALUE dummies (F2018 C1590; gfortran rejects the function forms in a pure interface) and a compiler may
+ * merge or drop pure-function calls, so every output -- the return code included -- is a pointer argument here.  Same semantics. */
+void fxamd_f_compile(const char* pattern, int64_t pattern_len, int op, fxamd_program** out, int32_t* status, int32_t* rc);
+void fxamd_f_program_free(fxamd_program* p, int32_t* rc);
+void fxamd_f_strerror_copy(int32_t status, char* buf, int64_t capacity, int64_t* n);
+void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
+                              int32_t* h_from, int32_t* h_to, int32_t* rc);
+
 /* Which kernel path the last fxamd_match_batch_device call on this handle used (tests / diagnostics).  Multi-pass pipeline of
  * fx_search_fast / fx_match_fast (rows longer than 256 bytes, `.match.`, FXAMD_MULTIPASS=1): 1 = first pass + decode pass over deferred
  * tiles, 3 = first pass + general fix-up over a worklist, 5 / 6 = the same for automata with more than 8 states, 7 = byte-level tables

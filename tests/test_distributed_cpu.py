@@ -15,7 +15,7 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n_total = 1003
 a, b = fxdist.shard_bounds(n_total, rank, world)
-for L in (128, 256, 70000):   # spans narrowed to 1, 2 and 4 bytes (config 5, config 3, long rows)
+for L in (128, 256, 40000, 70000):   # spans narrowed to 1, 2, 2 (unsigned: above 32767) and 4 bytes (config 5, config 3, long rows)
     g = torch.Generator().manual_seed(5)
     flags_all = (torch.rand(n_total, generator=g) < 0.5).to(torch.uint8)
     from_all = (torch.randint(1, L, (n_total,), generator=g) * flags_all).to(torch.int32)
@@ -28,7 +28,7 @@ for L in (128, 256, 70000):   # spans narrowed to 1, 2 and 4 bytes (config 5, co
         assert res is None
 # the same through gather_packed: each rank's shard as ONE packed image (what Program.match_device_packed returns on a GPU; built
 # here with the torch implementation of the layout), one collective, unpacked on the root
-for L in (128, 256):
+for L in (128, 256, 65535):
     g = torch.Generator().manual_seed(7)
     flags_all = (torch.rand(n_total, generator=g) < 0.4).to(torch.uint8)
     from_all = (torch.randint(1, L, (n_total,), generator=g) * flags_all).to(torch.int32)
@@ -40,12 +40,13 @@ for L in (128, 256):
     img[:bits.numel()] = bits
     img[off_f:off_f + f8.numel() * f8.element_size()] = f8.view(torch.uint8)
     img[off_t:off_t + t8.numel() * t8.element_size()] = t8.view(torch.uint8)
-    res = fxdist.gather_packed(img, n_total, L, True, dst=0)
+    bufs = fxdist.gather_buffers(n_total, L, True, img.device, dst=0)   # made once, outside the gather (uneven shards: 501 / 502 rows)
+    res = fxdist.gather_packed(img, n_total, L, True, dst=0, buffers=bufs)
     if rank == 0:
         shards, sizes = res
         assert sizes == [fxdist.shard_bounds(n_total, r, world)[1] - fxdist.shard_bounds(n_total, r, world)[0] for r in range(world)]
         dt = fxdist.span_dtype(L)
-        w = torch.empty(0, dtype=dt).element_size()
+        w = fxdist.span_bytes(L)
         fl, fr, tt = [], [], []
         for im, mm in zip(shards, sizes):
             o_f, o_t, _ = fxdist.packed_layout(mm, L)
@@ -80,7 +81,7 @@ def test_shard_bounds_cover_everything():
 def test_pack_unpack_roundtrip():
     from forgex_amd import dist as fxdist
     g = torch.Generator().manual_seed(1)
-    for n, L in ((1, 8), (13, 255), (64, 256), (1001, 70000)):
+    for n, L in ((1, 8), (13, 255), (64, 256), (77, 32768), (500, 65535), (1001, 70000)):
         f = (torch.rand(n, generator=g) < 0.3).to(torch.uint8)
         a = torch.randint(0, L + 1, (n,), generator=g).to(torch.int32)
         b = torch.randint(0, L + 1, (n,), generator=g).to(torch.int32)
@@ -88,6 +89,19 @@ def test_pack_unpack_roundtrip():
         assert bits.numel() == (n + 7) // 8
         f2, a2, b2 = fxdist.unpack_results(bits, a8, b8, n)
         assert torch.equal(f, f2) and torch.equal(a, a2) and torch.equal(b, b2)
+
+
+def test_packed_layout_is_the_c_abis(built):
+    """forgex_amd.dist (torch ops) and fxamd_packed_layout (what the kernels write) agree on offsets and span widths, in
+    particular for rows of 32768..65535 bytes (two-byte UNSIGNED spans)."""
+    import forgex_amd
+    from forgex_amd import dist as fxdist
+    for L in (1, 255, 256, 32767, 32768, 65535, 65536, 100000):
+        for n in (0, 1, 63, 64, 65, 1003, 12_500_000):
+            off_f, off_t, total, w = forgex_amd.packed_layout(n, L, True)
+            assert fxdist.packed_layout(n, L) == (off_f, off_t, total), (n, L)
+            assert fxdist.span_bytes(L) == w, L
+            assert torch.empty(0, dtype=fxdist.span_dtype(L)).element_size() == w
 
 
 def test_two_rank_gather_gloo(tmp_path):

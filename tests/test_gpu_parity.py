@@ -1030,3 +1030,50 @@ def test_long_rows_last_bytes_of_a_tile(fx):
                 om, _, _ = oracle_lib.batch(1, pat, rows, NT)
                 pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
                 assert np.array_equal(fm, om), (pat, L, n, "match", np.flatnonzero(fm != om)[:5])
+
+
+def test_config_scale_rows_vs_real_reference_fixture(fx):
+    """tests/golden/config_rows.tsv: the REAL reference's flag / from / to (recorded in the container by
+    tests/golden/make_config_goldens.py through oracle/_ref/ref_driver) on 2000-6144 rows of each BASELINE config (first and last
+    rows of the batch, every shard of config 5's 8-GPU partition, 1024 corrupted rows of config 4), 4096 invalid-UTF-8 mutations at
+    row lengths 64..256 under four patterns and the Appendix A quirk probes embedded in rows of 64..256 bytes.  The rows are
+    regenerated here by (section, index), checked against the recorded CRC, and go through the C ABI on the device.  This is the
+    comparison that does NOT share the front end with the product: reference src/api_internal_m.F90:108-164, :171-303,
+    src/essential/utf8_m.f90:168-246."""
+    import zlib
+    import config_rows as cr
+    fix, crcs = cr.load_fixture(os.path.join(golden.GOLDEN, "config_rows.tsv"))
+    n_rows = 0
+    paths = {}
+    for name, op, pat, L, n, getter in cr.all_sections():
+        rows = getter()
+        assert cr.crc_of(rows) == crcs[name], name
+        prog, f, a, b = _device_run(fx, pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH, rows, spans=True)
+        want = fix[name]
+        bad = np.flatnonzero(f.astype(np.int64) != want[:, 0])
+        assert bad.size == 0, (name, int(bad[0]), bytes(rows[bad[0]]))
+        if op == "R":
+            bad = np.flatnonzero((a.astype(np.int64) != want[:, 1]) | (b.astype(np.int64) != want[:, 2]))
+            assert bad.size == 0, (name, int(bad[0]), int(a[bad[0]]), int(b[bad[0]]), want[bad[0]].tolist(), bytes(rows[bad[0]]))
+            # flags-only entry: the same verdicts
+            _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+            assert np.array_equal(f2.astype(np.int64), want[:, 0]), name
+        paths[name] = prog.last_path()
+        n_rows += n
+    # the BASELINE configs run on the tile kernels (one-launch kernel / half-row pipeline), not on the general kernel
+    assert paths["cfg3"] == 16 and paths["cfg2"] in (9, 10, 11, 12, 13, 14) and paths["cfg4"] in (10, 11) and paths["cfg5"] in (9, 10, 11), paths
+    cases = cr.probe_cases()
+    blob = b"".join(p.encode() + b"\0" + op.encode() + t for p, op, t in cases)
+    assert (zlib.crc32(blob) & 0xFFFFFFFF) == crcs["probes"]
+    groups = {}
+    for i, (pat, op, row) in enumerate(cases):
+        groups.setdefault((pat, op, len(row)), []).append(i)
+    for (pat, op, L), idx in groups.items():
+        rows = np.frombuffer(b"".join(cases[i][2] for i in idx), dtype=np.uint8).reshape(len(idx), L)
+        _, f, a, b = _device_run(fx, pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH, rows, spans=True)
+        want = fix["probes"][idx]
+        assert np.array_equal(f.astype(np.int64), want[:, 0]), (pat, op, L, f.tolist(), want[:, 0].tolist())
+        if op == "R":
+            assert np.array_equal(a.astype(np.int64), want[:, 1]) and np.array_equal(b.astype(np.int64), want[:, 2]), (pat, op, L)
+        n_rows += len(idx)
+    assert n_rows > 28000
