@@ -3,8 +3,15 @@
 
 A "step" is ONE pass of the hot path over the resident batch: fxamd_match_batch_device (flags + (from,to) spans
 for every row) on BASELINE.json config 3 -- `[a-z]+\\d+` over 10M x 256 B synthetic rows, inputs already in HBM.
-With --gpus N each rank owns its own shard of an N-times larger batch (weak scaling, no data-path collective);
-the packed-result gather over RCCL is timed separately and reported as `gather_ms`.
+With --gpus N each rank owns its own shard of an N-times larger batch (weak scaling, the default, no data-path collective);
+`--scaling strong` keeps the TOTAL at the config's row count (10M rows for config 3, as BASELINE.json's north star words it:
+"a 10M-string batch at 1, 2, 4 and 8 GPUs") and gives rank i the contiguous rows [i*N/W, (i+1)*N/W).  The packed-result gather
+over RCCL is timed separately and reported as `gather_ms`.
+
+Documented multi-GPU invocations (the driver's `--gpus N --steps K --warmup W` form is the first):
+    python bench.py --gpus 8                         weak scaling on config 3: 8 x 10M x 256 B
+    python bench.py --gpus 8 --scaling strong        config 3's 10M rows split over 8 GPUs
+    python bench.py --gpus 8 --config cfg5           BASELINE config 5: 100M x 128 B sharded over 8 GPUs + RCCL gather of the spans
 
 Launch: `python bench.py --gpus N` starts the N rank processes itself (one per GPU, RCCL rendezvous on 127.0.0.1) when no
 launcher did; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the launcher's
@@ -195,13 +202,23 @@ def host_path_rate(fx, prog, cfg, row_len, nrows=1 << 20):
     from forgex_amd import synth
     rows = np.ascontiguousarray(synth.batch(cfg, 0, nrows, torch.device("cpu")).numpy())
     prog.match_host(rows, spans=True)   # first call allocates the handle's chunk slots
-    t0 = time.perf_counter()
     reps = 3
-    for _ in range(reps):
-        res = prog.match_host(rows, spans=True)
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": nrows * row_len / dt / 1e9, "unit": "GB/s of input, PCIe-inclusive (H2D rows + kernels + D2H results)",
-            "rows": nrows, "ms_per_call": dt * 1e3, "matches": int(res[0].sum())}
+
+    def rate():
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = prog.match_host(rows, spans=True)
+        return (time.perf_counter() - t0) / reps, res
+    dt, res = rate()
+    out = {"value": nrows * row_len / dt / 1e9, "unit": "GB/s of input, PCIe-inclusive (H2D rows + kernels + D2H results), pageable caller memory",
+           "rows": nrows, "ms_per_call": dt * 1e3, "matches": int(res[0].sum())}
+    try:   # the same with the caller's array pinned in place (fxamd_host_register): the rows travel by DMA from the caller's memory
+        with fx.pinned(rows):
+            dtp, _ = rate()
+        out["pinned"] = {"value": nrows * row_len / dtp / 1e9, "ms_per_call": dtp * 1e3}
+    except Exception as e:
+        out["pinned"] = {"value": None, "error": repr(e)}
+    return out
 
 
 def dryrun(args, rank, world, emit):
@@ -232,7 +249,7 @@ def dryrun(args, rank, world, emit):
     dist.destroy_process_group()
     if rank == 0:
         emit({"metric": "input GB/s scanned (.in. over 10M strings)", "value": None, "unit": "GB/s", "n_gpus": world, "dryrun": True,
-              "ranks_joined": int(tt.item()), "gather_ok": ok, "steps": args.steps, "warmup": args.warmup,
+              "ranks_joined": int(tt.item()), "gather_ok": ok, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
               "config": {"workload": "dry run of the %d-rank plumbing on CPU (gloo); no GPU work" % world, "parallelism": "shard%d" % world,
                          "rows_per_gpu": rows_per_gpu}})
     return 0
@@ -246,6 +263,8 @@ def main():
                     help="untimed steps first; the clocks settle over the first ~20-30 back-to-back launches after an idle gap (DESIGN.md 4.1)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's size; cfg5: 12.5M)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU scans its own config-sized shard; strong: the config's rows are split over the GPUs")
     ap.add_argument("--flags-only", action="store_true", help="time the flags-only `.in.` entry instead of flags+spans")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the whole-batch host check (profiling runs)")
@@ -291,9 +310,14 @@ def main():
 
     cfg = args.config
     n_cfg, row_len = synth.SHAPES[cfg]
-    rows_per_gpu = args.rows or (n_cfg if cfg != "cfg5" else n_cfg // 8)
+    if args.scaling == "strong" and not args.rows:
+        # the config's rows (config 5: all 100M) split into contiguous shards, rank i = [i*N/W, (i+1)*N/W)
+        start, stop = fxdist.shard_bounds(n_cfg, rank, world)
+        rows_per_gpu = stop - start
+    else:
+        rows_per_gpu = args.rows or (n_cfg if cfg != "cfg5" else n_cfg // 8)
+        start = rank * rows_per_gpu
     pattern = synth.PATTERNS[cfg]
-    start = rank * rows_per_gpu
     prog = forgex_amd.Program(pattern, forgex_amd.OP_SEARCH)
     assert prog.status == 0
     spans = not args.flags_only
@@ -301,6 +325,19 @@ def main():
     frm = torch.empty(rows_per_gpu, dtype=torch.int32, device=dev) if spans else None
     to = torch.empty(rows_per_gpu, dtype=torch.int32, device=dev) if spans else None
     out = (flags, frm, to)
+    # Program initialisation, as a service does it once at start-up -- NOT a warm-up step of the workload: tables uploaded, the
+    # stream's scratch reserved, and the kernels' code objects loaded by one call on 64 rows of the generator (HIP loads a code
+    # object at the first launch of one of its kernels: tens of milliseconds of host work during which the GPU idles).  Measured
+    # (profiles/r03_transient.md): the first ~40 launches after an idle GPU run up to 38 % slower -- the core clock, not memory: a
+    # plain copy and the kernel's no-compute build show no such transient -- so an init that happens between the generator and the
+    # warm-up steps puts the whole `--warmup 5 --steps 20` region inside that transient.
+    init_rows = synth.batch(cfg, start, 64, dev)
+    init_out = (torch.empty(64, dtype=torch.uint8, device=dev), torch.empty(64, dtype=torch.int32, device=dev) if spans else None,
+                torch.empty(64, dtype=torch.int32, device=dev) if spans else None)
+    prog.match_device(init_rows, spans=spans, out=init_out)
+    rc = forgex_amd.lib().fxamd_program_reserve(prog._h, rows_per_gpu, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
     # the batch is generated on the GPU LAST (seconds of generator kernels), so that the warm-up steps follow a busy GPU, not an idle gap
     rows = synth.batch(cfg, start, rows_per_gpu, dev)
 
@@ -330,7 +367,12 @@ def main():
         step()
     dt = timed(args.steps)
     n_matches = int((flags != 0).sum().item())
-    total_bytes = world * rows_per_gpu * row_len * args.steps
+    rows_all = rows_per_gpu * world
+    if use_dist and args.scaling == "strong":
+        tt = torch.tensor([rows_per_gpu], dtype=torch.int64, device=dev)
+        dist.all_reduce(tt)
+        rows_all = int(tt.item())
+    total_bytes = rows_all * row_len * args.steps
     # ---- the same again at settled clocks (SETTLE more back-to-back launches first) ------------------------------------------------
     for _ in range(SETTLE):
         step()
@@ -407,7 +449,7 @@ def main():
                     prog.match_device(rows, spans=False, out=out_f)
                 torch.cuda.synchronize()
                 fdt = time.perf_counter() - f0
-                flags_only = {"value": world * rows_per_gpu * row_len * args.steps / fdt / 1e9, "unit": "GB/s (this rank's time, all ranks' bytes)",
+                flags_only = {"value": rows_all * row_len * args.steps / fdt / 1e9, "unit": "GB/s (this rank's time, all ranks' bytes)",
                               "ms_per_step": fdt / args.steps * 1e3}
                 step()   # restore flags + spans for the checks below
                 torch.cuda.synchronize()
@@ -450,32 +492,40 @@ def main():
             prog.match_device_packed(rows, spans=spans, out=packed)
         torch.cuda.synchronize()
         packed_step_ms = (time.perf_counter() - p0) / 20 * 1e3
-        fxdist.gather_packed(packed, rows_per_gpu * world, row_len, spans)   # warm-up (RCCL connection setup)
+        # shards of equal size (weak scaling) travel as they are; the buffers of the gather are made once, outside the timed call
+        n_gather = rows_per_gpu * world
+        if args.scaling == "strong":
+            n_gather = rows_all
+        bufs = fxdist.gather_buffers(n_gather, row_len, spans, dev)
+        fxdist.gather_packed(packed, n_gather, row_len, spans, buffers=bufs)   # warm-up (RCCL connection setup)
         barrier()
         g0 = time.perf_counter()
-        res = fxdist.gather_packed(packed, rows_per_gpu * world, row_len, spans)
+        res = fxdist.gather_packed(packed, n_gather, row_len, spans, buffers=bufs)
         if rank == 0:
             shards, sizes = res
             unpacked = [forgex_amd.unpack_results(img, m, row_len, spans) for img, m in zip(shards, sizes)]
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            assert sum(sizes) == rows_per_gpu * world
+            assert sum(sizes) == n_gather and sizes[0] == rows_per_gpu
             # the gathered shard of rank 0 is what rank 0's plain call computed
             assert torch.equal(unpacked[0][0], flags) and (not spans or (torch.equal(unpacked[0][1], frm) and torch.equal(unpacked[0][2], to)))
 
+    # the other ranks are done: rank 0's host-side legs (whole-batch parity, CPU baseline) need no collective
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
     line = None
     if rank == 0:
         line = {
             "metric": "input GB/s scanned (.in. over 10M strings)", "value": total_bytes / dt / 1e9, "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: `%s` .in. (flags%s) over %d x %d B rows per GPU, counter-based PRNG rows resident in HBM" % (
                 cfg, pattern, " + (from,to) spans" if spans else " only", rows_per_gpu, row_len),
-                "rows_per_gpu": rows_per_gpu, "row_len": row_len, "pattern": pattern, "parallelism": "shard%d" % world,
+                "rows_per_gpu": rows_per_gpu, "rows_total": rows_all, "row_len": row_len, "pattern": pattern, "parallelism": "shard%d" % world,
                 "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches},
             "frac_of_hbm_peak": total_bytes / dt / 1e9 / (HBM_PEAK_GBS * world),
-            "frac_of_one_eighth_gpu": total_bytes / dt / 1e9 / (HBM_PEAK_GBS / 8 * world),
             "settled": {"value": total_bytes / dt_settled / 1e9, "ms_per_step": dt_settled / args.steps * 1e3,
                         "note": "the same %d timed steps after %d more untimed launches (clock transient over)" % (args.steps, SETTLE)},
             "roofline": roofline, "gather_ms": gather_ms, "packed_step_ms": packed_step_ms, "flags_only": flags_only, "host_path": host_path,
@@ -488,7 +538,7 @@ def main():
                 line["parity"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
         else:
             line["parity"] = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             gpu_res = None
             if spans:
                 k = min(rows_per_gpu, 200000)
@@ -496,9 +546,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, pattern, row_len, gpu_res)
         else:
             line["cpu_baseline"] = None
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         emit(line)
 

@@ -153,6 +153,26 @@ class Program:
         return flags, frm, to
 
 
+class pinned:
+    """`with pinned(rows): prog.match_host(rows)` -- the numpy array pinned in place for the block (fxamd_host_register): the host
+    entry then reads it by DMA instead of staging pageable memory."""
+
+    def __init__(self, arr):
+        self.arr = np.ascontiguousarray(arr)
+        if self.arr is not arr:
+            raise ValueError("pinned() needs a C-contiguous array (it is pinned in place)")
+
+    def __enter__(self):
+        rc = _lib.lib().fxamd_host_register(self.arr.ctypes.data_as(ctypes.c_void_p), self.arr.nbytes)
+        if rc != 0:
+            raise RuntimeError("fxamd_host_register failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
+        return self.arr
+
+    def __exit__(self, *exc):
+        _lib.lib().fxamd_host_unregister(self.arr.ctypes.data_as(ctypes.c_void_p))
+        return False
+
+
 def packed_layout(n, row_len, spans=True):
     """(off_from, off_to, total_bytes, span_bytes) of a packed result image (fxamd_packed_layout)."""
     a, b, t = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)

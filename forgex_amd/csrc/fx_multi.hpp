@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
             deferred_any |= 1u << p;
             continue;
          }
-         auto emit = [&](const int64_t r, const bool live, const bool, const uint32_t flag, const int32_t fr, const int32_t tt) {
+         auto emit = [&](const int64_t r, const bool live, const bool, const uint32_t flag, const int32_t fr, const int32_t tt, const bool) {
             if (live) {
                flags[base + r] = (uint8_t)flag;
                if (SPANS) {

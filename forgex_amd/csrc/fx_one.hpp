@@ -51,10 +51,28 @@ struct FxScanCtx {
    bool whole, raw;
    uint32_t pre_na;
 };
-template <int CH, bool SPANS, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool PREPAD, class TabT, class Emit>
+// Match compaction (DEFERQ): the exact start and the forward pass are per-ROW work that only rows with a hit need, but a
+// wave pays for them per TILE -- at full price when a few lanes in 64 have a hit (config 2: one row in ten matches).  Unless the tile
+// is dense in hits (more than FX_DEFER_DENSE of 64 rows), those rows are queued per wave (row, hit group, state entering it) and
+// finished 64 at a time from global memory (fx_finish_from_global); their flag is known at once (a start inside the text always
+// yields a span), only from / to follow at the flush.
+#ifndef FX_DEFER_DENSE
+#define FX_DEFER_DENSE 12   // tiles with more hit rows than this finish them in place (config 3 / 5: half of the rows match -- queueing those costs
+                            // scattered from / to stores and a second read of the rows' bytes: measured slower, profiles/r03_defer_ab.txt)
+#endif
+struct FxFwdQueue {
+   uint32_t* q;        // LDS: 64 row numbers, then 64 x (hit group | entry state << 16)
+   uint32_t n;         // entries (wave-uniform)
+   uint32_t family;    // table family of the queued entries: 0 class-level, 1 byte-level (wave-uniform)
+};
+struct FxNoFlush {
+   __device__ __forceinline__ void operator()() const {}
+};
+template <int CH, bool SPANS, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool PREPAD, bool DEFERQ = false, class TabT,
+          class Emit, class Flush = FxNoFlush>
 __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __restrict__ tabR, const TabT* __restrict__ tabA, const uint8_t* TRp,
                                              const uint8_t* TAp, const FastParams& P, const int64_t row, const bool row_ok, const bool ordered,
-                                             bool& except, Emit& emit) {
+                                             bool& except, Emit& emit, FxFwdQueue* fq = nullptr, Flush flush = Flush()) {
    {
       constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2;
       (void)CHAIN;
@@ -112,10 +130,39 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          row_hi = (na & 0x80808080u) != 0;
          if (REDO_TILE && __builtin_amdgcn_ballot_w64(row_hi) != 0) return true;
       }
-      uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
+      // leading NUL: a hit there is the leftmost start
       {
-         // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
-         const uint32_t g = gsel != 0xFFFFFFFFu ? gsel : 0u;
+         const F fz = tabR[0];
+         state = fxstep(fz, state, TRp);
+      }
+      const bool s_nul = state >= P.hit_min;
+      const bool hit = gsel != 0xFFFFFFFFu;
+      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8: the row is queued for the decode pass
+      // (GEN, class-level tables: a row that ended in the overlap state of a bordered prefix literal, or that holds a byte >= 0x80)
+      except = (BYTES && state == P.inv) || (ROW_EXC && !BYTES && !DECODED && ((P.inv_on != 0 && state == P.inv) || row_hi));
+      // ---- match compaction: rows with a start inside the text go to the wave's queue unless the tile is dense in them ----
+      bool queued = false;
+      if constexpr (DEFERQ && SPANS && !DECODED) {
+         const bool want = hit && !s_nul && !except && row_ok && P.lit_len == 0 && L >= 16u;
+         const uint64_t qm = __builtin_amdgcn_ballot_w64(want);
+         const uint32_t cnt = (uint32_t)__builtin_popcountll(qm);
+         if (cnt != 0u && cnt <= (uint32_t)FX_DEFER_DENSE) {
+            if (fq->n + cnt > 64u || (fq->n != 0u && fq->family != (BYTES ? 1u : 0u))) flush();
+            queued = want;
+            if (queued) {
+               const uint32_t slot = fq->n + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull));
+               fq->q[slot] = (uint32_t)row;
+               fq->q[64u + slot] = gsel | ((S_ == 0 ? (esel & 0xFFu) : esel) << 16);
+            }
+            fq->n += cnt;
+            fq->family = BYTES ? 1u : 0u;
+         }
+      }
+      uint32_t s = hit ? 2u : 0u;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none; 2 stands for "inside the text"
+      // exact byte of the leftmost hit: re-walk the selected group -- only spans need it (a verdict is "some start"), and only rows
+      // that were not queued
+      if (SPANS && __builtin_amdgcn_ballot_w64(hit && !queued && !s_nul && !except) != 0) {
+         const uint32_t g = hit ? gsel : 0u;
          const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
          F f[8];
          lookup8(f, rw.x, rw.y, tabR);
@@ -125,16 +172,11 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             st = fxstep(f[i], st, TRp);
             loc = st >= P.hit_min ? (uint32_t)i : loc;
          }
-         s = gsel != 0xFFFFFFFFu ? g * 8u + 2u + loc : 0u;
-         const F fz = tabR[0];   // leading NUL
-         state = fxstep(fz, state, TRp);
-         s = state >= P.hit_min ? 1u : s;
+         s = hit ? g * 8u + 2u + loc : 0u;
       }
-      // byte-level tables: the backward pass ended in the INVALID state -> structurally invalid UTF-8: the row is queued for the decode pass
-      // (GEN, class-level tables: a row that ended in the overlap state of a bordered prefix literal, or that holds a byte >= 0x80)
-      except = (BYTES && state == P.inv) || (ROW_EXC && !BYTES && !DECODED && ((P.inv_on != 0 && state == P.inv) || row_hi));
+      s = s_nul ? 1u : s;
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
-      uint32_t cur = (s != 0 && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
+      uint32_t cur = (s != 0 && !queued && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
       uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
@@ -245,7 +287,8 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       } else {
          flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
       }
-      emit(row, row_ok && !except, ordered, flag, fr, tt);
+      if (queued) flag = 1;   // (from / to follow when the queue is flushed)
+      emit(row, row_ok && !except, ordered, flag, fr, tt, !queued);
       return false;
    }
 }
@@ -278,6 +321,8 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    __shared__ fx_nib bwideR[BSCH == 2 ? 256 : 1];
    __shared__ fx_nib bwideA[BSCH == 2 ? 256 : 1];
    __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
+   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED;   // match compaction (see fx_scan_tile)
+   __shared__ uint32_t fwd_q[DEFERQ ? 4 * 128 : 1];   // per-wave queues of rows whose exact start + forward pass are finished 64 at a time
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // ---- tables -> LDS ----
@@ -340,11 +385,12 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
 
    // results of one row.  `ordered`: the wave holds 64 consecutive rows (a tile of the batch): the packed flag word is its ballot;
    // a gathered row (exception queue) sets its bit in the word its tile's wave stored earlier.
-   auto emit = [&](const int64_t row, const bool live, const bool ordered, const uint32_t flag, const int32_t fr, const int32_t tt) {
+   // spans_live == false: a row of the match-compaction queue -- its flag is final, its from / to are stored when the queue is flushed
+   auto emit = [&](const int64_t row, const bool live, const bool ordered, const uint32_t flag, const int32_t fr, const int32_t tt, const bool spans_live = true) {
       if (out_mode == 0u) {
          if (live) {
             flags[row] = (uint8_t)flag;
-            if (SPANS) {
+            if (SPANS && spans_live) {
                from[row] = fr;
                to[row] = tt;
             }
@@ -358,7 +404,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       } else if (live && flag != 0u) {
          atomicOr(reinterpret_cast<uint32_t*>(flags) + (row >> 5), 1u << ((uint32_t)row & 31u));
       }
-      if (SPANS && live) {
+      if (SPANS && live && spans_live) {
          if (out_mode == 1u) {
             reinterpret_cast<uint8_t*>(from)[row] = (uint8_t)fr;
             reinterpret_cast<uint8_t*>(to)[row] = (uint8_t)tt;
@@ -374,10 +420,11 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
 
    // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
    const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u};
-   auto scan = [&](auto cfg, const int64_t row, const bool row_ok, const bool ordered, bool& except) -> bool {
+   // tables of one family (class-level / byte-level) in the scheme `S_`, handed to `fn(tabR, tabA, TRp, TAp, P)`
+   auto with_tables = [&](auto cfg, auto&& fn) {
       using C = decltype(cfg);
       constexpr int S_ = C::sch;
-      constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2, BYTES = C::bytes, DECODED = C::decoded;
+      constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2, BYTES = C::bytes;
       using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, fx_nib, uint2>::type>::type;
       const FastParams& P = BYTES ? fpb : fp;
       const uint16_t* cm = BYTES ? bmap : cmap;
@@ -385,7 +432,55 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideA : wideA) : reinterpret_cast<const TabT*>(permA));
       const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cm) + 512;
       const uint8_t* TAp = TRp + (CHAIN ? (BYTES ? b_tr : c_tr) : 0u);
-      return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered, except, emit);
+      return fn(tabR, tabA, TRp, TAp, P);
+   };
+   // ---- match compaction: this wave's queue and its flush (every lane finishes one queued row from global memory) ----------------
+   FxFwdQueue fwdq{fwd_q + (DEFERQ ? wave * 128u : 0u), 0u, 0u};
+   auto flush_fwd = [&]() {
+      if constexpr (DEFERQ) {
+         if (fwdq.n == 0u) return;
+         const bool on = lane < fwdq.n;
+         const uint32_t qrow = on ? fwdq.q[lane] : 0u, ge = on ? fwdq.q[64u + lane] : 0u;
+         const bool fam_bytes = fwdq.family != 0u;
+         fwdq.n = 0u;
+         const uint8_t* rp = rows + (int64_t)qrow * (int64_t)L;
+         uint32_t s = 0, mm = 0;
+         auto finish = [&](auto cfg) {
+            constexpr int S_ = decltype(cfg)::sch;
+            with_tables(cfg, [&](auto tabR, auto tabA, const uint8_t* TRp, const uint8_t* TAp, const FastParams& P) {
+               const uint32_t e = S_ == 0 ? (ge >> 16) * 0x01010101u : (ge >> 16);
+               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm);
+               return 0;
+            });
+         };
+         if constexpr (HAS_B) {
+            if (fam_bytes) finish(FxScanCfg<(BSCH != 0 ? BSCH : 1), true, false>{});
+            else if constexpr (!ALLB) finish(FxScanCfg<SCH, false, false>{});
+         } else finish(FxScanCfg<SCH, false, false>{});
+         if (on) {   // api_internal_m.F90:140-148 with a start inside the text (from = s - 1 >= 1)
+            const int32_t fr = (int32_t)(s - 1u), tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
+            if (out_mode == 0u || out_mode == 4u) {
+               from[qrow] = fr;
+               to[qrow] = tt;
+            } else if (out_mode == 1u) {
+               reinterpret_cast<uint8_t*>(from)[qrow] = (uint8_t)fr;
+               reinterpret_cast<uint8_t*>(to)[qrow] = (uint8_t)tt;
+            } else {
+               reinterpret_cast<uint16_t*>(from)[qrow] = (uint16_t)fr;
+               reinterpret_cast<uint16_t*>(to)[qrow] = (uint16_t)tt;
+            }
+         }
+      }
+   };
+   // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
+   auto scan = [&](auto cfg, const int64_t row, const bool row_ok, const bool ordered, bool& except) -> bool {
+      using C = decltype(cfg);
+      constexpr int S_ = C::sch;
+      constexpr bool BYTES = C::bytes, DECODED = C::decoded;
+      return with_tables(cfg, [&](auto tabR, auto tabA, const uint8_t* TRp, const uint8_t* TAp, const FastParams& P) -> bool {
+         return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered,
+                                                                                                          except, emit, &fwdq, flush_fwd);
+      });
    };
 
    // ---- the wave's loop: tiles of the batch, and -- when its queue would overflow, and at the end -- gathered tiles of exception rows
@@ -557,6 +652,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, is_tile, except);
       }
    }
+   flush_fwd();
 }
 
 // FastParams of the class-level tables (fp) and of the byte-level tables (fpb) are prepared by the host (fxamd.hip)
@@ -593,7 +689,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
-   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + (BSCH == 2 ? 4096 : 0) + 1024 + 64;
+   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + (BSCH == 2 ? 4096 : 0) + 1024 + 64 + (FX_DEFER_FWD != 0 ? 2048 : 0);
    const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;

@@ -16,7 +16,6 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../include/forgex_amd_bench.h"
 #include "compile.hpp"
 #include "program.h"
 #include "row_engine.hpp"
@@ -34,6 +33,22 @@ __device__ __forceinline__ uint32_t tile_cell(uint32_t R, uint32_t k) { return (
 typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FX_PREFETCH_DEPTH
 #define FX_PREFETCH_DEPTH 1   // tiles of global loads in flight per wave in the first pass
+#endif
+#ifndef FX_DEFER_FWD
+#define FX_DEFER_FWD 1   // match compaction in fx_search_one (fx_one.hpp): rows of SPARSE tiles that need the exact start + the forward
+                         // pass are queued per wave and finished 64 at a time
+#endif
+#ifndef FX_DEFER_LONG
+#define FX_DEFER_LONG 0  // the same in the segment-walking kernels of this file.  OFF: measured on config 3 (half of the rows match)
+                         // 0.65-0.72 ms against 0.48-0.51 ms (profiles/r03_defer_ab.txt) -- the queued rows' from / to become scattered
+                         // 4-byte stores (partial lines, written a second time next to the tile's own zeros) and their bytes are read
+                         // again from L2 / HBM; the speculative forward pass on the half row still in LDS stays.
+#endif
+#ifndef FX_FWD_GB
+#define FX_FWD_GB 2
+#endif
+#ifndef FX_HALF_WAVES
+#define FX_HALF_WAVES 3   // waves per SIMD the half-row kernel (256-byte rows, spans) is compiled for
 #endif
 #ifndef FX_LOAD_AUX
 #define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
@@ -390,6 +405,125 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
    o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
 }
 
+// ---- match compaction: one queued row per lane finished from GLOBAL memory ----------------------------------------------------------
+// Lane `on`: row bytes at rp (length L >= 8, any alignment), leftmost hit in 8-byte group g entered in reverse state e.  Re-walks the
+// group for the exact start, then walks forward from it (first window of 8*NW symbols, lookups issued 8*GB at a time, then 8 symbols per
+// round while any lane is alive).  Returns the wrapped start index s (>= 2) and max_match mm (0 = none; lit_len != 0: s + lit_len, no
+// walk).  The same arithmetic as the in-tile path (fx_scan_tile / fx_search_fast), with the row read through group_words<.., LONG>.
+template <int S_, int NW, int GB, class TabT>
+__device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ tabR, const TabT* __restrict__ tabA, const uint8_t* TRp, const uint8_t* TAp,
+                                                      const FastParams& P, const uint8_t* rp, const uint32_t L, const uint32_t lane, const bool on,
+                                                      const uint32_t g, const uint32_t e, uint32_t& s_out, uint32_t& mm_out) {
+   using F = typename FxF<S_>::type;
+   static_assert(NW % GB == 0, "window groups: a multiple of the lookup batch");
+   uint2 rw = make_uint2(0, 0);
+   uint32_t nv = 8;
+   if (on) {
+      if (g * 8u + 8u <= L) rw = *reinterpret_cast<const uint2*>(rp + g * 8u);
+      else {   // the row ends inside the group: its last 8 bytes, shifted down to the group's place (nothing behind the row is read)
+         const uint2 r = *reinterpret_cast<const uint2*>(rp + L - 8u);
+         nv = L - g * 8u;
+         const uint64_t v = (((uint64_t)r.y << 32) | r.x) >> (64u - 8u * nv);
+         rw = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+      }
+   }
+   uint32_t s;
+   {
+      F f[8];
+      lookup8(f, rw.x, rw.y, tabR);
+      uint32_t st = e, loc = 0;
+#pragma unroll
+      for (int i = 7; i >= 0; --i) {
+         const uint32_t nx = fxstep(f[i], st, TRp);
+         const bool ok = (uint32_t)i < nv;   // (per lane)
+         st = ok ? nx : st;
+         loc = ok && nx >= P.hit_min ? (uint32_t)i : loc;
+      }
+      s = g * 8u + 2u + loc;
+   }
+   s_out = s;
+   uint32_t mm = P.lit_len != 0 ? s + P.lit_len : 0u;
+   uint32_t cur = (on && P.lit_len == 0) ? P.A_init : 0u;
+   uint32_t j = s - 2u;
+   if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+      uint32_t o[2 * NW];
+      {
+         const uint32_t base = j & ~7u, sh = j & 7u;
+         uint32_t d[2 * NW + 2];
+#pragma unroll
+         for (int q = 0; q < NW + 1; ++q) group_words<false, true>(d[2 * q], d[2 * q + 1], rp, lane, base + 8u * q, L);
+         const uint32_t up = 0u - ((sh >> 2) & 1u);
+         uint32_t ee[2 * NW + 1];
+#pragma unroll
+         for (int k = 0; k < 2 * NW + 1; ++k) ee[k] = (up & d[k + 1]) | (~up & d[k]);
+#pragma unroll
+         for (int k = 0; k < 2 * NW; ++k) o[k] = __builtin_amdgcn_alignbyte(ee[k + 1], ee[k], sh & 3u);
+      }
+      uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
+#pragma unroll
+      for (int gb = 0; gb < NW; gb += GB) {
+         F f[8 * GB];
+#pragma unroll
+         for (int q = 0; q < GB; ++q) lookup8(&f[8 * q], o[2 * (gb + q)], o[2 * (gb + q) + 1], tabA);
+#pragma unroll
+         for (int q = 0; q < GB; ++q) {
+            const uint32_t entry = cur;
+            uint32_t st[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+               cur = fxstep(f[8 * q + i], cur, TAp);
+               st[i] = cur;
+            }
+            const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+            const bool hit = mx >= P.acc_min;
+            gl = hit ? (uint32_t)(gb + q) : gl;
+            el = hit ? entry : el;
+            blo = hit ? o[2 * (gb + q)] : blo;
+            bhi = hit ? o[2 * (gb + q) + 1] : bhi;
+         }
+      }
+      {
+         F fr8[8];
+         lookup8(fr8, blo, bhi, tabA);
+         uint32_t st = el, loc = 0;
+#pragma unroll
+         for (int i = 0; i < 8; ++i) {
+            st = fxstep(fr8[i], st, TAp);
+            loc = st >= P.acc_min ? (uint32_t)i : loc;
+         }
+         mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+      }
+      j += 8u * NW;
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {   // matches longer than the window: 8 symbols per round, the next group read one round ahead
+         const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
+         uint32_t gbp = j & ~7u;
+         uint32_t t0[2], t1[2];
+         group_words<false, true>(t0[0], t0[1], rp, lane, gbp, L);
+         group_words<false, true>(t1[0], t1[1], rp, lane, gbp + 8u, L);
+         do {
+            uint32_t t2[2];
+            group_words<false, true>(t2[0], t2[1], rp, lane, gbp + 16u, L);
+            const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
+            const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
+            F f8[8];
+            lookup8(f8, o0, o1, tabA);
+            uint32_t loc = 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+               cur = fxstep(f8[i], cur, TAp);
+               loc = cur >= P.acc_min ? (uint32_t)i : loc;
+            }
+            mm = loc != 8u ? j + loc + 3u : mm;
+            j += 8u;
+            gbp += 8u;
+            t0[0] = t1[0]; t0[1] = t1[1];
+            t1[0] = t2[0]; t1[1] = t2[1];
+         } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
+      }
+   }
+   mm_out = mm;
+}
+
 // ---- optional phase stamps (debug builds only: make stamp) --------------------------------------------------------------
 // -DFX_STAMP: lane 0 of every wave accumulates s_memtime deltas per phase of fx_search_fast and adds them to fx_stamp_acc[].
 #ifdef FX_STAMP
@@ -453,8 +587,13 @@ __device__ unsigned long long fx_stamp_acc[16];
 // n_deferred points at this call's two words: [0] "a first pass deferred tiles", [1] number of exception rows in `worklist`.
 // LONG: rows longer than 256 bytes (any length up to 64 KiB), CH = 16: the backward pass walks the row segment by segment through the
 // same LDS tile, the short forward pass reads its bytes straight from global memory.  First-pass and BYTES modes only.
+// (no end-of-row chunk column in LDS for the segment-walking kernels once their forward pass reads global memory only)
+template <int CH, bool SPANS, bool LONG>
+constexpr int fx_tile_cols() {
+   return (!LONG || (CH == 8 && SPANS && FX_DEFER_LONG == 0)) ? CH + 1 : CH;
+}
 template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
-__global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+__global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : 1) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
                                                         uint32_t Lr, uint32_t* __restrict__ clear_next, uint32_t* __restrict__ worklist) {
@@ -465,6 +604,12 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // segments per row, the last one shorter when Lr % SEGB != 0
    constexpr bool ragged = RAGGED;
    constexpr bool HALFROW = LONG && CH == 8;   // 256-byte rows staged as two 128-byte halves (the launcher guarantees Lr == 256)
+   // Match compaction (segment-walking kernels with spans): the exact start and the forward pass are per-ROW work that only rows with a
+   // hit need, but a wave pays for them per TILE -- at full price when one lane in 64 has a hit.  Such rows are queued (row, hit group,
+   // state entering it) in a per-wave LDS queue instead, and when 64 have gathered -- and once more at the end -- every lane takes one
+   // queued row: re-walks its hit group and walks forward, reading the row's bytes from global memory (L2: the tile was just read).
+   // The tile pass itself stores their flag (a hit inside the text always yields a span: flag 1); from / to follow at the flush.
+   constexpr bool DEFER = FX_DEFER_LONG != 0 && LONG && SPANS;
    static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 or 8, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
@@ -485,9 +630,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    __shared__ fx_nib wideR[WIDE ? 256 : 1];
    __shared__ fx_nib wideA[WIDE ? 256 : 1];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
+   __shared__ uint32_t fwd_q[DEFER ? 4 * 64 * 2 : 1];   // match compaction: per wave 64 x (row, hit group | entry state << 16)
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
-   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * (CH + 1));
+   constexpr int COLS = fx_tile_cols<CH, SPANS, LONG>();   // chunk columns per row in LDS: the row's chunks [+ the end-of-row column]
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * COLS);
    const uint32_t tr_bytes = BYTES ? h->byte_TR_bytes : h->chain_TR_bytes, ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
    const uint32_t chain_bytes = CHAIN ? ((512u + tr_bytes + ta_bytes + 15u) & ~15u) : 0u;
    const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cmap) + 512;
@@ -522,7 +669,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
    if (FIXUP && class_map_in_lds) {
-      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * (CH + 1)) + chain_bytes);
+      uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * COLS) + chain_bytes);
       const uint32_t n16 = 1024u + h->n_pages * 64u;
       for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
       __syncthreads();
@@ -534,8 +681,8 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
    const uint32_t sym_ffff = 128u + h->cls_ffff;
    // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (0xFE, whose table
    // row is all-dead), so the forward pass reads "past the end" like any other position.  Written once, never overwritten.
-   uint4* tile = tiles + wave * (64 * (CH + 1));
-   tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   uint4* tile = tiles + wave * (64 * COLS);
+   if constexpr (COLS > CH) tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
    // rows of fewer WHOLE chunks than the instantiation has: their unused chunk columns hold the inert symbol 255 from here on
    // (the staging stores never touch them; the decode passes re-pad per tile because they rewrite the cells)
    const bool whole = RAGGED && (Lr & 15u) == 0u;
@@ -565,7 +712,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) return;
       uint32_t o[8];
       fetch32<RAGGED, FG>(o, src, lane, j, Lx);
-      constexpr int GB = 4;   // 8-symbol groups whose lookups are issued together
+      constexpr int GB = (FG && DEFER) ? FX_FWD_GB : 4;   // 8-symbol groups whose lookups are issued together (fewer in the flush: registers)
       uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
       for (int gb = 0; gb < 4; gb += GB) {
@@ -630,6 +777,49 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             t0[0] = t1[0]; t0[1] = t1[1];
             t1[0] = t2[0]; t1[1] = t2[1];
          } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
+      }
+   };
+   // ---- match compaction: the per-wave queue of rows with a hit, and its flush (see DEFER above) ------------------------------------
+   uint32_t* const fq = fwd_q + (DEFER ? wave * 128u : 0u);
+   uint32_t fq_n = 0;   // entries in the queue (wave-uniform)
+   auto flush_queue = [&]() {
+      if (fq_n == 0u) return;
+      const bool on = lane < fq_n;
+      const uint32_t qrow = on ? fq[lane] : 0u, ge = on ? fq[64u + lane] : 0u;
+      fq_n = 0;
+      const uint32_t g = ge & 0xFFFFu, e = SCH == 0 ? (ge >> 16) * 0x01010101u : (ge >> 16);
+      const uint8_t* rp = rows + (int64_t)qrow * (int64_t)L;
+      // exact byte of the leftmost hit: re-walk the hit group (8 bytes of the row, from global memory; the row may end inside the group)
+      uint2 rw = make_uint2(0, 0);
+      uint32_t nv = 8;
+      if (on) {
+         if (g * 8u + 8u <= L) rw = *reinterpret_cast<const uint2*>(rp + g * 8u);
+         else {
+            const uint2 r = *reinterpret_cast<const uint2*>(rp + L - 8u);
+            nv = L - g * 8u;
+            const uint64_t v = (((uint64_t)r.y << 32) | r.x) >> (64u - 8u * nv);
+            rw = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+         }
+      }
+      F f[8];
+      lookup8(f, rw.x, rw.y, tabR);
+      uint32_t st = e, loc = 0;
+#pragma unroll
+      for (int i = 7; i >= 0; --i) {
+         const uint32_t nx = fxstep(f[i], st, TRp);
+         const bool ok = (uint32_t)i < nv;   // (per lane)
+         st = ok ? nx : st;
+         loc = ok && nx >= fp.hit_min ? (uint32_t)i : loc;
+      }
+      const uint32_t s = g * 8u + 2u + loc;   // wrapped index of the start
+      uint32_t mm = fp.lit_len != 0 ? s + fp.lit_len : 0u;
+      forward_pass(std::true_type{}, rp, (uint32_t)L, (on && fp.lit_len == 0) ? fp.A_init : 0u, mm, s - 2u);
+      if (on) {   // api_internal_m.F90:140-148 (a start inside the text: from = s - 1 >= 1)
+         const int32_t tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
+         const bool okm = mm != 0 && tt > 0;
+         from[qrow] = okm ? (int32_t)(s - 1u) : 0;
+         to[qrow] = okm ? tt : 0;
+         if (!okm) flags[qrow] = 0;   // (cannot happen: a hit at s means a non-empty match starts there)
       }
    };
    // `live`: the tile in `stage` is to be scanned (always, except in the marked-tile passes); on return it says so for t_next
@@ -781,7 +971,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
             if (seg_len == SEGB) walk(std::true_type{});
             else walk(std::false_type{});
          }
-         if constexpr (HALFROW) {
+         if constexpr (HALFROW && !DEFER) {
             // Half-row staging (two segments per row): the right half is in LDS now and will be overwritten by the left one.  A row
             // whose leftmost hit SO FAR lies here gets its exact start and -- speculatively: a hit in the left half supersedes it --
             // its forward pass now, from LDS (this half + the end-of-row column), instead of from global memory afterwards.
@@ -809,7 +999,14 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       }
       STAMP(2);
       uint32_t s = 0;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none
-      {
+      if constexpr (DEFER) {
+         // match compaction: the exact start is found at the flush; here only "a start inside the text" (2) / "at the leading NUL" (1)
+         s = gsel != 0xFFFFFFFFu ? 2u : 0u;
+         const F fz = tabR[0];   // leading NUL
+         state = fxstep(fz, state, TRp);
+         s = state >= fp.hit_min ? 1u : s;
+         if (!row_ok) s = 0;
+      } else {
          // exact byte of the leftmost hit: re-walk the selected group (every lane walks exactly one group)
          // (half-row staging: a hit group of the right half was resolved while that half was in LDS -- s_half; the re-walk here is
          //  for hit groups of the left half, which is what the tile holds now)
@@ -874,8 +1071,11 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       // The row is extended virtually: position L holds the trailing NUL (byte 0 -> F[0]), later positions kill the state;
       // an accept after consuming position `pos` gives max_match = pos + 3 for text bytes and for the trailing NUL alike.
       // (half-row staging: a start in the right half had its forward pass while that half was in LDS -- mm_half)
-      const bool fwd_here = !HALFROW || s != s_half || s == 0u;
-      uint32_t cur = (s != 0 && fwd_here && !nonascii && (SPANS || s == 1) && fp.lit_len == 0) ? fp.A_init : 0u;
+      const bool fwd_here = !HALFROW || DEFER || s != s_half || s == 0u;
+      // match compaction: rows with a start inside the text are queued (their flag is known: such a start always yields a span);
+      // only starts at the leading NUL (^-anchored patterns) walk forward here
+      const bool queued = DEFER && s >= 2u && !nonascii;
+      uint32_t cur = (s != 0 && fwd_here && !queued && !nonascii && (SPANS || s == 1) && fp.lit_len == 0) ? fp.A_init : 0u;
       uint32_t mm = (fp.lit_len != 0 && s != 0) ? s + fp.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
@@ -885,7 +1085,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       }
       STAMP(3);
       forward_pass(std::integral_constant<bool, LONG>{}, fsrc, (uint32_t)L, cur, mm, j);
-      if (HALFROW && !fwd_here && fp.lit_len == 0) mm = mm_half;
+      if (HALFROW && !DEFER && !fwd_here && fp.lit_len == 0) mm = mm_half;
       STAMP(5);
       uint32_t flag = 0;
       int32_t fr = 0, tt = 0;
@@ -900,13 +1100,27 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
       } else {
          flag = (s >= 2 || (s == 1 && mm > 2)) ? 1u : 0u;
       }
+      if (queued) flag = 1;
       if (nonascii) flag = FX_NEEDS_GENERAL;
       any_deferred = any_deferred || defer_tile;
       if (row_ok) {
          flags[row] = (uint8_t)flag;
-         if (SPANS) {
+         if (SPANS && !queued) {
             from[row] = fr;
             to[row] = tt;
+         }
+      }
+      if constexpr (DEFER) {
+         const uint64_t qm = __builtin_amdgcn_ballot_w64(queued);
+         if (qm != 0) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(qm);
+            if (fq_n + cnt > 64u) flush_queue();
+            if (queued) {
+               const uint32_t slot = fq_n + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull));
+               fq[slot] = (uint32_t)row;
+               fq[64u + slot] = gsel | ((SCH == 0 ? (esel & 0xFFu) : esel) << 16);
+            }
+            fq_n += cnt;
          }
       }
    };
@@ -940,6 +1154,7 @@ __global__ __launch_bounds__(256) void fx_search_fast(const uint8_t* __restrict_
          if (done) break;
       }
    }
+   if constexpr (DEFER) flush_queue();
    STAMP(6);
    STAMP_FLUSH;
    // one plain store per wave (not an atomic per tile: 16k same-address atomics cost ~0.2 ms); the value only gates the second pass
@@ -1197,7 +1412,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    // three with half-row staging), so that the last round fills the chip too
    // (the gated passes -- marked tiles, worklist -- usually find nothing to do: a grid of what is resident, so that an empty pass is
    //  one round of blocks that leave at once)
-   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH == 8 && Lr > 16u * CH) ? 256 * 9 : 256 * 8));
+   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH == 8 && Lr > 16u * CH) ? 256 * 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : 3) : 256 * 8));
    if (blocks > cap) blocks = cap;
    // decode passes: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
@@ -1208,6 +1423,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
                           // half-row staging of 256-byte rows), first-pass / byte-level modes only
       if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 0)) {
          constexpr int CHN = SCH;
+         const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds;
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false, true>)
                                 : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {

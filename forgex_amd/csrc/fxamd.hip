@@ -13,6 +13,7 @@
 //                        rows the fast kernel flags as non-ASCII.
 #include <functional>
 
+#include "../../include/forgex_amd_bench.h"
 #include "fx_multi.hpp"
 
 #ifndef FX_SINGLE_TU   // the launcher instantiations live in fx_tile_inst.hip (one object per chunk count)
@@ -481,7 +482,9 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
 }
 
 static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if ((reinterpret_cast<uintptr_t>(d_rows) & 15u) != 0) return false;
+   // (any base address: a tile is addressed through a buffer resource whose base is the tile's first byte, so a batch that does not
+   //  start at a 16-byte multiple only turns the tile loads into unaligned ones -- it used to fall to the general kernel, 20x slower)
+   (void)d_rows;
    if (long_row(row_len)) return true;
    if (row_len < 2 || row_len > 256) return false;   // (any length in between: rows that are not whole chunks are padded in LDS;
                                                       //  a one-byte row can be the single blank of api_internal_m.F90:68-74)
@@ -491,6 +494,7 @@ static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
 // class-level table scheme for these rows: -1 = tile kernel not applicable, 0 = v_perm (<= 8 states), 2 = wide v_perm (<= 16),
 // 1 = chain (tables must fit the CU's LDS next to the tiles)   [the numbers are the kernels' SCH template argument]
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+   if (std::getenv("FXAMD_FORCE_GENERAL")) return -1;   // test hook: the general kernel (one lane per row) for everything
    if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return -1;
    if (h.flags & FXP_F_FAST_OK) return 0;
    if ((h.flags & FXP_F_W16_OK) && !std::getenv("FXAMD_NO_W16")) return 2;
@@ -1473,6 +1477,21 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
    }
    if (registered) (void)hipHostUnregister(const_cast<uint8_t*>(h_rows));
    return rc;
+}
+
+// ---- caller-pinned host buffers --------------------------------------------------------------------------------------------------
+// fxamd_match_batch_host copies the caller's rows with hipMemcpyAsync: from PAGEABLE memory the runtime stages them through its own
+// pinned bounce buffers (one more CPU copy, and the call is not asynchronous), from pinned memory the DMA engine reads them in place.
+// A caller that keeps a large batch in one array pins it once with these (the array stays usable as before).
+int fxamd_host_register(void* p, int64_t bytes) {
+   if (!p || bytes <= 0) return FXAMD_E_ARG;
+   FX_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+   return FXAMD_OK;
+}
+int fxamd_host_unregister(void* p) {
+   if (!p) return FXAMD_E_ARG;
+   FX_HIP(hipHostUnregister(p));
+   return FXAMD_OK;
 }
 
 // ---- subroutine forms for Fortran `pure` hosts ---------------------------------------------------------------------------------

@@ -86,8 +86,8 @@ int fxamd_program_reserve(fxamd_program* p, int64_t max_rows, void* hip_stream);
  * DEVICE pointers; the work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and is
  * asynchronous.  `.in.`: flags = verdict, from/to = 1-based byte span of regex() (0,0 when none).
  * `.match.`: flags = verdict, from/to untouched.  Invalid pattern: all flags 0, from/to 0.
- * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2 bytes .. 64 KiB when
- * d_rows is 16-byte aligned, other shapes run on the general kernel (one lane per row, roughly 20x slower).  The handle keeps its
+ * Any n, row_len and alignment give the same (reference-exact) results; the tile kernels take rows of 2 bytes .. 64 KiB at any base
+ * address (16-byte aligned batches load fastest), other shapes run on the general kernel (one lane per row, roughly 20x slower).  The handle keeps its
  * uploaded tables per device and its scratch per (device, stream): the call works on whatever device is current, and calls on
  * one handle may overlap on the device when they use different streams.  n is not limited by the 32-bit row numbers of the kernels'
  * work lists: a batch of more than 2^30 rows is enqueued in slices of that many rows on the same stream. */
@@ -123,6 +123,13 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
 int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags,
                            int32_t* h_from, int32_t* h_to);
 
+/* Pin / unpin a caller's host array in place (hipHostRegister): fxamd_match_batch_host then reads the rows by DMA straight from the
+ * caller's memory instead of staging pageable memory through the runtime's bounce buffers.  For callers that keep a large batch in
+ * one array and match it repeatedly (or once, when the array is large: pinning costs about as much as one pass over pageable memory).
+ * The array stays usable as before; unregister before freeing it. */
+int fxamd_host_register(void* p, int64_t bytes);
+int fxamd_host_unregister(void* p);
+
 /* Subroutine forms of four entries above for Fortran `pure` hosts (forgex_amd/fortran/forgex.F90 binds these): a PURE FUNCTION may
  * only have INTENT(IN) / VALUE dummies (F2018 C1590; gfortran rejects the function forms in a pure interface) and a compiler may
  * merge or drop pure-function calls, so every output -- the return code included -- is a pointer argument here.  Same semantics. */
@@ -141,7 +148,8 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * 11 = byte-level tables on every tile (12 / 13 / 14: the same with the general row procedure for queued rows).
  * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
  * one-launch kernel over the tiles that pass left.
- * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE.) */
+ * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
+ * FXAMD_FORCE_GENERAL.) */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);

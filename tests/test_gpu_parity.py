@@ -87,23 +87,37 @@ def test_config_rows_vs_oracle(fx, cfg, n):
         assert prog.last_path() in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16)   # tile kernels (9-11: the one-launch kernel)
 
 
-def test_fast_and_general_kernels_agree(fx):
-    """The same rows through the fast kernel (aligned [n,256]) and through the general kernel (a misaligned base address forces it)."""
+def test_fast_and_general_kernels_agree(fx, monkeypatch):
+    """The same rows through the tile kernels (aligned and MISALIGNED base address: unaligned tile loads, same kernels) and through
+    the general kernel (one lane per row; FXAMD_FORCE_GENERAL is the only way left to reach it with a supported pattern)."""
     import torch
     from forgex_amd import synth
-    rows = synth.batch("cfg3", 5000, 8192, torch.device("cuda"))
-    pat = synth.PATTERNS["cfg3"]
-    p = fx.Program(pat, fx.OP_SEARCH)
-    f1, a1, b1 = p.match_device(rows)
-    assert p.last_path() in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16)
-    # the same rows at a base address that is not 16-byte aligned: the tile kernels decline, the general kernel takes them
-    buf = torch.empty(rows.numel() + 1, dtype=torch.uint8, device=rows.device)
-    wide = buf[1:].view(rows.shape)
-    wide.copy_(rows)
-    f2, a2, b2 = p.match_device(wide)
-    assert p.last_path() == 2
-    torch.cuda.synchronize()
-    assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2)
+    for cfg, n in (("cfg3", 8192), ("cfg2", 4096), ("cfg4", 2048), ("cfg5", 4096)):
+        rows = synth.batch(cfg, 5000, n, torch.device("cuda"))
+        pat = synth.PATTERNS[cfg]
+        p = fx.Program(pat, fx.OP_SEARCH)
+        f1, a1, b1 = p.match_device(rows)
+        tile_path = p.last_path()
+        assert tile_path in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16)
+        for off in (1, 4, 7):   # base addresses that are not 16-byte aligned: still the tile kernels
+            buf = torch.empty(rows.numel() + 16, dtype=torch.uint8, device=rows.device)
+            wide = buf[off:off + rows.numel()].view(rows.shape)
+            wide.copy_(rows)
+            f2, a2, b2 = p.match_device(wide)
+            assert p.last_path() == tile_path, (cfg, off, p.last_path())
+            torch.cuda.synchronize()
+            assert torch.equal(f1, f2) and torch.equal(a1, a2) and torch.equal(b1, b2), (cfg, off)
+            m = fx.Program(pat, fx.OP_MATCH)
+            g1 = m.match_device(rows, spans=False)[0]
+            g2 = m.match_device(wide, spans=False)[0]
+            torch.cuda.synchronize()
+            assert torch.equal(g1, g2), (cfg, off)
+        monkeypatch.setenv("FXAMD_FORCE_GENERAL", "1")
+        f3, a3, b3 = p.match_device(rows)
+        assert p.last_path() == 2
+        monkeypatch.delenv("FXAMD_FORCE_GENERAL")
+        torch.cuda.synchronize()
+        assert torch.equal(f1, f3) and torch.equal(a1, a3) and torch.equal(b1, b3), cfg
 
 
 def test_non_ascii_rows_take_the_fixup_pass(fx):

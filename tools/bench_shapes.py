@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""The workloads behind DESIGN.md 4.1d's table other than the four `.in.` configs bench.py covers: `.match.`, rows longer than
+256 bytes, literal search, many patterns in one pass, packed results -- one named SHAPE per run, so that the same command can sit
+behind `rocprofv3 --kernel-trace --stats` / `--pmc` (tools/profile_shapes.sh) and every row of that table has a kernel trace and
+PMC traffic under profiles/.
+
+    python tools/bench_shapes.py --shape match_cfg3 [--steps 50 --warmup 20]
+    python tools/bench_shapes.py --list
+
+One JSON line: step time (HIP events over the timed steps), input GB/s, algorithmic bytes per step (rows * (row_len + out bytes
+per row)) and the fraction of the 8 TB/s HBM peak they amount to, last_path.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# name -> (description, op, patterns, source config, row_len view (None = the config's), rows, packed, spans)
+SHAPES = {
+    "match_cfg3":   ("`.match.` `[a-z ]+\\d*[a-z ]*` over config-3 rows (8-state tables, one verdict byte per row)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg3", None, 10_000_000, False, False),
+    "match_cfg1x":  ("`.match.` `\\d{3}-\\d{4}` (config 1's pattern, nibble tables) over 64M x 8 B rows of config 1's generator", "match", [r"\d{3}-\d{4}"], "cfg1", None, 64_000_000, False, False),
+    "match_utf8":   ("`.match.` `[α-ωぁ-ん ]+` over config-4 rows (byte-level tables)", "match", ["[α-ωぁ-ん ]+"], "cfg4", None, 1 << 20, False, False),
+    "long_1024":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as 2.5M x 1024 B rows", "search", [r"[a-z]+\d+"], "cfg3", 1024, 2_500_000, False, True),
+    "long_4096":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as 625k x 4096 B rows", "search", [r"[a-z]+\d+"], "cfg3", 4096, 625_000, False, True),
+    "long_400":     ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as 6.4M x 400 B rows (not a multiple of 16)", "search", [r"[a-z]+\d+"], "cfg3", 400, 6_400_000, False, True),
+    "nibble_cfg3":  ("`\\d{3}-\\d{4}` `.in.` + spans over config-3 rows (9..16 states: nibble tables)", "search", [r"\d{3}-\d{4}"], "cfg3", None, 10_000_000, False, True),
+    "chain_cfg3":   ("an e-mail pattern `.in.` + spans over config-3 rows (> 16 states: chain tables)", "search", [r"[a-z0-9]+@[a-z0-9]+\.[a-z]{2,4}"], "cfg3", None, 10_000_000, False, True),
+    "literal_cfg2": ("literal `foobar` `.in.` + spans over 16M x 64 B rows of config 2's generator (raw-byte INDEX on the tile kernel)", "search", ["foobar"], "cfg2", None, 16 << 20, False, True),
+    "multi6_cfg3":  ("six 8-state patterns over config-3 rows in ONE pass (fx_search_multi)", "search",
+                     [r"[a-z]+\d+", r"\d+[a-z]", r"[a-z]+ \d", r"q[a-z]*\d", r"\d\d+", r"[a-z]\d[a-z]"], "cfg3", None, 10_000_000, False, True),
+    "packed_cfg5":  ("config 5's shard with PACKED results (1 bit + 2 x uint8 per row, written by the search kernel)", "search", [r"[a-z]+\d+"], "cfg5", None, 12_500_000, True, True),
+    "packed_cfg3":  ("config 3 with PACKED results (half-row pipeline + fx_pack)", "search", [r"[a-z]+\d+"], "cfg3", None, 10_000_000, True, True),
+    "ragged_255":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 255 B (ragged loader)", "search", [r"[a-z]+\d+"], "cfg3", 255, 10_000_000, False, True),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="match_cfg3")
+    ap.add_argument("--list", action="store_true")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    args = ap.parse_args()
+    if args.list:
+        for k, v in SHAPES.items():
+            print("%-14s %s" % (k, v[0]))
+        return
+    desc, op, pats, cfg, view, n, packed, spans = SHAPES[args.shape]
+    import torch
+    import forgex_amd
+    from forgex_amd import synth
+    dev = torch.device("cuda", 0)
+    _, L0 = synth.SHAPES[cfg]
+    if view is None:
+        L = L0
+        rows = synth.batch(cfg, 0, n, dev)
+    else:
+        L = view
+        n0 = (n * L + L0 - 1) // L0
+        flat = synth.batch(cfg, 0, n0, dev).reshape(-1)
+        rows = flat[: n * L].reshape(n, L)
+    opc = forgex_amd.OP_MATCH if op == "match" else forgex_amd.OP_SEARCH
+    progs = [forgex_amd.Program(p, opc) for p in pats]
+    assert all(p.status == 0 for p in progs)
+    m = len(progs)
+    if m > 1:
+        def step():
+            return forgex_amd.match_many(progs, rows, spans=spans)
+        out_bytes = m * (9 if spans else 1)
+    elif packed:
+        buf = progs[0].match_device_packed(rows, spans=spans)
+
+        def step():
+            return progs[0].match_device_packed(rows, spans=spans, out=buf)
+        w = forgex_amd.packed_layout(n, L, spans)[3]
+        out_bytes = 0.125 + 2 * w
+    else:
+        flags = torch.empty(n, dtype=torch.uint8, device=dev)
+        frm = torch.empty(n, dtype=torch.int32, device=dev) if spans else None
+        to = torch.empty(n, dtype=torch.int32, device=dev) if spans else None
+
+        def step():
+            return progs[0].match_device(rows, spans=spans, out=(flags, frm, to))
+        out_bytes = 9 if spans else 1
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.steps):
+        res = step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / args.steps
+    if m > 1:
+        matches = int((res[0] != 0).sum().item())
+    elif packed:
+        matches = None
+    else:
+        matches = int((flags != 0).sum().item())
+    alg = n * (L + out_bytes)
+    print(json.dumps({"shape": args.shape, "what": desc, "rows": n, "row_len": L, "patterns": pats, "op": op, "ms_per_step": ms,
+                      "input_gbs": n * L / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_step": alg,
+                      "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / 8000.0, "last_path": [p.last_path() for p in progs], "matches": matches,
+                      "steps": args.steps, "warmup": args.warmup}))
+
+
+if __name__ == "__main__":
+    main()
