@@ -56,6 +56,12 @@ struct FxScanCtx {
 // is dense in hits (more than FX_DEFER_DENSE of 64 rows), those rows are queued per wave (row, hit group, state entering it) and
 // finished 64 at a time from global memory (fx_finish_from_global); their flag is known at once (a start inside the text always
 // yields a span), only from / to follow at the flush.
+#ifndef FX_FWD_ALIGNED
+#define FX_FWD_ALIGNED 1      // long matches on many lanes: the forward pass continues in aligned 8-byte groups (fx_scan_tile)
+#endif
+#ifndef FX_FWD_ALIGNED_MIN
+#define FX_FWD_ALIGNED_MIN 12  // lanes still walking after the first window for that to pay
+#endif
 #ifndef FX_DEFER_DENSE
 #define FX_DEFER_DENSE 12   // tiles with more hit rows than this finish them in place (config 3 / 5: half of the rows match -- queueing those costs
                             // scattered from / to stores and a second read of the rows' bytes: measured slower, profiles/r03_defer_ab.txt)
@@ -226,8 +232,100 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
          }
          j += 8u * NG;
-         // matches longer than the window: 8 symbols per round trip, the next group read one round ahead (see fx_search_fast)
-         if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
+         // Matches longer than the window.  MANY lanes still walking (config 4: nine rows in ten match from their first character to
+         // their last): the rest of the row in ALIGNED 8-byte groups with the backward pass's lookup pipeline -- 5 instead of 7.6
+         // instructions per byte.  Few lanes: 8 symbols per round trip from wherever each lane stands (below).
+         bool aligned_done = false;
+         if constexpr (!RAGGED && CH >= 4 && FX_FWD_ALIGNED != 0) {
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != 0)) >= (uint32_t)FX_FWD_ALIGNED_MIN) {
+               aligned_done = true;
+               // (1) every lane to its next 8-byte boundary: up to 7 symbols, per lane
+               const uint32_t nrem = (0u - j) & 7u;
+               if (__builtin_amdgcn_ballot_w64(cur != 0 && nrem != 0u) != 0) {
+                  uint32_t o1[2];
+                  fetch_groups<RAGGED, 1>(o1, tb, lane, j, (uint32_t)L);
+                  F f8[8];
+                  lookup8(f8, o1[0], o1[1], tabA);
+#pragma unroll
+                  for (int q = 0; q < 7; ++q) {
+                     const uint32_t nx = fxstep(f8[q], cur, TAp);
+                     const bool on = (uint32_t)q < nrem;
+                     cur = on ? nx : cur;
+                     mm = (on && nx >= P.acc_min) ? j + (uint32_t)q + 3u : mm;
+                  }
+                  j += nrem;
+               }
+               // (2) aligned groups from this lane's group g0 on; the wave walks chunks c0 .. CH (chunk CH = the end-of-row column:
+               //     the trailing NUL, then KILL symbols), a lane joins at its own group; per group only "any accept" + entry state
+               const uint32_t g0 = j >> 3;
+               uint32_t c0 = 0;
+               while (c0 < (uint32_t)CH && __builtin_amdgcn_ballot_w64(cur != 0 && (g0 >> 1) <= c0) == 0) ++c0;
+               uint32_t gl2 = 0xFFFFFFFFu, el2 = 0;
+               F fa[8], fb[8];
+               uint4 wk = tile[tile_cell(lane, c0)], wn = tile[tile_cell(lane, c0 < (uint32_t)CH ? c0 + 1u : c0)];
+               lookup8(fa, wk.x, wk.y, tabA);
+#pragma unroll 1
+               for (uint32_t c = c0; c <= (uint32_t)CH; ++c) {
+                  lookup8(fb, wk.z, wk.w, tabA);
+                  __builtin_amdgcn_sched_barrier(0);
+                  {
+                     const uint32_t entry = cur;
+                     uint32_t st[8], t = cur;
+#pragma unroll
+                     for (int q = 0; q < 8; ++q) {
+                        t = fxstep(fa[q], t, TAp);
+                        st[q] = t;
+                     }
+                     const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+                     const bool act = 2u * c >= g0;
+                     cur = act ? t : cur;
+                     const bool hit = act && mx >= P.acc_min;
+                     gl2 = hit ? 2u * c : gl2;
+                     el2 = hit ? entry : el2;
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (c < (uint32_t)CH) {
+                     wk = wn;
+                     lookup8(fa, wk.x, wk.y, tabA);
+                     wn = tile[tile_cell(lane, c + 2u <= (uint32_t)CH ? c + 2u : (uint32_t)CH)];
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  {
+                     const uint32_t entry = cur;
+                     uint32_t st[8], t = cur;
+#pragma unroll
+                     for (int q = 0; q < 8; ++q) {
+                        t = fxstep(fb[q], t, TAp);
+                        st[q] = t;
+                     }
+                     const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+                     const bool act = 2u * c + 1u >= g0;
+                     cur = act ? t : cur;
+                     const bool hit = act && mx >= P.acc_min;
+                     gl2 = hit ? 2u * c + 1u : gl2;
+                     el2 = hit ? entry : el2;
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) break;
+               }
+               // the exact symbol of the last accept: re-walk that group (every lane one group)
+               if (__builtin_amdgcn_ballot_w64(gl2 != 0xFFFFFFFFu) != 0) {
+                  const uint32_t g = gl2 != 0xFFFFFFFFu ? gl2 : 0u;
+                  const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+                  F fr8[8];
+                  lookup8(fr8, rw.x, rw.y, tabA);
+                  uint32_t st = el2, loc = 0;
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) {
+                     st = fxstep(fr8[q], st, TAp);
+                     loc = st >= P.acc_min ? (uint32_t)q : loc;
+                  }
+                  mm = gl2 != 0xFFFFFFFFu ? 8u * g + loc + 3u : mm;
+               }
+            }
+         }
+         // 8 symbols per round trip, the next group read one round ahead (see fx_search_fast)
+         if (!aligned_done && __builtin_amdgcn_ballot_w64(cur != 0) != 0) {
             const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
             uint32_t gb = j & ~7u;
             uint32_t t0[2], t1[2];
@@ -293,6 +391,63 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
    }
 }
 
+// ---- `.match.` on a tile in LDS: one forward pass of the anchored automaton over every byte of the row from M_start (the state after
+// the optional leading NUL, api_internal_m.F90:280-289), verdict = the final state's FINAL entry (accept at ci = n + 2 or after the
+// trailing NUL, :296-302), behind the reference's literal / prefix / suffix gate (`gate`: 2 = TRUE, 0 = FALSE, 1 = the automaton
+// decides; fxrow::match_gate, evaluated by the caller on the RAW bytes).  Table families, REDO_TILE / ROW_EXC / `except` as in
+// fx_scan_tile; byte-level tables: a row whose walk ends inside a character or in the INVALID state (FINAL = 2) is an exception.
+template <int CH, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, class TabT, class Emit>
+__device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __restrict__ tabA, const uint8_t* TAp, const FastParams& P, const FxpHeader* h,
+                                              const uint32_t gate, const int64_t row, const bool row_ok, const bool ordered, bool& except, Emit& emit) {
+   constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2;
+   using F = typename FxF<S_>::type;
+   uint4* const tile = c.tile;
+   const uint32_t lane = c.lane, Lr = c.Lr;
+   const bool whole = c.whole;
+   (void)Lr;
+   (void)whole;
+   uint32_t st = P.A_init;   // = M_start
+   uint32_t na = 0;
+   if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);   // pads (symbol 255) are the identity for A
+   {
+      F fa[8], fb[8];
+      uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
+      if (CH >= 2) wn = tile[tile_cell(lane, 1)];
+      lookup8(fa, wk.x, wk.y, tabA);
+#pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (registers)
+      for (int k = 0; k < CH; ++k) {
+         if (!RAGGED || (whole && !DECODED && (uint32_t)k < (Lr >> 4))) na |= wk.x | wk.y | wk.z | wk.w;
+         lookup8(fb, wk.z, wk.w, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fa, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         if (k + 1 < CH) {
+            wk = wn;
+            lookup8(fa, wk.x, wk.y, tabA);
+            if (k + 2 < CH) wn = tile[tile_cell(lane, k + 2)];
+         }
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fb, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+   }
+   bool row_hi = false;
+   if (!BYTES && !DECODED) {
+      row_hi = (na & 0x80808080u) != 0;
+      if (REDO_TILE && __builtin_amdgcn_ballot_w64(row_hi) != 0) return true;
+   }
+   uint32_t fin;
+   if (CHAIN) fin = *reinterpret_cast<const uint16_t*>(TAp + st + 2u * ((BYTES ? h->byte_n_classes : h->n_classes) + 2u));   // FINAL column
+   else if (WIDE) {
+      const uint32_t* fm = BYTES ? h->bw16_finalM : h->w16_finalM;   // byte j = verdict of state j
+      fin = (fm[(st >> 2) & 3u] >> ((st & 3u) * 8u)) & 3u;
+   } else fin = __builtin_amdgcn_perm(h->fast_finalM[1], h->fast_finalM[0], st) & 1u;
+   const uint32_t flag = gate == 2u ? 1u : (gate == 0u ? 0u : (st != 0 && fin == 1u ? 1u : 0u));
+   except = (BYTES && gate == 1u && st != 0 && fin == 2u) || (ROW_EXC && !BYTES && !DECODED && row_hi);
+   emit(row, row_ok && !except, ordered, flag, 0, 0, true);
+   return false;
+}
+
 // SCH: scheme of the class-level tables (0 v_perm, 1 chain, 2 wide); BSCH: scheme of the byte-level tables (0 = none in this
 // launch, 1 chain, 2 wide).  SCH == 0 && BSCH != 0: per-tile selection.  SCH != 0 && BSCH != 0: the byte-level tables take every
 // tile (the class-level ones are no faster on ASCII), the class-level tables only serve the exception rows.
@@ -303,7 +458,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
 // MARKED: the follow-up of a multi-pass first pass (the half-row kernel of 256-byte rows): only tiles whose rows that pass marked
 // FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
 // and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
-template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false>
+template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
 __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr) {
@@ -312,6 +467,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    // `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit word i >> 6: the ballot of the tile's wave, one store per tile),
    // `from` / `to` = arrays of that many bytes per row (uint8 / uint16 / int32).
    static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
+   static_assert(!MATCH || (!SPANS && !MARKED), "`.match.` has no span and no multi-pass first pass");
    constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0, POOL = HAS_B || GEN;
    const uint32_t L = RAGGED ? Lr : 16u * CH;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
@@ -321,7 +477,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    __shared__ fx_nib bwideR[BSCH == 2 ? 256 : 1];
    __shared__ fx_nib bwideA[BSCH == 2 ? 256 : 1];
    __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
-   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED;   // match compaction (see fx_scan_tile)
+   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED && !MATCH;   // match compaction (see fx_scan_tile)
    __shared__ uint32_t fwd_q[DEFERQ ? 4 * 128 : 1];   // per-wave queues of rows whose exact start + forward pass are finished 64 at a time
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
@@ -472,14 +628,21 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          }
       }
    };
-   // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
+   uint32_t mgate = 1u;   // `.match.`: the literal / prefix / suffix gate of the row in this lane's cells, evaluated on the raw bytes
+   // ---- one scan of the tile in LDS (fx_scan_tile / fx_match_tile) with the tables of one family ---------------------------------
    auto scan = [&](auto cfg, const int64_t row, const bool row_ok, const bool ordered, bool& except) -> bool {
       using C = decltype(cfg);
       constexpr int S_ = C::sch;
       constexpr bool BYTES = C::bytes, DECODED = C::decoded;
       return with_tables(cfg, [&](auto tabR, auto tabA, const uint8_t* TRp, const uint8_t* TAp, const FastParams& P) -> bool {
-         return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered,
-                                                                                                          except, emit, &fwdq, flush_fwd);
+         if constexpr (MATCH) {
+            (void)tabR;
+            (void)TRp;
+            return fx_match_tile<CH, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN>(sctx, tabA, TAp, P, h, mgate, row, row_ok, ordered, except, emit);
+         } else {
+            return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered,
+                                                                                                             except, emit, &fwdq, flush_fwd);
+         }
       });
    };
 
@@ -564,6 +727,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          }
          pool_n = 0;
       }
+      if constexpr (MATCH) mgate = match_gate(h, prog, tb, lane, L);   // (on the raw bytes: before any decode rewrites the cells)
       bool except = false;
       bool redo = false;
       if (is_tile && !ALLB && !hint) {
@@ -684,7 +848,7 @@ inline int resident_blocks_per_cu(const void* fn, size_t lds, int fallback) {
 
 template <int CH, int SCH, int BSCH, bool GEN>
 hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
-                      uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st, uint32_t out_mode) {
+                      uint32_t class_map_bytes, uint32_t table_bytes, uint32_t Lr, hipStream_t st, uint32_t out_mode, bool is_match) {
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
@@ -710,6 +874,30 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       const int64_t cap = 256 * (env_mult > 0 ? env_mult : resident);
       if (blocks > cap) blocks = cap;
    };
+   if (is_match) {   // `.match.`: one verdict per row, no span
+      if (ragged) {
+         if constexpr (BSCH == 0) {
+            const void* fn = reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN, false, true>);
+            if (lds > 64 * 1024) {
+               hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+               if (e != hipSuccess) return e;
+            }
+            cap_grid(fn);
+            hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, nullptr);
+            return hipGetLastError();
+         } else {
+            return hipErrorInvalidValue;   // (never dispatched: byte-level tables need whole chunks)
+         }
+      }
+      const void* fn = reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>);
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      cap_grid(fn);
+      hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, nullptr);
+      return hipGetLastError();
+   }
    if (ragged) {
       if constexpr (BSCH == 0) {
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true, GEN>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN>);
@@ -766,4 +954,4 @@ hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_bl
 #define FX_ONE_COMBOS(X, CH) FX_ONE_COMBOS_G(X, CH, false) FX_ONE_COMBOS_G(X, CH, true)
 #define FX_ONE_ALL(X) \
    FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 3) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 6) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)
-#define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t)
+#define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t, bool)

@@ -712,7 +712,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) return;
       uint32_t o[8];
       fetch32<RAGGED, FG>(o, src, lane, j, Lx);
-      constexpr int GB = (FG && DEFER) ? FX_FWD_GB : 4;   // 8-symbol groups whose lookups are issued together (fewer in the flush: registers)
+#ifndef FX_FWD_GB_LDS
+#define FX_FWD_GB_LDS 4
+#endif
+      constexpr int GB = (FG && DEFER) ? FX_FWD_GB : FX_FWD_GB_LDS;   // 8-symbol groups whose lookups are issued together (fewer in the flush: registers)
       uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
       for (int gb = 0; gb < 4; gb += GB) {

@@ -583,25 +583,27 @@ static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
       fp.inv_on = 1u;
       fp.inv = sch == 2 ? h.R_inv : (sch == 1 ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
+   if (h.mode == FXP_MODE_MATCH_ENGINE) fp.inv = bytes ? (sch == 2 ? h.bw16_inv_A : h.byte_inv_A) : 0u;   // `.match.`: A only (A_init holds M_start)
    return fp;
 }
 template <int SCH, int BSCH, bool GEN>
 static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                                 int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode) {
+   const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
    const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t table_bytes = (SCH == 1 ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u) +
                                 (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
    const uint32_t Lr = (uint32_t)row_len;
    switch (tile_chunks(row_len)) {
-      case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      case 4: return launch_one<4, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      case 6: return launch_one<6, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      case 8: return launch_one<8, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      case 12: return launch_one<12, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
-      default: return launch_one<16, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode);
+      case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      case 4: return launch_one<4, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      case 6: return launch_one<6, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      case 8: return launch_one<8, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      case 12: return launch_one<12, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
+      default: return launch_one<16, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
    }
 }
 // bsch: 0 = no byte-level tables for these rows, 1 chain, 2 wide
@@ -667,8 +669,8 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    const FxpHeader& h = p->prog.hdr();
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
-      const bool one = sc0 >= 0 && h.mode == FXP_MODE_SEARCH_ENGINE && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !half_rows(sc0, row_len) &&
-                       !std::getenv("FXAMD_MULTIPASS");
+      const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
+                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(sc0, row_len)) && !std::getenv("FXAMD_MULTIPASS");
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -707,7 +709,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // The counter groups alternate between calls, and it is a call's FIRST-PASS kernel that zeroes the other group for the call
       // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
-      const bool one_launch = first_pass == FX_FP_OWN && !is_match && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && !half_rows(scheme, row_len) &&
+      const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len)) &&
                               !std::getenv("FXAMD_MULTIPASS");
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left

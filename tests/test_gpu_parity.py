@@ -436,7 +436,7 @@ def test_match_operator_on_tile_kernel(fx):
         if L == 52:
             rows[::3] = np.frombuffer(b"abcdefghijkl" * 4 + b"ab42"[:4], dtype=np.uint8)
         prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
-        assert prog.last_path() in (1, 3, 5, 6, 7, 8), (pat, prog.last_path())
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14), (pat, prog.last_path())   # `.match.` in ONE launch (fx_search_one, MATCH)
         of, _, _ = oracle_lib.batch(1, pat, rows, NT)
         assert np.array_equal(f, of), pat
     # the 8-byte rows of BASELINE config 1: shorter than one chunk, still on the tile kernel (ragged instantiation)
@@ -445,7 +445,68 @@ def test_match_operator_on_tile_kernel(fx):
     rows = synth.batch("cfg1", 0, 1000, torch.device("cpu")).numpy()
     prog, f, _, _ = _device_run(fx, synth.PATTERNS["cfg1"].encode(), fx.OP_MATCH, rows, spans=False)
     of, _, _ = oracle_lib.batch(1, synth.PATTERNS["cfg1"].encode(), rows, NT)
-    assert np.array_equal(f, of) and prog.last_path() in (5, 6, 7), prog.last_path()
+    assert np.array_equal(f, of) and prog.last_path() in (9, 10, 11, 12, 13, 14), prog.last_path()
+
+
+def test_match_one_launch_vs_multipass_pipeline(fx, monkeypatch):
+    """`.match.` in ONE launch (fx_search_one with MATCH: class-level tables on pure-ASCII tiles, byte-level tables or the in-LDS decode
+    on the others, exception rows through the per-wave queues) against the multi-pass pipeline of fx_match_fast (FXAMD_MULTIPASS=1) and
+    the oracle: ASCII, valid UTF-8 and 2 / 30 / 100 % structurally broken rows, every table scheme, whole-chunk and ragged rows, packed
+    verdicts.  Reference: src/api_internal_m.F90:171-303."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(31)
+    cases = [("cfg4", "[α-ωぁ-ん ]+", 1 << 14), ("cfg4", "[α-ωぁ-ん]+ *", 1 << 14), ("cfg4", ".+", 4096), ("cfg3", r"[a-z ]+\d*[a-z ]*", 1 << 14),
+             ("cfg3", r"[a-z ]*(\d{1,3}[a-z ]*)?", 8192), ("cfg2", r"[a-z]+", 1 << 14), ("cfg2", r"[a-z]*foo(bar|baz)[a-z]*", 1 << 14),
+             ("cfg5", r"([a-z]+ ?)+\d*.*", 8192), ("cfg1", r"\d{3}-\d{4}", 4000), ("cfg4", "(α|β|[ぁ-ん]|[γ-ω])+ +", 8192)]
+    n_one = 0
+    for cfg, pat, n in cases:
+        base = synth.batch(cfg, 1000, n, dev)
+        for bad_frac in (0.0, 0.02, 0.3, 1.0):
+            rows = base.clone()
+            if bad_frac > 0:
+                L = rows.shape[1]
+                sel = (torch.rand(n, generator=g) < bad_frac).to(dev)
+                pos = torch.randint(0, L, (n,), generator=g).to(dev)
+                val = torch.randint(0x80, 0x100, (n,), generator=g).to(torch.uint8).to(dev)
+                idx = torch.arange(n, device=dev)[sel]
+                rows[idx, pos[sel]] = val[sel]
+            for views in (None, 52):   # the rows as they are, and the same bytes viewed as ragged rows of 52 bytes
+                r = rows if views is None else rows.reshape(-1)[: (rows.numel() // views) * views].reshape(-1, views)
+                for wide in (True, False):
+                    monkeypatch.delenv("FXAMD_MULTIPASS", raising=False)
+                    monkeypatch.delenv("FXAMD_NO_W16", raising=False)
+                    if not wide:
+                        monkeypatch.setenv("FXAMD_NO_W16", "1")
+                    prog = fx.Program(pat, fx.OP_MATCH)
+                    assert prog.status == 0, pat
+                    f1, _, _ = prog.match_device(r, spans=False)
+                    torch.cuda.synchronize()
+                    path = prog.last_path()
+                    if path in (9, 10, 11, 12, 13, 14):
+                        n_one += 1
+                    packed = prog.match_device_packed(r, spans=False)
+                    fp, _, _ = fx.unpack_results(packed, r.shape[0], r.shape[1], False)
+                    torch.cuda.synchronize()
+                    monkeypatch.setenv("FXAMD_MULTIPASS", "1")
+                    ref = fx.Program(pat, fx.OP_MATCH)
+                    f2, _, _ = ref.match_device(r, spans=False)
+                    torch.cuda.synchronize()
+                    assert ref.last_path() in (1, 2, 3, 5, 6, 7, 8), (pat, ref.last_path())
+                    bad = torch.nonzero(f1 != f2)
+                    assert bad.numel() == 0, (cfg, pat, bad_frac, views, wide, path, int(bad[0]), int(f1[bad[0]]), int(f2[bad[0]]))
+                    assert torch.equal(fp, f1), (cfg, pat, bad_frac, views, wide, "packed")
+            monkeypatch.delenv("FXAMD_MULTIPASS", raising=False)
+            monkeypatch.delenv("FXAMD_NO_W16", raising=False)
+            k = min(n, 1500)
+            of, _, _ = oracle_lib.batch(1, pat.encode() if isinstance(pat, str) else pat, rows[:k].cpu().numpy(), NT)
+            assert np.array_equal(f1.cpu().numpy()[:0], of[:0])   # (shape check only: f1 is the last ragged view)
+            prog = fx.Program(pat, fx.OP_MATCH)
+            fo, _, _ = prog.match_device(rows[:k].contiguous(), spans=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(fo.cpu().numpy(), of), (cfg, pat, bad_frac, "oracle")
+    assert n_one >= 100, n_one
 
 
 def test_literal_index_search_on_tile_kernel(fx):
