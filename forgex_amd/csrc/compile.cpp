@@ -1372,7 +1372,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    {
       std::vector<uint16_t> bcm(256, 0), btr, bta;
       const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || (brute_equiv && !overlap_sink));
-      std::vector<uint8_t> bwa, bwr;
+      std::vector<uint8_t> bwa, bwr, b8a;
       if (want) {
          Sig full;
          for (int k = 0; k < nI; ++k) full.emplace_back(static_cast<uint32_t>(bounds[static_cast<size_t>(k)]), cls_of[static_cast<size_t>(k)]);
@@ -1457,10 +1457,22 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                   uint8_t fm[16] = {0};
                   for (int st2 = 0; st2 < Ab.d.n; ++st2) fm[st2] = static_cast<uint8_t>(Ab.fin[static_cast<size_t>(st2)]);
                   std::memcpy(h.bw16_finalM, fm, 16);
+                  // searches whose byte-level FORWARD automaton has <= 8 states: the same in the v_perm format (one v_perm_b32 per
+                  // byte on the forward pass of a UTF-8 tile; the backward pass keeps the nibble tables)
+                  if (!is_match && Ab.d.n <= 8) {
+                     b8a.assign(256 * 8, 0);
+                     for (int b = 0; b < 256; ++b)
+                        for (int st2 = 0; st2 < Ab.d.n; ++st2)
+                           b8a[static_cast<size_t>(b) * 8 + static_cast<size_t>(st2)] = static_cast<uint8_t>(Ab.d.T[static_cast<size_t>(st2) * 256 + b]);
+                     h.flags |= FXP_F_BYTE_A8;
+                     h.b8_A_init = static_cast<uint32_t>(Ab.d.init);
+                     h.b8_acc_min = static_cast<uint32_t>(accmin);   // (== Ab.d.n when no state accepts: never reached)
+                  }
                }
             }
          }
       }
+      h.off_b8A = bl.put(b8a.data(), b8a.size());
       h.off_byte_cls = bl.put(bcm.data(), bcm.size() * 2);
       h.off_byte_TR = bl.put(btr.data(), btr.size() * 2);
       h.off_byte_TA = bl.put(bta.data(), bta.size() * 2);
@@ -1569,7 +1581,7 @@ int validate_blob(const uint8_t* b, size_t size) {
    auto u16 = [&](uint32_t off, uint64_t i) { uint16_t v; std::memcpy(&v, b + off + 2 * i, 2); return v; };
    const uint32_t known = FXP_F_INIT_ACCEPTING | FXP_F_PREFILTER | FXP_F_HAS_SUFFIX | FXP_F_FAST_OK | FXP_F_HAS_R | FXP_F_MATCH_LITERAL |
                           FXP_F_FAST_UTF8 | FXP_F_NFA_SIM | FXP_F_CHAIN_OK | FXP_F_CHAIN_UTF8 | FXP_F_RAW_BYTES | FXP_F_RAGGED_OK | FXP_F_BYTE_DFA |
-                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK;
+                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8;
    if (h.flags & ~known) return 5;
    // chain-format table: rows of (ncls + 3) uint16, entries = row offsets of the same table; the 256-entry map holds 2 * column
    auto chain_ok = [&](uint32_t off_cls, uint32_t off_T, uint32_t T_bytes, uint32_t ncls, uint32_t row_bytes, bool final_col) {
@@ -1668,7 +1680,14 @@ int validate_blob(const uint8_t* b, size_t size) {
          if (!state_ok(h.byte_R_start, h.byte_TR_bytes, h.byte_row_bytes)) return 66;
       } else if (h.byte_TR_bytes != 0 && !inside(h.off_byte_TR, h.byte_TR_bytes)) return 67;
       if ((h.flags & FXP_F_BYTE_W16) && (!inside(h.off_bw16A, 2048) || !inside(h.off_bw16R, 2048))) return 68;
-   } else if (h.flags & FXP_F_BYTE_W16) return 69;
+      if (h.flags & FXP_F_BYTE_A8) {
+         if (!(h.flags & FXP_F_BYTE_W16) || h.mode == FXP_MODE_MATCH_ENGINE || !inside(h.off_b8A, 2048)) return 70;
+         if (h.b8_A_init >= 8u || h.b8_acc_min > 8u) return 71;
+         const uint8_t* t = b + h.off_b8A;
+         for (uint32_t i = 0; i < 2048u; ++i)
+            if (t[i] >= 8u) return 72;
+      }
+   } else if (h.flags & (FXP_F_BYTE_W16 | FXP_F_BYTE_A8)) return 69;
    return 0;
 }
 

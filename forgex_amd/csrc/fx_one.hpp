@@ -31,9 +31,11 @@ struct FxTileRow {
    }
 };
 
-template <int SCH_, bool BYTES_, bool DECODED_>
+// SCH_: scheme of the backward (and, unless SA_ says otherwise, the forward) tables; SA_: scheme of the FORWARD tables (byte-level tables
+// with FXP_F_BYTE_A8: nibble tables backwards, 8-state v_perm tables forwards)
+template <int SCH_, bool BYTES_, bool DECODED_, int SA_ = SCH_>
 struct FxScanCfg {
-   static constexpr int sch = SCH_;
+   static constexpr int sch = SCH_, sch_a = SA_;
    static constexpr bool bytes = BYTES_, decoded = DECODED_;
 };
 
@@ -74,16 +76,17 @@ struct FxFwdQueue {
 struct FxNoFlush {
    __device__ __forceinline__ void operator()() const {}
 };
-template <int CH, bool SPANS, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool PREPAD, bool DEFERQ = false, class TabT,
-          class Emit, class Flush = FxNoFlush>
-__device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __restrict__ tabR, const TabT* __restrict__ tabA, const uint8_t* TRp,
+template <int CH, bool SPANS, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool PREPAD, bool DEFERQ = false, int S_A = S_,
+          class TabT, class TabTA, class Emit, class Flush = FxNoFlush>
+__device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __restrict__ tabR, const TabTA* __restrict__ tabA, const uint8_t* TRp,
                                              const uint8_t* TAp, const FastParams& P, const int64_t row, const bool row_ok, const bool ordered,
                                              bool& except, Emit& emit, FxFwdQueue* fq = nullptr, Flush flush = Flush()) {
    {
       constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2;
       (void)CHAIN;
       (void)WIDE;
-      using F = typename FxF<S_>::type;
+      using F = typename FxF<S_>::type;      // backward tables (R)
+      using FA = typename FxF<S_A>::type;    // forward tables (A)
       uint4* const tile = c.tile;
       const uint8_t* const tb = c.tb;
       const uint32_t lane = c.lane, L = c.L, Lr = c.Lr;
@@ -186,7 +189,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
-         const F f = tabA[0];
+         const FA f = tabA[0];
          cur = fxstep(f, cur, TAp);
          mm = cur >= P.acc_min ? 2u : 0u;
       }
@@ -200,7 +203,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
          for (int gb = 0; gb < NG; gb += GB) {
-            F f[8 * GB];
+            FA f[8 * GB];
 #pragma unroll
             for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
 #pragma unroll
@@ -221,7 +224,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             }
          }
          {
-            F fr8[8];
+            FA fr8[8];
             lookup8(fr8, blo, bhi, tabA);
             uint32_t st = el, loc = 0;
 #pragma unroll
@@ -236,7 +239,8 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          // their last): the rest of the row in ALIGNED 8-byte groups with the backward pass's lookup pipeline -- 5 instead of 7.6
          // instructions per byte.  Few lanes: 8 symbols per round trip from wherever each lane stands (below).
          bool aligned_done = false;
-         if constexpr (!RAGGED && CH >= 4 && FX_FWD_ALIGNED != 0) {
+         if constexpr (!RAGGED && CH >= 4 && FX_FWD_ALIGNED != 0 && BYTES) {   // (byte-level scans: UTF-8 text, where matches run long; the class-level
+                                                                                //  scans of ASCII tiles keep the shorter code: config 5 lost 1 % to its mere presence)
             if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != 0)) >= (uint32_t)FX_FWD_ALIGNED_MIN) {
                aligned_done = true;
                // (1) every lane to its next 8-byte boundary: up to 7 symbols, per lane
@@ -244,7 +248,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                if (__builtin_amdgcn_ballot_w64(cur != 0 && nrem != 0u) != 0) {
                   uint32_t o1[2];
                   fetch_groups<RAGGED, 1>(o1, tb, lane, j, (uint32_t)L);
-                  F f8[8];
+                  FA f8[8];
                   lookup8(f8, o1[0], o1[1], tabA);
 #pragma unroll
                   for (int q = 0; q < 7; ++q) {
@@ -261,7 +265,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                uint32_t c0 = 0;
                while (c0 < (uint32_t)CH && __builtin_amdgcn_ballot_w64(cur != 0 && (g0 >> 1) <= c0) == 0) ++c0;
                uint32_t gl2 = 0xFFFFFFFFu, el2 = 0;
-               F fa[8], fb[8];
+               FA fa[8], fb[8];
                uint4 wk = tile[tile_cell(lane, c0)], wn = tile[tile_cell(lane, c0 < (uint32_t)CH ? c0 + 1u : c0)];
                lookup8(fa, wk.x, wk.y, tabA);
 #pragma unroll 1
@@ -312,7 +316,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                if (__builtin_amdgcn_ballot_w64(gl2 != 0xFFFFFFFFu) != 0) {
                   const uint32_t g = gl2 != 0xFFFFFFFFu ? gl2 : 0u;
                   const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
-                  F fr8[8];
+                  FA fr8[8];
                   lookup8(fr8, rw.x, rw.y, tabA);
                   uint32_t st = el2, loc = 0;
 #pragma unroll
@@ -339,7 +343,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
                const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
                const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
-               F f8[8];
+               FA f8[8];
                lookup8(f8, o0, o1, tabA);
                const uint32_t entry = cur;
                uint32_t st[8];
@@ -360,7 +364,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                t1[0] = t2[0]; t1[1] = t2[1];
             } while (__builtin_amdgcn_ballot_w64(cur != 0) != 0);
             if (__builtin_amdgcn_ballot_w64(jl != 0xFFFFFFFFu) != 0) {
-               F fr8[8];
+               FA fr8[8];
                lookup8(fr8, lo2, hi2, tabA);
                uint32_t st = el2, loc = 0;
 #pragma unroll
@@ -469,15 +473,21 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
    static_assert(!MATCH || (!SPANS && !MARKED), "`.match.` has no span and no multi-pass first pass");
    constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0, POOL = HAS_B || GEN;
+   using BCfg = FxScanCfg<(BSCH == 3 ? 2 : (BSCH != 0 ? BSCH : 1)), true, false, (BSCH == 3 ? 0 : (BSCH != 0 ? BSCH : 1))>;   // the byte-level tables' scan
+   static_assert(BSCH != 3 || !MATCH, "FXP_F_BYTE_A8 is a search program's table");
    const uint32_t L = RAGGED ? Lr : 16u * CH;
    __shared__ uint2 permR[SCH == 0 ? 256 : 1];
    __shared__ uint2 permA[SCH == 0 ? 256 : 1];
    __shared__ fx_nib wideR[SCH == 2 ? 256 : 1];
    __shared__ fx_nib wideA[SCH == 2 ? 256 : 1];
-   __shared__ fx_nib bwideR[BSCH == 2 ? 256 : 1];
+   __shared__ fx_nib bwideR[(BSCH == 2 || BSCH == 3) ? 256 : 1];
    __shared__ fx_nib bwideA[BSCH == 2 ? 256 : 1];
+   __shared__ uint2 bpermA[BSCH == 3 ? 256 : 1];   // BSCH 3: byte-level tables, nibble format backwards, 8-state v_perm format forwards (FXP_F_BYTE_A8)
    __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
-   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED && !MATCH;   // match compaction (see fx_scan_tile)
+   // match compaction (see fx_scan_tile): rows of up to 64 bytes, where the exact start + first forward window are a third of a tile's
+   // instructions (config 2: 21.0 -> 18.8 us); on longer rows its bookkeeping cost more than it saved on the BASELINE shapes
+   // (config 5: +2 %, config 4: +1 %, profiles/r03_defer_ab.txt)
+   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED && !MATCH && CH <= 4;
    __shared__ uint32_t fwd_q[DEFERQ ? 4 * 128 : 1];   // per-wave queues of rows whose exact start + forward pass are finished 64 at a time
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
@@ -508,9 +518,10 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_byte_TA);
       const uint32_t nr = b_tr / 2, na = b_ta / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) bmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
-   } else if (BSCH == 2) {
+   } else if (BSCH == 2 || BSCH == 3) {
       bwideR[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16R)[threadIdx.x];
-      bwideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16A)[threadIdx.x];
+      if (BSCH == 2) bwideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16A)[threadIdx.x];
+      else bpermA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_b8A)[threadIdx.x];
    }
    // BMP class map (page index + pages) of the in-LDS UTF-8 decode, behind the tables when it fits
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
@@ -585,10 +596,15 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const FastParams& P = BYTES ? fpb : fp;
       const uint16_t* cm = BYTES ? bmap : cmap;
       const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideR : wideR) : reinterpret_cast<const TabT*>(permR));
-      const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideA : wideA) : reinterpret_cast<const TabT*>(permA));
       const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cm) + 512;
       const uint8_t* TAp = TRp + (CHAIN ? (BYTES ? b_tr : c_tr) : 0u);
-      return fn(tabR, tabA, TRp, TAp, P);
+      if constexpr (C::sch_a != S_) {   // byte-level tables with FXP_F_BYTE_A8: the forward automaton in the 8-state v_perm format
+         static_assert(C::sch_a == 0 && BYTES && S_ == 2, "forward scheme differs: nibble tables backwards, v_perm forwards");
+         return fn(tabR, reinterpret_cast<const uint2*>(bpermA), TRp, TAp, P);
+      } else {
+         const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cm) : (WIDE ? reinterpret_cast<const TabT*>(BYTES ? bwideA : wideA) : reinterpret_cast<const TabT*>(permA));
+         return fn(tabR, tabA, TRp, TAp, P);
+      }
    };
    // ---- match compaction: this wave's queue and its flush (every lane finishes one queued row from global memory) ----------------
    FxFwdQueue fwdq{fwd_q + (DEFERQ ? wave * 128u : 0u), 0u, 0u};
@@ -605,12 +621,12 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             constexpr int S_ = decltype(cfg)::sch;
             with_tables(cfg, [&](auto tabR, auto tabA, const uint8_t* TRp, const uint8_t* TAp, const FastParams& P) {
                const uint32_t e = S_ == 0 ? (ge >> 16) * 0x01010101u : (ge >> 16);
-               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm);
+               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2, decltype(cfg)::sch_a>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm);
                return 0;
             });
          };
          if constexpr (HAS_B) {
-            if (fam_bytes) finish(FxScanCfg<(BSCH != 0 ? BSCH : 1), true, false>{});
+            if (fam_bytes) finish(BCfg{});
             else if constexpr (!ALLB) finish(FxScanCfg<SCH, false, false>{});
          } else finish(FxScanCfg<SCH, false, false>{});
          if (on) {   // api_internal_m.F90:140-148 with a start inside the text (from = s - 1 >= 1)
@@ -640,7 +656,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             (void)TRp;
             return fx_match_tile<CH, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN>(sctx, tabA, TAp, P, h, mgate, row, row_ok, ordered, except, emit);
          } else {
-            return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered,
+            return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ, C::sch_a>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered,
                                                                                                              except, emit, &fwdq, flush_fwd);
          }
       });
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const bool nonascii = !is_tile || hint || redo;   // (gathered rows always take the decode)
       if constexpr (HAS_B) {
          if (is_tile && (ALLB || nonascii)) {
-            (void)scan(FxScanCfg<(BSCH != 0 ? BSCH : 1), true, false>{}, row, row_ok, true, except);
+            (void)scan(BCfg{}, row, row_ok, true, except);
             pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
             pend_row = (uint32_t)row;
          }
@@ -853,7 +869,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
-   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + (BSCH == 2 ? 4096 : 0) + 1024 + 64 + (FX_DEFER_FWD != 0 ? 2048 : 0);
+   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64 + ((FX_DEFER_FWD != 0 && CH <= 4) ? 2048 : 0);
    const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
@@ -875,6 +891,9 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       if (blocks > cap) blocks = cap;
    };
    if (is_match) {   // `.match.`: one verdict per row, no span
+     if constexpr (BSCH == 3) {
+      return hipErrorInvalidValue;   // (never dispatched: FXP_F_BYTE_A8 is a search program's table)
+     } else {
       if (ragged) {
          if constexpr (BSCH == 0) {
             const void* fn = reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN, false, true>);
@@ -897,6 +916,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       cap_grid(fn);
       hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, nullptr);
       return hipGetLastError();
+     }
    }
    if (ragged) {
       if constexpr (BSCH == 0) {
@@ -930,7 +950,7 @@ hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_bl
                              uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate) {
    constexpr int CH = 16;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
-   const size_t static_b = 4096 + (BSCH == 2 ? 4096 : 0) + 1024 + 64;
+   const size_t static_b = 4096 + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64;
    const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const int64_t n_tiles = (n + 63) >> 6;
@@ -950,7 +970,7 @@ hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_bl
 #define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*)
 
 // every (CH, SCH, BSCH, GEN) the dispatch code of fxamd.hip can ask for
-#define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)
+#define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 0, 3, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)
 #define FX_ONE_COMBOS(X, CH) FX_ONE_COMBOS_G(X, CH, false) FX_ONE_COMBOS_G(X, CH, true)
 #define FX_ONE_ALL(X) \
    FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 3) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 6) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)

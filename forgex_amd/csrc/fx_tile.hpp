@@ -410,11 +410,12 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
 // group for the exact start, then walks forward from it (first window of 8*NW symbols, lookups issued 8*GB at a time, then 8 symbols per
 // round while any lane is alive).  Returns the wrapped start index s (>= 2) and max_match mm (0 = none; lit_len != 0: s + lit_len, no
 // walk).  The same arithmetic as the in-tile path (fx_scan_tile / fx_search_fast), with the row read through group_words<.., LONG>.
-template <int S_, int NW, int GB, class TabT>
-__device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ tabR, const TabT* __restrict__ tabA, const uint8_t* TRp, const uint8_t* TAp,
+template <int S_, int NW, int GB, int S_A = S_, class TabT, class TabTA>
+__device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ tabR, const TabTA* __restrict__ tabA, const uint8_t* TRp, const uint8_t* TAp,
                                                       const FastParams& P, const uint8_t* rp, const uint32_t L, const uint32_t lane, const bool on,
                                                       const uint32_t g, const uint32_t e, uint32_t& s_out, uint32_t& mm_out) {
    using F = typename FxF<S_>::type;
+   using FA = typename FxF<S_A>::type;
    static_assert(NW % GB == 0, "window groups: a multiple of the lookup batch");
    uint2 rw = make_uint2(0, 0);
    uint32_t nv = 8;
@@ -462,7 +463,7 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
       uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
       for (int gb = 0; gb < NW; gb += GB) {
-         F f[8 * GB];
+         FA f[8 * GB];
 #pragma unroll
          for (int q = 0; q < GB; ++q) lookup8(&f[8 * q], o[2 * (gb + q)], o[2 * (gb + q) + 1], tabA);
 #pragma unroll
@@ -483,7 +484,7 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
          }
       }
       {
-         F fr8[8];
+         FA fr8[8];
          lookup8(fr8, blo, bhi, tabA);
          uint32_t st = el, loc = 0;
 #pragma unroll
@@ -505,7 +506,7 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
             group_words<false, true>(t2[0], t2[1], rp, lane, gbp + 16u, L);
             const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
             const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
-            F f8[8];
+            FA f8[8];
             lookup8(f8, o0, o1, tabA);
             uint32_t loc = 8;
 #pragma unroll

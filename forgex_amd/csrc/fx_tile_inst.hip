@@ -18,4 +18,5 @@ template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;
 template hipError_t launch_one_marked<0> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<1> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<2> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<3> FX_ONE_MARKED_SIG;
 #endif

@@ -28,6 +28,7 @@ FX_ONE_ALL(FX_X)
 extern template hipError_t launch_one_marked<0> FX_ONE_MARKED_SIG;
 extern template hipError_t launch_one_marked<1> FX_ONE_MARKED_SIG;
 extern template hipError_t launch_one_marked<2> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<3> FX_ONE_MARKED_SIG;
 extern template hipError_t launch_multi<1> FX_MULTI_SIG;
 extern template hipError_t launch_multi<2> FX_MULTI_SIG;
 extern template hipError_t launch_multi<3> FX_MULTI_SIG;
@@ -561,6 +562,12 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
 static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
                  0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u};
+   if (sch == 3) {   // byte-level tables, FXP_F_BYTE_A8: nibble format backwards, 8-state v_perm format (replicated state bytes) forwards
+      fp = params_of(h, 2, true);
+      fp.A_init = h.b8_A_init * 0x01010101u;
+      fp.acc_min = h.b8_acc_min * 0x01010101u;
+      return fp;
+   }
    if (sch == 2) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.R_start = bytes ? h.bw16_R_start : h.w16_R_start;
       fp.A_init = bytes ? h.bw16_A_init : h.w16_A_init;
@@ -613,7 +620,7 @@ static hipError_t launch_one_any(int sch, int bsch, bool gen, const FxpHeader& h
    if (sch == S && bsch == B)                                                                                                     \
       return gen ? launch_one_ch<S, B, true>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode)                 \
                  : launch_one_ch<S, B, false>(h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode);
-   FX_ONE_CASE(0, 0) FX_ONE_CASE(1, 0) FX_ONE_CASE(2, 0) FX_ONE_CASE(0, 1) FX_ONE_CASE(0, 2) FX_ONE_CASE(1, 1) FX_ONE_CASE(1, 2) FX_ONE_CASE(2, 1) FX_ONE_CASE(2, 2)
+   FX_ONE_CASE(0, 0) FX_ONE_CASE(1, 0) FX_ONE_CASE(2, 0) FX_ONE_CASE(0, 1) FX_ONE_CASE(0, 2) FX_ONE_CASE(0, 3) FX_ONE_CASE(1, 1) FX_ONE_CASE(1, 2) FX_ONE_CASE(2, 1) FX_ONE_CASE(2, 2)
 #undef FX_ONE_CASE
    return hipErrorInvalidValue;
 }
@@ -623,7 +630,8 @@ static int one_bytes_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t r
    if (!bytes_ok(h, d_rows, row_len)) return 0;
    const size_t tiles_b = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1);
    const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 4096 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
-   if (bytes_scheme(h) == 2 && tiles_b + cls_b + 4096 + 2048 <= 80 * 1024) return 2;
+   if (bytes_scheme(h) == 2 && tiles_b + cls_b + 4096 + 2048 <= 80 * 1024)   // (3: with the forward automaton in the v_perm format, FXP_F_BYTE_A8)
+      return (sch == 0 && (h.flags & FXP_F_BYTE_A8) && h.mode == FXP_MODE_SEARCH_ENGINE && !std::getenv("FXAMD_NO_A8")) ? 3 : 2;
    if (tiles_b + cls_b + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 + 2048 <= 150 * 1024) return 1;
    return 0;
 }
@@ -795,7 +803,8 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
          const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
-         if (ob == 2) FX_HIP(launch_one_marked<2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
+         if (ob == 3) FX_HIP(launch_one_marked<3>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
+         else if (ob == 2) FX_HIP(launch_one_marked<2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
          else if (ob == 1) FX_HIP(launch_one_marked<1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
          else FX_HIP(launch_one_marked<0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
          p->last_path = 16;

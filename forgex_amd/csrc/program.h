@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 13u
+#define FXP_VERSION 14u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -38,6 +38,7 @@ enum FxpFlags {
    FXP_F_W16_OK = 1u << 13,         // 16-state nibble tables present (automata with 9..16 states: a 64-bit shift per byte instead of the LDS chain)
    FXP_F_W16_UTF8 = 1u << 14,       // ... and they hold the 128+class / SKIP rows (the decode pass may use them)
    FXP_F_BYTE_W16 = 1u << 15,       // the byte-level automata also exist in the 16-state nibble format
+   FXP_F_BYTE_A8 = 1u << 18,        // searches: the byte-level FORWARD automaton has <= 8 states and also exists in the v_perm format (b8A)
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match
    FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it
@@ -101,6 +102,11 @@ struct FxpHeader {
    uint32_t off_w16A, off_w16R;     // uint8 [256][8]   (16 nibbles per symbol)
    uint32_t off_bw16A, off_bw16R;   // uint8 [256][8]
    uint32_t w16_finalM[4], bw16_finalM[4];   // `.match.`: byte j = verdict of state j after the last text byte (byte-level: 2 = redo by the decode path)
+   // ---- FXP_F_BYTE_A8: the byte-level forward automaton of a SEARCH (structure errors lead to its dead state: the backward pass has
+   //      sent such rows to the exception path before any forward walk) in the 8-state v_perm format, indexed by the raw byte: the
+   //      forward pass of a UTF-8 tile costs one v_perm_b32 per byte instead of the nibble format's three instructions ----
+   uint32_t off_b8A;      // uint8 [256][8]
+   uint32_t b8_A_init, b8_acc_min;
    uint32_t R_inv;        // FXP_F_OVERLAP_SINK: that state of R (a row that ends its backward pass there is left to the general engine)
    uint32_t checksum;     // FNV-1a of the whole image with this field read as zero (fxc::blob_checksum); checked by fxamd_program_from_blob
 };
