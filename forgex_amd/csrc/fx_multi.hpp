@@ -2,7 +2,9 @@
 // elemental over `pattern` too, src/forgex.F90:74,163).  A tile of 64 rows is staged in LDS once; the tables of all m patterns
 // (8-state v_perm scheme: 4 KB each) sit in LDS next to the tiles, and the wave that owns the tile scans it once per pattern
 // (fx_scan_tile), writing pattern p's results to flags[p*n + row] (from / to likewise).  HBM traffic: the rows once plus m result
-// sets, instead of m times the rows.
+// sets, instead of m times the rows.  Patterns that have byte-level tables in the nibble format (FXP_F_BYTE_W16; bsch 2, or 3 with the
+// forward automaton in the v_perm format) bring them along (8 KB per pattern instead of 4): a tile with a byte >= 0x80 is scanned for
+// them right here, on the raw bytes, instead of being deferred to a pass of their own that reads the rows again.
 // The kernel is the FIRST PASS of every pattern's multi-pass pipeline (what fx_search_fast's MODE 0 does), sharing the staging:
 // a tile with a byte >= 0x80 is deferred for the patterns that have a later pass for such tiles (its rows are marked
 // FX_NEEDS_GENERAL in that pattern's flags, the pattern's "deferred" word is set), and rows a pattern's tables cannot answer -- a
@@ -21,6 +23,9 @@ struct FxMultiArgs {
    uint32_t* ctr[FX_MULTI_MAX];         // this call's counter group of each ([0] tiles deferred, [1] rows in its worklist)
    uint32_t* worklist[FX_MULTI_MAX];    // rows left to each pattern's fix-up
    uint32_t defer_tiles[FX_MULTI_MAX];  // 1: a later pass of this pattern takes whole tiles that hold a byte >= 0x80
+   FastParams fpb[FX_MULTI_MAX];        // byte-level parameters of each (bsch != 0)
+   uint32_t bsch[FX_MULTI_MAX];         // 0: no byte-level tables in this pass; 2: nibble tables; 3: nibble backwards, v_perm forwards (FXP_F_BYTE_A8)
+   uint32_t any_bytes;                  // some pattern has bsch != 0: the table area holds 8 KB per pattern (else 4 KB)
    uint32_t m;
 };
 
@@ -28,15 +33,22 @@ template <int CH, bool SPANS, bool RAGGED, int WPB>
 __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __restrict__ rows, int64_t n, FxMultiArgs a, uint8_t* __restrict__ flags,
                                                               int32_t* __restrict__ from, int32_t* __restrict__ to, uint32_t Lr) {
    const uint32_t L = RAGGED ? Lr : 16u * CH;
-   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // WPB waves x 64*(CH+1) cells, then m x (permR[256], permA[256])
+   extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // WPB waves x 64*(CH+1) cells, then m x (permR[256], permA[256] [, bwideR[256], bwideA / b8A[256]])
    uint2* tabs = reinterpret_cast<uint2*>(tiles + WPB * 64 * (CH + 1));
+   const uint32_t tstride = a.any_bytes ? 1024u : 512u;   // 8-byte entries per pattern
    for (uint32_t p = 0; p < a.m; ++p) {
       const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
       const uint2* gR = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastR);
       const uint2* gA = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastA);
+      const uint2* bR = reinterpret_cast<const uint2*>(a.blob[p] + h->off_bw16R);
+      const uint2* bA = reinterpret_cast<const uint2*>(a.blob[p] + (a.bsch[p] == 3u ? h->off_b8A : h->off_bw16A));
       for (uint32_t i = threadIdx.x; i < 256u; i += 64u * WPB) {
-         tabs[p * 512u + i] = gR[i];
-         tabs[p * 512u + 256u + i] = gA[i];
+         tabs[p * tstride + i] = gR[i];
+         tabs[p * tstride + 256u + i] = gA[i];
+         if (a.bsch[p] != 0u) {
+            tabs[p * tstride + 512u + i] = bR[i];
+            tabs[p * tstride + 768u + i] = bA[i];
+         }
       }
    }
    // the counter words of consecutive calls alternate: this call zeroes the other group of every pattern (see fx_search_fast)
@@ -89,7 +101,8 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
          const int64_t base = (int64_t)a.slot[p] * n;
          const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
          sc.raw = (h->flags & FXP_F_RAW_BYTES) != 0;
-         if (tile_hi && !sc.raw && a.defer_tiles[p] != 0u) {   // left whole to this pattern's pass over deferred tiles
+         const bool bytes_here = !RAGGED && tile_hi && !sc.raw && a.bsch[p] != 0u;   // scanned right here with the pattern's byte-level tables
+         if (tile_hi && !sc.raw && !bytes_here && a.defer_tiles[p] != 0u) {   // left whole to this pattern's pass over deferred tiles
             if (row_ok) flags[base + row] = FX_NEEDS_GENERAL;
             deferred_any |= 1u << p;
             continue;
@@ -103,10 +116,21 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
                }
             }
          };
-         const uint2* tR = tabs + p * 512u;
+         const uint2* tR = tabs + p * tstride;
          const uint2* tA = tR + 256;
          bool except = false;
-         (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
+         if constexpr (!RAGGED) {
+            if (bytes_here) {   // raw bytes, nibble tables backwards; forwards nibble or (bsch 3) 8-state v_perm; INVALID rows are listed below
+               const fx_nib* bR = reinterpret_cast<const fx_nib*>(tR + 512);
+               if (a.bsch[p] == 3u)
+                  (void)fx_scan_tile<CH, SPANS, false, 2, true, false, false, false, true, false, 0>(sc, bR, tR + 768, nullptr, nullptr, a.fpb[p], row, row_ok, true, except, emit);
+               else
+                  (void)fx_scan_tile<CH, SPANS, false, 2, true, false, false, false, true, false, 2>(sc, bR, reinterpret_cast<const fx_nib*>(tR + 768), nullptr, nullptr,
+                                                                                                       a.fpb[p], row, row_ok, true, except, emit);
+            }
+         }
+         if (!bytes_here)
+            (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
          // rows these tables cannot answer: marked, and listed for the pattern's row-level fix-up (one atomic per tile that has any)
          const bool listed = except && row_ok;
          const uint64_t em = __builtin_amdgcn_ballot_w64(listed);
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
 // waves per block: 8 when that keeps more waves on a CU than blocks of 4 (the tables are stored once per block)
 template <int CH>
 hipError_t launch_multi(const uint8_t* rows, int64_t n, const FxMultiArgs& a, uint8_t* flags, int32_t* from, int32_t* to, uint32_t Lr, hipStream_t st) {
-   const size_t tab_b = (size_t)a.m * 4096;
+   const size_t tab_b = (size_t)a.m * (a.any_bytes ? 8192 : 4096);
    const size_t t4 = (size_t)4 * 64 * (CH + 1) * 16 + tab_b, t8 = (size_t)8 * 64 * (CH + 1) * 16 + tab_b;
    const size_t cap = 160 * 1024;
    const int w4 = t4 <= cap ? 4 * (int)(cap / t4) : 0, w8 = t8 <= cap ? 8 * (int)(cap / t8) : 0;
@@ -170,9 +194,9 @@ hipError_t launch_multi(const uint8_t* rows, int64_t n, const FxMultiArgs& a, ui
 #undef FX_MULTI_LAUNCH
 }
 // how many patterns one launch can take for rows of this chunk count (tables + at least four tiles in 160 KB of LDS)
-static inline int multi_max_patterns(int ch) {
+static inline int multi_max_patterns(int ch, bool any_bytes = false) {
    const size_t t4 = (size_t)4 * 64 * (ch + 1) * 16;
-   int m = (int)((160 * 1024 - t4) / 4096);
+   int m = (int)((160 * 1024 - t4) / (any_bytes ? 8192 : 4096));
    return m > FX_MULTI_MAX ? FX_MULTI_MAX : (m < 0 ? 0 : m);
 }
 #define FX_MULTI_SIG (const uint8_t*, int64_t, const FxMultiArgs&, uint8_t*, int32_t*, int32_t*, uint32_t, hipStream_t)

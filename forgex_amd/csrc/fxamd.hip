@@ -670,6 +670,7 @@ struct SharedFirstPass {
    uint32_t* ctr = nullptr;
    uint32_t* worklist = nullptr;
    uint32_t defer_tiles = 0;
+   bool bytes_in_shared = false;   // the shared pass scans tiles with bytes >= 0x80 with this pattern's byte-level tables: no pass over deferred tiles
 };
 static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
                          uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode = 0u, int first_pass = FX_FP_OWN,
@@ -817,7 +818,9 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       else FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
       if (bytes) {
          // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
-         if (is_match) FX_HIP(match_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
+         // (a shared first pass that scanned those tiles itself has deferred none: only its exception rows are left)
+         if (first_pass == FX_FP_DONE && shared && shared->bytes_in_shared) {
+         } else if (is_match) FX_HIP(match_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
          else FX_HIP(fast_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
          p->last_path = 8;
          return exceptions();
@@ -1267,7 +1270,15 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
             fused.push_back(i);
       }
    const int ch = tile_chunks(row_len);
-   const int gmax = ch > 0 ? multi_max_patterns(ch) : 0;
+   // byte-level tables in the shared pass (nibble format; 8 KB of LDS per pattern then): when some fused pattern has them for these rows
+   std::vector<int> obs((size_t)m, 0);
+   bool any_bytes = false;
+   for (int32_t i : fused) {
+      const int ob = one_bytes_scheme(progs[i]->prog.hdr(), d_rows, row_len, 0);
+      obs[(size_t)i] = (ob == 2 || ob == 3) && progs[i]->prog.hdr().mode == FXP_MODE_SEARCH_ENGINE && !std::getenv("FXAMD_MULTI_NO_BYTES") ? ob : 0;
+      any_bytes = any_bytes || obs[(size_t)i] != 0;
+   }
+   const int gmax = ch > 0 ? multi_max_patterns(ch, any_bytes) : 0;
    if ((int)fused.size() < 2 || gmax < 2) fused.clear();
    std::vector<char> done((size_t)m, 0);
    int dev = -1;
@@ -1315,6 +1326,12 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          a.ctr[a.m] = shs[k - g0].ctr;
          a.worklist[a.m] = shs[k - g0].worklist;
          a.defer_tiles[a.m] = shs[k - g0].defer_tiles;
+         a.bsch[a.m] = (uint32_t)obs[(size_t)slot];
+         if (obs[(size_t)slot] != 0) {
+            a.fpb[a.m] = params_of(p->prog.hdr(), obs[(size_t)slot], true);
+            shs[k - g0].bytes_in_shared = true;
+         }
+         a.any_bytes = any_bytes ? 1u : 0u;
          ++a.m;
       }
       if (rc != FXAMD_OK) {

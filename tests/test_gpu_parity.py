@@ -641,6 +641,48 @@ def test_many_patterns_over_one_batch(fx, shape):
         assert np.array_equal(f2[i].cpu().numpy(), of), (shape, p, "flags only")
 
 
+def test_many_patterns_utf8_tiles_in_the_shared_pass(fx, monkeypatch):
+    """fx_search_multi brings the patterns' byte-level tables along (nibble format; forward automaton in the v_perm format where the
+    program has it): tiles with bytes >= 0x80 are scanned in the shared pass instead of being deferred to a pass per pattern.  Same
+    results as with the deferring shared pass (FXAMD_MULTI_NO_BYTES=1) and as one pattern at a time, on config-4 rows with 0 / 3 / 100 %
+    structurally broken rows (exception rows go to each pattern's worklist pass)."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    pats = [synth.PATTERNS["cfg4"], "[ぁ-ん]+", "[α-ω][ぁ-ん]", "ん[α-ω]+", "[a-z]+", "(α|β|γ)[ぁ-ん]."]
+    g = torch.Generator().manual_seed(77)
+    for bad_frac in (0.0, 0.03, 1.0):
+        n = 1 << 15
+        rows = synth.batch("cfg4", 3000, n, dev)
+        if bad_frac > 0:
+            sel = (torch.rand(n, generator=g) < bad_frac).to(dev)
+            pos = torch.randint(0, 192, (n,), generator=g).to(dev)
+            val = torch.randint(0x80, 0x100, (n,), generator=g).to(torch.uint8).to(dev)
+            idx = torch.arange(n, device=dev)[sel]
+            rows[idx, pos[sel]] = val[sel]
+        monkeypatch.delenv("FXAMD_MULTI_NO_BYTES", raising=False)
+        progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+        infos = [p.info()["flags"] for p in progs]
+        assert sum(1 for fl in infos if fl & (1 << 15)) >= 4   # FXP_F_BYTE_W16: byte-level nibble tables
+        f, a, b = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        assert sum(1 for p in progs if p.last_path() == 15) >= 4, [p.last_path() for p in progs]
+        monkeypatch.setenv("FXAMD_MULTI_NO_BYTES", "1")
+        f2, a2, b2 = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("FXAMD_MULTI_NO_BYTES", raising=False)
+        assert torch.equal(f, f2) and torch.equal(a, a2) and torch.equal(b, b2), bad_frac
+        for i, p in enumerate(progs):
+            f1, a1, b1 = p.match_device(rows)
+            torch.cuda.synchronize()
+            assert torch.equal(f[i], f1) and torch.equal(a[i], a1) and torch.equal(b[i], b1), (bad_frac, pats[i])
+        k = 1200
+        host = rows[:k].cpu().numpy()
+        for i, p in enumerate(pats):
+            of, oa, ob = oracle_lib.batch(2, p.encode(), host, NT)
+            assert np.array_equal(f[i][:k].cpu().numpy(), of) and np.array_equal(a[i][:k].cpu().numpy(), oa) and np.array_equal(b[i][:k].cpu().numpy(), ob), (bad_frac, p)
+
+
 def test_many_patterns_fuzz_groups(fx):
     """fx_search_multi under random pattern GROUPS: 2..10 generated patterns (whatever path each one qualifies for: shared first pass,
     own one-launch kernel, general kernel) against the same rows -- ASCII, mixed with valid and broken UTF-8, whole-chunk and ragged
