@@ -131,7 +131,9 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     touches a GPU and relays rank 0's single JSON line.  CPU dry run (gloo) of exactly that plumbing."""
     line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "1001"])
     assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True
-    assert line["config"]["parallelism"] == "shard2"
+    assert line["config"]["parallelism"] == "shard2" and line["scaling"] == "weak"
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong", "--config", "cfg5"])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True and line["scaling"] == "strong"
 
 
 def test_bench_under_torch_distributed_run():

@@ -1194,3 +1194,38 @@ def test_config_scale_rows_vs_real_reference_fixture(fx):
             assert np.array_equal(a.astype(np.int64), want[:, 1]) and np.array_equal(b.astype(np.int64), want[:, 2]), (pat, op, L)
         n_rows += len(idx)
     assert n_rows > 28000
+
+
+def test_one_launch_calls_replay_from_a_hip_graph(fx):
+    """The one-launch paths (`last_path` 9-14: no host-side counter alternation, nothing allocated once the handle has its scratch) can be
+    captured into a hipGraph and replayed on new row contents -- what a latency-bound caller of small batches does (a 1000-row batch is
+    one ~5 us kernel; eager calls pay the launch path every time).  Search with spans, flags only, and `.match.`."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    for cfg, op, spans in (("cfg2", fx.OP_SEARCH, True), ("cfg5", fx.OP_SEARCH, True), ("cfg4", fx.OP_SEARCH, False), ("cfg1", fx.OP_MATCH, False)):
+        n = 4096
+        rows = synth.batch(cfg, 0, n, dev)
+        prog = fx.Program(synth.PATTERNS[cfg], op)
+        out = prog.match_device(rows, spans=spans)   # (first call: tables uploaded, scratch allocated, code objects loaded)
+        torch.cuda.synchronize()
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14), (cfg, prog.last_path())
+        assert fx.lib().fxamd_program_reserve(prog._h, n, torch.cuda.current_stream().cuda_stream) == 0
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):   # the capture stream needs its own scratch set: reserve it before capturing
+            assert fx.lib().fxamd_program_reserve(prog._h, n, side.cuda_stream) == 0
+            prog.match_device(rows, spans=spans, out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            prog.match_device(rows, spans=spans, out=out)
+        for start in (10000, 77777, 123456):
+            rows.copy_(synth.batch(cfg, start, n, dev))
+            g.replay()
+            torch.cuda.synchronize()
+            got = [t.clone() if t is not None else None for t in out]
+            want = prog.match_device(rows, spans=spans)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]), (cfg, start)
+            if spans:
+                assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (cfg, start)
