@@ -26,6 +26,7 @@ struct FxMultiArgs {
    FastParams fpb[FX_MULTI_MAX];        // byte-level parameters of each (bsch != 0)
    uint32_t bsch[FX_MULTI_MAX];         // 0: no byte-level tables in this pass; 2: nibble tables; 3: nibble backwards, v_perm forwards (FXP_F_BYTE_A8)
    uint32_t any_bytes;                  // some pattern has bsch != 0: the table area holds 8 KB per pattern (else 4 KB)
+   uint32_t inq[FX_MULTI_MAX];          // 1: exception rows of this pattern's byte-level scan are finished INSIDE this launch (its class-level tables decode UTF-8)
    uint32_t m;
 };
 
@@ -36,6 +37,23 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // WPB waves x 64*(CH+1) cells, then m x (permR[256], permA[256] [, bwideR[256], bwideA / b8A[256]])
    uint2* tabs = reinterpret_cast<uint2*>(tiles + WPB * 64 * (CH + 1));
    const uint32_t tstride = a.any_bytes ? 1024u : 512u;   // 8-byte entries per pattern
+   // behind the tables (any_bytes only): per wave one queue of 64 exception rows (row, pattern) of ALL patterns, and the patterns'
+   // parameters where a lane can index them by its own pattern
+   uint32_t* xq_all = reinterpret_cast<uint32_t*>(tabs + (size_t)a.m * tstride);
+   uint32_t* xpar = xq_all + WPB * 128;   // [FX_MULTI_MAX][16]: R_start, A_init, hit_min, acc_min, inv, inv_on, lit_len, slot, blob lo, blob hi
+   if (a.any_bytes && threadIdx.x < a.m) {
+      const uint32_t q = threadIdx.x;
+      xpar[q * 16 + 0] = a.fp[q].R_start;
+      xpar[q * 16 + 1] = a.fp[q].A_init;
+      xpar[q * 16 + 2] = a.fp[q].hit_min;
+      xpar[q * 16 + 3] = a.fp[q].acc_min;
+      xpar[q * 16 + 4] = a.fp[q].inv;
+      xpar[q * 16 + 5] = a.fp[q].inv_on;
+      xpar[q * 16 + 6] = a.fp[q].lit_len;
+      xpar[q * 16 + 7] = a.slot[q];
+      xpar[q * 16 + 8] = (uint32_t)reinterpret_cast<uintptr_t>(a.blob[q]);
+      xpar[q * 16 + 9] = (uint32_t)(reinterpret_cast<uintptr_t>(a.blob[q]) >> 32);
+   }
    for (uint32_t p = 0; p < a.m; ++p) {
       const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
       const uint2* gR = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastR);
@@ -70,6 +88,63 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * WPB + wave, wave_stride = (int64_t)gridDim.x * WPB;
    uint32_t deferred_any = 0;   // bit p: this wave deferred a tile for pattern p
+   // ---- exception rows finished inside the launch: ONE queue per wave for all patterns.  A drain gathers the queued rows into the
+   //      tile (lane r = entry r), decodes each row with ITS pattern's class map, scans it with ITS pattern's class-level tables
+   //      (per-lane table base, per-lane parameters) and stores the result in its pattern's slot.  Drained when full -- after the
+   //      current tile's last pattern: the tile buffer is free then -- and when the wave has finished its tiles.
+   uint32_t* const xq = xq_all + wave * 128u;
+   uint32_t xq_n = 0;
+   auto drain = [&]() {
+      if (xq_n == 0u) return;
+      const bool on = lane < xq_n;
+      const uint32_t qrow = on ? xq[lane] : 0u, qp = on ? xq[64u + lane] : 0u;
+      xq_n = 0;
+      if constexpr (!RAGGED) {
+         const uint4* src = reinterpret_cast<const uint4*>(rows + (int64_t)qrow * (int64_t)(16 * CH));
+         constexpr int GD = CH <= 12 ? CH : 8;
+#pragma unroll 1
+         for (int k0 = 0; k0 < CH; k0 += GD) {
+            uint4 g4[GD];
+#pragma unroll
+            for (int i = 0; i < GD; ++i) g4[i] = (on && k0 + i < CH) ? src[k0 + i < CH ? k0 + i : 0] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < GD; ++i)
+               if (k0 + i < CH) tile[tile_cell(lane, k0 + i)] = g4[i];
+         }
+         const uint32_t* par = xpar + qp * 16u;
+         const uint8_t* blob = reinterpret_cast<const uint8_t*>(((uint64_t)par[9] << 32) | par[8]);
+         const FxpHeader* h = reinterpret_cast<const FxpHeader*>(blob);
+         const fxrow::ClassTables ct{reinterpret_cast<const uint16_t*>(blob + h->off_cls_page), reinterpret_cast<const uint16_t*>(blob + h->off_cls_pages),
+                                     reinterpret_cast<const uint16_t*>(blob + h->off_bound_cls), reinterpret_cast<const int32_t*>(blob + h->off_bounds), h->n_bounds};
+         const uint32_t sym_ffff = 128u + h->cls_ffff;
+         {   // on-device UTF-8 decode of this lane's row, in place, into the pattern's fast-path symbol ids
+            uint32_t prev = 0;
+            uint4 cur = tile[tile_cell(lane, 0)];
+            for (int k = 0; k < CH; ++k) {
+               const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
+               const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
+               tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
+               prev = cur.w;
+               cur = nxt;
+            }
+         }
+         const FastParams P{par[0], par[1], par[2], par[3], par[4], par[5], 0u, 0u, par[6]};
+         const int64_t base = (int64_t)par[7] * n;
+         auto emit = [&](const int64_t r, const bool live, const bool, const uint32_t flag, const int32_t fr, const int32_t tt, const bool) {
+            if (live) {
+               flags[base + r] = (uint8_t)flag;
+               if (SPANS) {
+                  from[base + r] = fr;
+                  to[base + r] = tt;
+               }
+            }
+         };
+         FxScanCtx scx{tile, tb, lane, L, Lr, false, false, 0u};
+         const uint2* tR = tabs + qp * tstride;
+         bool except = false;
+         (void)fx_scan_tile<CH, SPANS, false, 0, false, true, false, false, false>(scx, tR, tR + 256, nullptr, nullptr, P, (int64_t)qrow, on, false, except, emit);
+      }
+   };
    uint4 stage[CH];
    if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
    else load_tile<CH>(stage, rows, wave_global << 6, n, lane);
@@ -97,6 +172,8 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
          sc.pre_na = na;
       }
       const bool tile_hi = __builtin_amdgcn_ballot_w64((sc.pre_na & 0x80808080u) != 0) != 0;
+      uint64_t pend[FX_MULTI_MAX];   // per pattern: lanes whose row is an exception to be finished in this launch (wave-uniform)
+      uint32_t pend_any = 0;
       for (uint32_t p = 0; p < a.m; ++p) {
          const int64_t base = (int64_t)a.slot[p] * n;
          const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
@@ -131,8 +208,18 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
          }
          if (!bytes_here)
             (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
-         // rows these tables cannot answer: marked, and listed for the pattern's row-level fix-up (one atomic per tile that has any)
-         const bool listed = except && row_ok;
+         // rows these tables cannot answer: finished inside the launch when the pattern's class-level tables can decode them (queued;
+         // the queue is drained after this tile's last pattern when it would not take them), else marked and listed for the pattern's
+         // row-level fix-up (one atomic per tile that has any)
+         const bool inq_here = bytes_here && a.inq[p] != 0u;
+         if (inq_here) {
+            const uint64_t qm = __builtin_amdgcn_ballot_w64(except && row_ok);
+            if (qm != 0) {
+               pend_any |= 1u << p;
+               pend[p] = qm;
+            }
+         }
+         const bool listed = except && row_ok && !inq_here;
          const uint64_t em = __builtin_amdgcn_ballot_w64(listed);
          if (em != 0) {
             uint32_t wbase = 0;
@@ -144,7 +231,23 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
             }
          }
       }
+      // this tile's exception rows: into the wave's queue (the tile is finished for every pattern: a drain may overwrite it)
+      if (pend_any != 0u) {
+         for (uint32_t p = 0; p < a.m; ++p) {
+            if (!((pend_any >> p) & 1u)) continue;
+            const uint64_t qm = pend[p];
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(qm);
+            if (xq_n + cnt > 64u) drain();
+            if ((qm >> lane) & 1ull) {
+               const uint32_t slot = xq_n + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull));
+               xq[slot] = (uint32_t)row;
+               xq[64u + slot] = p;
+            }
+            xq_n += cnt;
+         }
+      }
    }
+   drain();
    // one plain store per wave and pattern (the value only gates the pattern's pass over deferred tiles)
    if (lane == 0)
       for (uint32_t p = 0; p < a.m; ++p)
@@ -154,8 +257,8 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
 // waves per block: 8 when that keeps more waves on a CU than blocks of 4 (the tables are stored once per block)
 template <int CH>
 hipError_t launch_multi(const uint8_t* rows, int64_t n, const FxMultiArgs& a, uint8_t* flags, int32_t* from, int32_t* to, uint32_t Lr, hipStream_t st) {
-   const size_t tab_b = (size_t)a.m * (a.any_bytes ? 8192 : 4096);
-   const size_t t4 = (size_t)4 * 64 * (CH + 1) * 16 + tab_b, t8 = (size_t)8 * 64 * (CH + 1) * 16 + tab_b;
+   const size_t tab_b = (size_t)a.m * (a.any_bytes ? 8192 : 4096), xb = a.any_bytes ? (size_t)FX_MULTI_MAX * 64 : 0;   // (+ per wave 512 B of queue)
+   const size_t t4 = (size_t)4 * 64 * (CH + 1) * 16 + tab_b + (a.any_bytes ? 4 * 512 : 0) + xb, t8 = (size_t)8 * 64 * (CH + 1) * 16 + tab_b + (a.any_bytes ? 8 * 512 : 0) + xb;
    const size_t cap = 160 * 1024;
    const int w4 = t4 <= cap ? 4 * (int)(cap / t4) : 0, w8 = t8 <= cap ? 8 * (int)(cap / t8) : 0;
    if (w4 == 0 && w8 == 0) return hipErrorInvalidValue;   // (the caller bounds m by multi_max_patterns)
@@ -195,7 +298,7 @@ hipError_t launch_multi(const uint8_t* rows, int64_t n, const FxMultiArgs& a, ui
 }
 // how many patterns one launch can take for rows of this chunk count (tables + at least four tiles in 160 KB of LDS)
 static inline int multi_max_patterns(int ch, bool any_bytes = false) {
-   const size_t t4 = (size_t)4 * 64 * (ch + 1) * 16;
+   const size_t t4 = (size_t)4 * 64 * (ch + 1) * 16 + (any_bytes ? 4 * 512 + FX_MULTI_MAX * 64 : 0);
    int m = (int)((160 * 1024 - t4) / (any_bytes ? 8192 : 4096));
    return m > FX_MULTI_MAX ? FX_MULTI_MAX : (m < 0 ? 0 : m);
 }

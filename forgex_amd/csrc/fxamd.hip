@@ -671,6 +671,7 @@ struct SharedFirstPass {
    uint32_t* worklist = nullptr;
    uint32_t defer_tiles = 0;
    bool bytes_in_shared = false;   // the shared pass scans tiles with bytes >= 0x80 with this pattern's byte-level tables: no pass over deferred tiles
+   bool exc_in_shared = false;     // ... and finishes the exception rows of those scans itself (class-level tables that decode): no follow-up at all
 };
 static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
                          uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode = 0u, int first_pass = FX_FP_OWN,
@@ -820,6 +821,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
          // (a shared first pass that scanned those tiles itself has deferred none: only its exception rows are left)
          if (first_pass == FX_FP_DONE && shared && shared->bytes_in_shared) {
+            if (shared->exc_in_shared) {   // nothing was deferred, nothing was listed
+               p->last_path = 8;
+               return FXAMD_OK;
+            }
          } else if (is_match) FX_HIP(match_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
          else FX_HIP(fast_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
          p->last_path = 8;
@@ -1241,6 +1246,45 @@ int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, in
    return FXAMD_OK;
 }
 
+// Side streams for the per-pattern follow-up passes of a shared first pass: each is a small, latency-bound launch (a gated pass over
+// a pattern's exception rows), so the patterns' follow-ups run side by side -- forked from the caller's stream by an event, joined back
+// by one event per pattern -- instead of one after the other (6 UTF-8 patterns on config 4's rows: 6 x ~40 us in a row otherwise).
+struct SideStreams {
+   int device = -1;
+   hipEvent_t fork = nullptr;
+   std::vector<hipStream_t> streams;
+   std::vector<hipEvent_t> joined;
+};
+static std::mutex g_side_mu;   // held while a fork / join is enqueued (the events are shared)
+static std::vector<SideStreams*> g_side;
+static SideStreams* side_streams(int dev, size_t k) {   // (g_side_mu held)
+   SideStreams* ss = nullptr;
+   for (SideStreams* x : g_side)
+      if (x->device == dev) ss = x;
+   if (!ss) {
+      ss = new (std::nothrow) SideStreams();
+      if (!ss) return nullptr;
+      ss->device = dev;
+      if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) {
+         delete ss;
+         return nullptr;
+      }
+      g_side.push_back(ss);
+   }
+   while (ss->streams.size() < k) {
+      hipStream_t s = nullptr;
+      hipEvent_t e = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+         (void)hipStreamDestroy(s);
+         return nullptr;
+      }
+      ss->streams.push_back(s);
+      ss->joined.push_back(e);
+   }
+   return ss;
+}
+
 // m patterns over the same device-resident rows: results pattern-major ([m][n]) -- the elemental operators with an ARRAY of patterns
 // (forgex.F90:74 / :163) against one batch.  Patterns on the 8-state tile tables (rows of up to 256 bytes) share ONE pass over the
 // rows, a group of up to multi_max_patterns() per launch of fx_search_multi; every other pattern runs its own pipeline.
@@ -1330,6 +1374,10 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          if (obs[(size_t)slot] != 0) {
             a.fpb[a.m] = params_of(p->prog.hdr(), obs[(size_t)slot], true);
             shs[k - g0].bytes_in_shared = true;
+            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && !std::getenv("FXAMD_MULTI_NO_INQ")) {
+               a.inq[a.m] = 1u;
+               shs[k - g0].exc_in_shared = true;
+            }
          }
          a.any_bytes = any_bytes ? 1u : 0u;
          ++a.m;
@@ -1355,11 +1403,34 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       }
       // every pattern's own follow-up passes (tiles it deferred, rows it listed): gated kernels, empty on pure-ASCII batches.  They
       // use the counter words and the worklist PREPARE chose (carried in `shs`, not recomputed).
+      // (side by side on side streams when the batch may hold rows for them -- some pattern scans UTF-8 tiles in the shared pass or
+      //  defers them; the scratch -- counter words, worklist -- is the one PREPARE chose on the caller's stream)
+      std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
+      SideStreams* ss = nullptr;
+      if (!std::getenv("FXAMD_MULTI_SERIAL")) {
+         side_lock.lock();
+         ss = side_streams(dev, g1 - g0);
+         if (ss && hipEventRecord(ss->fork, st) != hipSuccess) ss = nullptr;
+         if (!ss) {
+            (void)hipGetLastError();
+            side_lock.unlock();
+         }
+      }
       for (size_t k = g0; k < g1; ++k) {
          fxamd_program* p = progs[fused[k]];
          const int64_t slot = fused[k];
+         hipStream_t fs = st;
+         if (ss) {
+            fs = ss->streams[k - g0];
+            FX_HIP(hipStreamWaitEvent(fs, ss->fork, 0));
+         }
          rc = enqueue_batch(p, blobs[k - g0], scs[k - g0], d_rows, n, row_len, d_flags + slot * n, d_from ? d_from + slot * n : nullptr,
-                            d_to ? d_to + slot * n : nullptr, st, 0u, FX_FP_DONE, &shs[k - g0]);
+                            d_to ? d_to + slot * n : nullptr, fs, 0u, FX_FP_DONE, &shs[k - g0]);
+         if (ss) {   // joined back whatever happened: nothing of this call may stay detached from the caller's stream
+            const hipError_t e1 = hipEventRecord(ss->joined[k - g0], fs);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, ss->joined[k - g0], 0) : e1;
+            if (e2 != hipSuccess && rc == FXAMD_OK) rc = hip_fail(e2);
+         }
          if (rc != FXAMD_OK) return rc;   // (the shared first pass ran: the counter groups are consistent)
          p->last_path = 15;   // first pass shared with other patterns
          done[(size_t)slot] = 1;

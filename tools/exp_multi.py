@@ -19,8 +19,9 @@ sets = {
     "2 on the 8-state tables": [rb"[a-z]+\d+", rb"(ab|cd)+\d"],
 }
 if cfg == "cfg4":   # UTF-8 rows: the shared pass scans them with the patterns' byte-level tables (FXAMD_MULTI_NO_BYTES=1: defers them instead)
-    sets = {"6 UTF-8 patterns": [synth.PATTERNS["cfg4"].encode(), "[ぁ-ん]+".encode(), "[α-ω][ぁ-ん]".encode(), "ん[α-ω]+".encode(), rb"[a-z]+",
-                                 "(α|β|γ)[ぁ-ん].".encode()]}
+    sets["6 UTF-8 patterns"] = [synth.PATTERNS["cfg4"].encode(), "[ぁ-ん]+".encode(), "[α-ω][ぁ-ん]".encode(), "ん[α-ω]+".encode(), rb"[a-z]+",
+                                 "(α|β|γ)[ぁ-ん].".encode()]
+    sets["5 UTF-8 patterns whose tables decode"] = [synth.PATTERNS["cfg4"].encode(), "[ぁ-ん]+".encode(), "[α-ω][ぁ-ん]".encode(), rb"[a-z]+", "(α|β|γ)[ぁ-ん].".encode()]
 
 
 def rate(fn, reps=20):
