@@ -1313,6 +1313,11 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
              fast_scheme(h, d_rows, row_len) == 0)
             fused.push_back(i);
       }
+   // The shared pass pays where a tile is small enough for full occupancy next to m patterns' tables -- rows of up to 128 bytes: 6 patterns
+   // over 100 M x 128 B 15.4 ms against 16.9 ms pattern by pattern -- and LOSES on longer rows, whose single-pattern kernels run at more
+   // waves per SIMD (half-row staging at 256 bytes: 3.67 against 3.21 ms; config 4's UTF-8 rows: 0.68 against 0.58 ms;
+   // tools/exp_multi.py, gpurun call r03_c11): those run one pipeline per pattern.  FXAMD_MULTI_ALWAYS=1: test hook.
+   if (row_len > 128 && !std::getenv("FXAMD_MULTI_ALWAYS")) fused.clear();
    const int ch = tile_chunks(row_len);
    // byte-level tables in the shared pass (nibble format; 8 KB of LDS per pattern then): when some fused pattern has them for these rows
    std::vector<int> obs((size_t)m, 0);
@@ -1374,7 +1379,10 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          if (obs[(size_t)slot] != 0) {
             a.fpb[a.m] = params_of(p->prog.hdr(), obs[(size_t)slot], true);
             shs[k - g0].bytes_in_shared = true;
-            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && !std::getenv("FXAMD_MULTI_NO_INQ")) {
+            // (finishing the exception rows inside the shared pass -- one mixed-pattern queue per wave -- is built and tested but OFF: a
+            //  drained row decodes through its pattern's class map in GLOBAL memory, there is no LDS left for six of them, and the
+            //  pass got slower: 0.898 against 0.750 ms for 6 UTF-8 patterns on config 4's rows; FXAMD_MULTI_INQ=1 turns it on)
+            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && std::getenv("FXAMD_MULTI_INQ")) {
                a.inq[a.m] = 1u;
                shs[k - g0].exc_in_shared = true;
             }

@@ -110,8 +110,9 @@ int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, in
 
 /* m patterns against the same device-resident rows (the reference's elemental operators accept an ARRAY of patterns,
  * src/forgex.F90:74, :163): progs[i] fills d_flags[i*n .. i*n+n) (and d_from / d_to likewise).  Patterns whose automata fit the
- * 8-state tile tables share ONE pass over rows of up to 256 bytes (up to 8 patterns per launch, their tables side by side in LDS:
- * the rows are read from HBM once); every other pattern runs its own pipeline, enqueued on the same stream.  A handle may appear more
+ * 8-state tile tables share ONE pass over rows of up to 128 bytes (up to 8 patterns per launch, their tables side by side in LDS:
+ * the rows are read from HBM once; on longer rows one pipeline per pattern is faster and is what runs); every other pattern runs
+ * its own pipeline, enqueued on the same stream.  A handle may appear more
  * than once (identical patterns share one cached program): it is computed once and its results are copied to its other slots. */
 int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8_t* d_rows, int64_t n, int64_t row_len,
                              uint8_t* d_flags, int32_t* d_from, int32_t* d_to, void* hip_stream);
@@ -149,7 +150,8 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
  * one-launch kernel over the tiles that pass left.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
- * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_NO_INQ, FXAMD_MULTI_SERIAL.) */
+ * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,
+ * FXAMD_MULTI_ALWAYS.) */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);

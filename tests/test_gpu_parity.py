@@ -606,7 +606,7 @@ def test_prefix_and_suffix_literal_patterns_on_tile_kernel(fx):
 
 
 @pytest.mark.parametrize("shape", ["cfg3", "cfg4", "cfg2-ragged", "cfg5-many"])
-def test_many_patterns_over_one_batch(fx, shape):
+def test_many_patterns_over_one_batch(fx, shape, monkeypatch):
     """fxamd_match_multi_device: an array of patterns against the same rows, results pattern-major.  Patterns on the 8-state tile
     tables share ONE pass over the rows (fx_search_multi, last_path 15) -- pure-ASCII rows, UTF-8 rows with broken sequences (tiles
     deferred to each pattern's own passes), ragged row lengths, bordered prefix literals (rows listed for the fix-up), more patterns
@@ -614,6 +614,7 @@ def test_many_patterns_over_one_batch(fx, shape):
     import torch
     from forgex_amd import synth
     dev = torch.device("cuda")
+    monkeypatch.setenv("FXAMD_MULTI_ALWAYS", "1")   # (rows longer than 128 bytes take one pipeline per pattern by default: the shared pass is slower there)
     pats = [rb"[a-z]+\d+", rb"\d{3}-\d{4}", rb"zz+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d"]
     if shape == "cfg3":
         rows = synth.batch("cfg3", 0, 20000, dev)
@@ -650,6 +651,7 @@ def test_many_patterns_utf8_tiles_in_the_shared_pass(fx, monkeypatch):
     from forgex_amd import synth
     dev = torch.device("cuda")
     pats = [synth.PATTERNS["cfg4"], "[ぁ-ん]+", "[α-ω][ぁ-ん]", "ん[α-ω]+", "[a-z]+", "(α|β|γ)[ぁ-ん]."]
+    monkeypatch.setenv("FXAMD_MULTI_ALWAYS", "1")   # (192-byte rows: the shared pass is not the default)
     g = torch.Generator().manual_seed(77)
     for bad_frac in (0.0, 0.03, 1.0):
         n = 1 << 15
@@ -672,6 +674,11 @@ def test_many_patterns_utf8_tiles_in_the_shared_pass(fx, monkeypatch):
         torch.cuda.synchronize()
         monkeypatch.delenv("FXAMD_MULTI_NO_BYTES", raising=False)
         assert torch.equal(f, f2) and torch.equal(a, a2) and torch.equal(b, b2), bad_frac
+        monkeypatch.setenv("FXAMD_MULTI_INQ", "1")   # exception rows finished inside the shared pass (mixed-pattern queue per wave)
+        f3, a3, b3 = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("FXAMD_MULTI_INQ", raising=False)
+        assert torch.equal(f, f3) and torch.equal(a, a3) and torch.equal(b, b3), bad_frac
         for i, p in enumerate(progs):
             f1, a1, b1 = p.match_device(rows)
             torch.cuda.synchronize()
@@ -699,6 +706,7 @@ def test_many_patterns_fuzz_groups(fx):
               b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
     dev = torch.device("cuda")
     shared = 0
+    os.environ["FXAMD_MULTI_ALWAYS"] = "1"   # (the shared pass at every row length, not only where it is the default)
     for _ in range(groups):
         pats = []
         while len(pats) < rng.randint(2, 10):
@@ -729,6 +737,7 @@ def test_many_patterns_fuzz_groups(fx):
             assert np.array_equal(f[i].cpu().numpy(), of), (pats, i, L, n, progs[i].last_path())
             assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), (pats, i, L, n, progs[i].last_path())
             assert np.array_equal(f2[i].cpu().numpy(), of), (pats, i, L, n, "flags only")
+    os.environ.pop("FXAMD_MULTI_ALWAYS", None)
     assert shared >= groups   # the shared pass did run (most generated patterns fit the 8-state tables)
 
 
@@ -1229,3 +1238,23 @@ def test_one_launch_calls_replay_from_a_hip_graph(fx):
             assert torch.equal(got[0], want[0]), (cfg, start)
             if spans:
                 assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (cfg, start)
+
+
+def test_many_patterns_default_dispatch_by_row_length(fx):
+    """By default the shared pass (`last_path` 15) takes rows of up to 128 bytes; longer rows run one pipeline per pattern (measured
+    faster: tools/exp_multi.py).  Same results either way."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    pats = [rb"[a-z]+\d+", rb"[0-9]$", rb"(ab|cd)+\d", rb"x[yz]+\d"]
+    for cfg, want_shared in (("cfg5", True), ("cfg2", True), ("cfg3", False), ("cfg4", False)):
+        rows = synth.batch(cfg, 0, 8192, dev)
+        progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+        f, a, b = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        paths = [p.last_path() for p in progs]
+        assert (paths.count(15) == len(pats)) == want_shared and (want_shared or 15 not in paths), (cfg, paths)
+        for i, p in enumerate(progs):
+            f1, a1, b1 = p.match_device(rows)
+            torch.cuda.synchronize()
+            assert torch.equal(f[i], f1) and torch.equal(a[i], a1) and torch.equal(b[i], b1), (cfg, pats[i])

@@ -43,4 +43,6 @@ print("%s %d rows: single pattern %.3f ms (path %d)  [FXAMD_NO_MULTI=%s FXAMD_MU
 for name, pats in sets.items():
     progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
     tm = rate(lambda: fx.match_many(progs, rows), reps=10)
-    print("  %-30s %.3f ms = %.2f x single   paths %s" % (name, tm * 1e3, tm / t1, [p.last_path() for p in progs]), flush=True)
+    paths = [p.last_path() for p in progs]
+    tf = rate(lambda: fx.match_many(progs, rows, spans=False), reps=10)
+    print("  %-38s spans %.3f ms = %.2f x single   flags only %.3f ms   paths %s" % (name, tm * 1e3, tm / t1, tf * 1e3, paths), flush=True)
