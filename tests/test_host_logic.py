@@ -434,3 +434,47 @@ def test_compile_cache_shares_and_releases_programs(built, monkeypatch):
     p = fx.Program(rb"cache[a-z]+\d+", fx.OP_SEARCH)
     q = fx.Program.from_blob(p.blob(), fx.OP_SEARCH)
     assert q._h.value != p._h.value and q.blob() == p.blob()
+
+
+def test_compile_cache_survives_concurrent_compile_free_churn(built):
+    """Handles are refcounted and shared through the compile cache; fxamd_program_free of the last user handle pins the cached program
+    while it looks at its scratch, and a concurrent fxamd_compile may evict it meanwhile (round 2's advisor finding: use after free).
+    Eight threads compile and free 150 distinct patterns -- more than the cache holds -- in different orders; every handle must report
+    its own pattern's status, and nothing may crash."""
+    import threading
+    import forgex_amd as fx
+    L = fx.lib()
+    pats = [(b"churn%d[a-z]+\\d{%d}" % (i, 1 + i % 5), i % 2) for i in range(150)] + [(b"(bad%d" % i, 0) for i in range(10)]
+    want = {}
+    for pat, op in pats:
+        h, st = ctypes.c_void_p(), ctypes.c_int32(0)
+        assert L.fxamd_compile(pat, len(pat), op, ctypes.byref(h), ctypes.byref(st)) == 0
+        want[(pat, op)] = st.value
+        L.fxamd_program_free(h)
+    errors = []
+
+    def worker(seed):
+        import random
+        rng = random.Random(seed)
+        held = []
+        for _ in range(3000):
+            pat, op = rng.choice(pats)
+            h, st = ctypes.c_void_p(), ctypes.c_int32(0)
+            if L.fxamd_compile(pat, len(pat), op, ctypes.byref(h), ctypes.byref(st)) != 0 or st.value != want[(pat, op)]:
+                errors.append((pat, op, st.value))
+                return
+            if L.fxamd_program_status(h) != want[(pat, op)]:
+                errors.append((pat, op, "status of the handle"))
+                return
+            held.append(h)
+            if len(held) > rng.randint(0, 6):
+                L.fxamd_program_free(held.pop(rng.randrange(len(held))))
+        for h in held:
+            L.fxamd_program_free(h)
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
