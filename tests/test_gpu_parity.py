@@ -1158,7 +1158,8 @@ def test_long_rows_last_bytes_of_a_tile(fx):
                 assert np.array_equal(fm, om), (pat, L, n, "match", np.flatnonzero(fm != om)[:5])
 
 
-def test_config_scale_rows_vs_real_reference_fixture(fx):
+@pytest.mark.parametrize("hook", ["", "FXAMD_MULTIPASS", "FXAMD_NO_A8", "FXAMD_NO_BYTE_DFA", "FXAMD_NO_W16", "FXAMD_NO_HALF", "FXAMD_FORCE_GENERAL"])
+def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
     """tests/golden/config_rows.tsv: the REAL reference's flag / from / to (recorded in the container by
     tests/golden/make_config_goldens.py through oracle/_ref/ref_driver) on 2000-6144 rows of each BASELINE config (first and last
     rows of the batch, every shard of config 5's 8-GPU partition, 1024 corrupted rows of config 4), 4096 invalid-UTF-8 mutations at
@@ -1168,6 +1169,11 @@ def test_config_scale_rows_vs_real_reference_fixture(fx):
     src/essential/utf8_m.f90:168-246."""
     import zlib
     import config_rows as cr
+    # (every pipeline against the reference's answers: the default dispatch, the multi-pass pipelines, byte-level tables without the
+    #  v_perm forward automaton, the in-LDS decode instead of byte-level tables, chain instead of nibble tables, whole-row instead of
+    #  half-row staging, the general kernel)
+    if hook:
+        monkeypatch.setenv(hook, "1")
     fix, crcs = cr.load_fixture(os.path.join(golden.GOLDEN, "config_rows.tsv"))
     n_rows = 0
     paths = {}
@@ -1187,7 +1193,12 @@ def test_config_scale_rows_vs_real_reference_fixture(fx):
         paths[name] = prog.last_path()
         n_rows += n
     # the BASELINE configs run on the tile kernels (one-launch kernel / half-row pipeline), not on the general kernel
-    assert paths["cfg3"] == 16 and paths["cfg2"] in (9, 10, 11, 12, 13, 14) and paths["cfg4"] in (10, 11) and paths["cfg5"] in (9, 10, 11), paths
+    if not hook:
+        assert paths["cfg3"] == 16 and paths["cfg2"] in (9, 10, 11, 12, 13, 14) and paths["cfg4"] in (10, 11) and paths["cfg5"] in (9, 10, 11), paths
+    elif hook == "FXAMD_FORCE_GENERAL":
+        assert set(paths.values()) == {2}, paths
+    elif hook == "FXAMD_MULTIPASS":
+        assert not set(paths.values()) & {9, 10, 11, 12, 13, 14}, paths
     cases = cr.probe_cases()
     blob = b"".join(p.encode() + b"\0" + op.encode() + t for p, op, t in cases)
     assert (zlib.crc32(blob) & 0xFFFFFFFF) == crcs["probes"]

@@ -1,0 +1,5 @@
+#!/bin/bash
+OUT=gpurun_out/r03_c12
+mkdir -p $OUT
+python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?"; tail -3 $OUT/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc $?"; grep -v amdgpu $OUT/smoke.log | tail -3
