@@ -1,4 +1,4 @@
-// fx_search_one: the `.in.` / regex search of fx_search_fast for rows of up to 256 bytes in ONE launch.
+// fx_search_one: a `.in.` / regex search -- or, with MATCH, a `.match.` -- over rows of up to 256 bytes in ONE launch.
 //
 // fx_search_fast needs up to three launches per call when rows may hold bytes >= 0x80 (first pass that DEFERS such tiles, a second
 // pass over them, a third over the exception rows), reads deferred tiles twice and pays for the empty gate launches on pure-ASCII
@@ -12,8 +12,12 @@
 //     tiles, the queued rows are GATHERED into a tile (lane r loads row queue[r] into its own cells), decoded in LDS and
 //     scanned with the class-level tables -- the decode pass of fx_search_fast's MODE 4, inside the same launch.
 // Programs whose class-level tables cannot decode UTF-8 (candidate-list driver programs) queue the rows their tables cannot answer
-// the same way and walk them with the general row procedure (GEN).  Rows longer than 256 bytes and `.match.` stay on
-// fx_search_fast / fx_match_fast and their multi-pass pipeline.
+// the same way and walk them with the general row procedure (GEN).  Rows longer than 256 bytes stay on fx_search_fast / fx_match_fast
+// and their multi-pass pipeline; 256-byte rows on the 8-state tables take fx_search_fast's half-row first pass and this kernel (MARKED)
+// as its one gated follow-up.
+// Round 3: `.match.` (fx_match_tile), match compaction for short rows (DEFERQ: the exact start + forward pass of sparse tiles' hit rows
+// are finished 64 at a time from global memory), the aligned forward loop for long matches, and byte-level tables whose forward
+// automaton is in the v_perm format (BSCH 3, FXP_F_BYTE_A8).
 #pragma once
 #include "fx_tile.hpp"
 

@@ -1,7 +1,9 @@
 // libforgex_amd.so: HIP kernels (gfx950 / CDNA4) + the C ABI of include/forgex_amd.h.
 //
-// Two kernel families:
-//   fx_search_fast<CH>   (fx_tile.hpp, with fx_match_fast) the hot kernel.  One wavefront owns a tile of 64 consecutive rows
+// Kernel families (DESIGN.md §0 has the dispatch table, §4 the kernels):
+//   fx_search_one<CH>    (fx_one.hpp) a search or a `.match.` over rows of up to 256 bytes in ONE launch; fx_search_multi (fx_multi.hpp):
+//                        m patterns in one pass over rows of up to 128 bytes.  Same tile staging and table schemes as:
+//   fx_search_fast<CH>   (fx_tile.hpp, with fx_match_fast) the half-row kernel of the headline shape, long rows, literal search.  One wavefront owns a tile of 64 consecutive rows
 //                        (64 x 16*CH bytes, contiguous in HBM): 16-byte/lane coalesced buffer loads -> swizzled ds_write_b128
 //                        -> transposed ds_read_b128 so that lane r holds row r.  The per-byte state advance is
 //                        ONE ds_read_b64 of the fused byte table F[byte] (8 next-state bytes, independent of the
