@@ -47,6 +47,11 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FX_FWD_GB
 #define FX_FWD_GB 2
 #endif
+#ifndef FX_HALF4
+#define FX_HALF4 0   // the half-row kernel (256-byte rows, spans) tuned for FOUR waves per SIMD: a leaner backward loop (incremental max,
+                     // one chunk of LDS prefetch), the forward window's lookups 16 at a time, ONE shared end-of-row cell per wave
+                     // (8 KB + 16 B of tile per wave: four blocks per CU) -- 127 VGPRs, no scratch
+#endif
 #ifndef FX_HALF_WAVES
 #define FX_HALF_WAVES 3   // waves per SIMD the half-row kernel (256-byte rows, spans) is compiled for
 #endif
@@ -287,8 +292,19 @@ struct FxF<2> {
 // Right-to-left state chain over 8 bytes.  All four bytes of `state` carry the same state id (v_perm_b32 advances four
 // identical copies), so whole registers compare like ids and no masking is needed.  Hit states have the LARGEST ids, so
 // the group's "any hit" is max(states) >= hit_min: one v_max3_u32 per two bytes instead of a compare+select per byte.
-template <class F>
+// (LEAN: the running maximum instead of eight kept states -- four more v_max per group, five fewer live registers)
+template <class F, bool LEAN = false>
 __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state, const uint8_t* T) {
+   if constexpr (LEAN) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int i = 7; i >= 1; i -= 2) {
+         const uint32_t s1 = fxstep(f[i], state, T);
+         state = fxstep(f[i - 1], s1, T);
+         m = max(max(m, s1), state);
+      }
+      return m;
+   }
    uint32_t st[8];
 #pragma unroll
    for (int i = 7; i >= 0; --i) {
@@ -324,7 +340,7 @@ __device__ __forceinline__ uint32_t chain8_back_n(const F (&f)[8], uint32_t& sta
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
 // at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
 template <bool RAGGED, bool LONG = false>
-__device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L) {
+__device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L, const uint8_t* eor = nullptr) {
    if (LONG) {
       // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); any L >= 8
       if (p + 8u <= L) {
@@ -347,7 +363,9 @@ __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const ui
    if (!RAGGED) {
       // whole chunks: index L.. lives in the row's extra chunk column (NUL, then KILL symbols); anything further reads its KILL half
       const uint32_t pc = p < L + 8u ? p : L + 8u;   // p and L are multiples of 8
-      const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 8u));
+      // (eor: ONE end-of-row cell shared by the wave's rows instead of a chunk column of them)
+      const uint8_t* src = (eor != nullptr && pc >= L) ? eor + (pc & 8u) : tb + (tile_cell(lane, pc >> 4) << 4) + (pc & 8u);
+      const uint2 r = *reinterpret_cast<const uint2*>(src);
       lo = r.x;
       hi = r.y;
       return;
@@ -365,11 +383,11 @@ __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const ui
    hi = word(r.y, p + 4u);
 }
 template <bool RAGGED, bool LONG = false>
-__device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L) {
+__device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L, const uint8_t* eor = nullptr) {
    const uint32_t base = j & ~7u, sh = j & 7u;
    uint32_t d[10];
 #pragma unroll
-   for (int g = 0; g < 5; ++g) group_words<RAGGED, LONG>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L);
+   for (int g = 0; g < 5; ++g) group_words<RAGGED, LONG>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L, eor);
    const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
    uint32_t e[9];
 #pragma unroll
@@ -591,10 +609,10 @@ __device__ unsigned long long fx_stamp_acc[16];
 // (no end-of-row chunk column in LDS for the segment-walking kernels once their forward pass reads global memory only)
 template <int CH, bool SPANS, bool LONG>
 constexpr int fx_tile_cols() {
-   return (!LONG || (CH == 8 && SPANS && FX_DEFER_LONG == 0)) ? CH + 1 : CH;
+   return (!LONG || (CH == 8 && SPANS && FX_DEFER_LONG == 0 && FX_HALF4 == 0)) ? CH + 1 : CH;
 }
 template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
-__global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : 1) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+__global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : ((LONG && CH == 8 && SPANS && FX_HALF4 != 0) ? 4 : 1)) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
                                                         uint32_t Lr, uint32_t* __restrict__ clear_next, uint32_t* __restrict__ worklist) {
@@ -611,6 +629,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    // queued row: re-walks its hit group and walks forward, reading the row's bytes from global memory (L2: the tile was just read).
    // The tile pass itself stores their flag (a hit inside the text always yields a span: flag 1); from / to follow at the flush.
    constexpr bool DEFER = FX_DEFER_LONG != 0 && LONG && SPANS;
+   constexpr bool HALF4 = FX_HALF4 != 0 && HALFROW && SPANS && !DEFER;   // the four-waves-per-SIMD tuning of the half-row kernel (see FX_HALF4)
    static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 or 8, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
@@ -684,6 +703,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    // row is all-dead), so the forward pass reads "past the end" like any other position.  Written once, never overwritten.
    uint4* tile = tiles + wave * (64 * COLS);
    if constexpr (COLS > CH) tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   // HALF4: one shared end-of-row cell per wave behind the four tiles (the speculative forward pass on the half row in LDS reads it)
+   uint4* const eor_cell = tiles + 4 * 64 * COLS + wave;
+   if (HALF4 && lane == 0) *eor_cell = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   const uint8_t* const eor8 = HALF4 ? reinterpret_cast<const uint8_t*>(eor_cell) : nullptr;
    // rows of fewer WHOLE chunks than the instantiation has: their unused chunk columns hold the inert symbol 255 from here on
    // (the staging stores never touch them; the decode passes re-pad per tile because they rewrite the cells)
    const bool whole = RAGGED && (Lr & 15u) == 0u;
@@ -712,11 +735,12 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       constexpr bool FG = decltype(from_global)::value;
       if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) return;
       uint32_t o[8];
-      fetch32<RAGGED, FG>(o, src, lane, j, Lx);
+      const uint8_t* const eor = FG ? nullptr : eor8;
+      fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor);
 #ifndef FX_FWD_GB_LDS
 #define FX_FWD_GB_LDS 4
 #endif
-      constexpr int GB = (FG && DEFER) ? FX_FWD_GB : FX_FWD_GB_LDS;   // 8-symbol groups whose lookups are issued together (fewer in the flush: registers)
+      constexpr int GB = (FG && DEFER) ? FX_FWD_GB : (HALF4 ? 2 : FX_FWD_GB_LDS);   // 8-symbol groups whose lookups are issued together (fewer in the flush: registers)
       uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
       for (int gb = 0; gb < 4; gb += GB) {
@@ -760,11 +784,11 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
          uint32_t gb = j & ~7u;
          uint32_t t0[2], t1[2];
-         group_words<RAGGED, FG>(t0[0], t0[1], src, lane, gb, Lx);
-         group_words<RAGGED, FG>(t1[0], t1[1], src, lane, gb + 8u, Lx);
+         group_words<RAGGED, FG>(t0[0], t0[1], src, lane, gb, Lx, eor);
+         group_words<RAGGED, FG>(t1[0], t1[1], src, lane, gb + 8u, Lx, eor);
          do {
             uint32_t t2[2];
-            group_words<RAGGED, FG>(t2[0], t2[1], src, lane, gb + 16u, Lx);
+            group_words<RAGGED, FG>(t2[0], t2[1], src, lane, gb + 16u, Lx, eor);
             const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
             const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
             F f8[8];
@@ -925,7 +949,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
             constexpr bool WG = decltype(whole_groups)::value;
             F fa[8], fb[8];
             uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
-            if (CH >= 2) wn = tile[tile_cell(lane, CH - 2)];
+            if (CH >= 2 && !HALF4) wn = tile[tile_cell(lane, CH - 2)];
             lookup8(fa, wk.z, wk.w, tabR);
 #pragma unroll
             for (int k = CH - 1; k >= 0; --k) {
@@ -948,21 +972,22 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                __builtin_amdgcn_sched_barrier(0);
                if (nhi != 0u) {
                   const uint32_t entry = state;
-                  const uint32_t mx = nhi == 8u ? chain8_back(fa, state, TRp) : chain8_back_n(fa, state, TRp, nhi);
+                  const uint32_t mx = nhi == 8u ? chain8_back<F, HALF4>(fa, state, TRp) : chain8_back_n(fa, state, TRp, nhi);
                   gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k + 1) : gsel;
                   esel = mx >= fp.hit_min ? entry : esel;
                   asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
                }
                __builtin_amdgcn_sched_barrier(0);
                if (k >= 1) {
-                  wk = wn;
+                  if (HALF4) wk = tile[tile_cell(lane, k - 1)];   // (no second chunk of prefetch: registers)
+                  else wk = wn;
                   lookup8(fa, wk.z, wk.w, tabR);
-                  if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+                  if (k >= 2 && !HALF4) wn = tile[tile_cell(lane, k - 2)];
                }
                __builtin_amdgcn_sched_barrier(0);
                if (nlo != 0u) {
                   const uint32_t entry = state;
-                  const uint32_t mx = nlo == 8u ? chain8_back(fb, state, TRp) : chain8_back_n(fb, state, TRp, nlo);
+                  const uint32_t mx = nlo == 8u ? chain8_back<F, HALF4>(fb, state, TRp) : chain8_back_n(fb, state, TRp, nlo);
                   gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k) : gsel;
                   esel = mx >= fp.hit_min ? entry : esel;
                   asm volatile("" : "+v"(esel));
@@ -1416,7 +1441,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    // three with half-row staging), so that the last round fills the chip too
    // (the gated passes -- marked tiles, worklist -- usually find nothing to do: a grid of what is resident, so that an empty pass is
    //  one round of blocks that leave at once)
-   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH == 8 && Lr > 16u * CH) ? 256 * 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : 3) : 256 * 8));
+   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH == 8 && Lr > 16u * CH) ? 256 * 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : (FX_HALF4 != 0 ? 4 : 3)) : 256 * 8));
    if (blocks > cap) blocks = cap;
    // decode passes: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
@@ -1427,7 +1452,8 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
                           // half-row staging of 256-byte rows), first-pass / byte-level modes only
       if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 0)) {
          constexpr int CHN = SCH;
-         const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds;
+         const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds +
+                            ((FX_HALF4 != 0 && CH == 8 && spans) ? 64 : 0);   // (+ the four shared end-of-row cells)
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false, true>)
                                 : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
