@@ -48,9 +48,11 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #define FX_FWD_GB 2
 #endif
 #ifndef FX_HALF4
-#define FX_HALF4 0   // the half-row kernel (256-byte rows, spans) tuned for FOUR waves per SIMD: a leaner backward loop (incremental max,
+#define FX_HALF4 1   // the half-row kernel (256-byte rows, spans) tuned for FOUR waves per SIMD: a leaner backward loop (incremental max,
                      // one chunk of LDS prefetch), the forward window's lookups 16 at a time, ONE shared end-of-row cell per wave
-                     // (8 KB + 16 B of tile per wave: four blocks per CU) -- 127 VGPRs, no scratch
+                     // (8 KB + 16 B of tile per wave: four blocks per CU) -- 127 VGPRs, no scratch.  Measured against the three-wave
+                     // build (156 VGPRs) in one allocation, profiles/r03_half4_ab.txt: kernel 0.500 -> 0.484, 0.491 -> 0.486,
+                     // 0.472 -> 0.467 ms; the driver's protocol 0.524 -> 0.511, 0.522 -> 0.498, 0.511 -> 0.486 ms per step
 #endif
 #ifndef FX_HALF_WAVES
 #define FX_HALF_WAVES 3   // waves per SIMD the half-row kernel (256-byte rows, spans) is compiled for
