@@ -418,8 +418,8 @@ def main():
             traffic = json.load(open(tpath)).get(cfg)
         except Exception:
             traffic = None
-    if prog.last_path() == 16:   # 256-byte rows: first pass (the timed kernel; half-row staging when spans are asked for) + one gated follow-up
-        kname = "fx_search_fast<8, true, 0, 0, false, true> (half-row staging)" if spans else "fx_search_fast<16, false, 0, 0, false, false>"
+    if prog.last_path() == 16:   # 256- / 128-byte rows: first pass (the timed kernel; half-row staging when spans are asked for) + one gated follow-up
+        kname = ("fx_search_fast<%d, true, 0, 0, false, true> (half-row staging)" % (row_len // 32)) if spans else "fx_search_fast<16, false, 0, 0, false, false>"
     else:
         kname = ("fx_search_one<%d>" if one_launch else "fx_search_fast<%d>") % (row_len // 16)
     if whole_step and not one_launch:

@@ -949,10 +949,10 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
 }
 
 // the gated follow-up of the half-row first pass: 256-byte rows, 8-state class-level tables, marked tiles only
-template <int BSCH>
+template <int CH, int BSCH>
 hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
                              uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate) {
-   constexpr int CH = 16;
+   static_assert(CH == 16 || CH == 8, "follow-up of the half-row first pass: 256- or 128-byte rows");
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    const size_t static_b = 4096 + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64;
    const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
@@ -967,8 +967,8 @@ hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_bl
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
    }
-   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 256u, 0u, gate);
-   else hipLaunchKernelGGL((fx_search_one<CH, false, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 256u, 0u, gate);
+   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 16u * CH, 0u, gate);
+   else hipLaunchKernelGGL((fx_search_one<CH, false, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 16u * CH, 0u, gate);
    return hipGetLastError();
 }
 #define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*)

@@ -96,7 +96,7 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __r
    // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
    // (k_lo, k_hi) = (0, CH-1); the short last one has k_hi = its last (possibly partial) chunk and the chunks behind it repeat that
    // one (never walked).  Rows start at any byte: the pieces are unaligned buffer loads.
-   static_assert(CH == 16 || CH == 8, "segment walker: 16 or 8 chunks per segment");
+   static_assert(CH == 16 || CH == 8 || CH == 4, "segment walker: 16, 8 or 4 chunks per segment");
    const int64_t rows_left = n - row0;
    // (extent rounded up to whole dwords, as in load_tile)
    const uint32_t valid = !enable ? 0u : ((rows_left >= 64 ? 64u * Lr : (rows_left > 0 ? (uint32_t)rows_left * Lr : 0u)) + 3u) & ~3u;
@@ -611,10 +611,10 @@ __device__ unsigned long long fx_stamp_acc[16];
 // (no end-of-row chunk column in LDS for the segment-walking kernels once their forward pass reads global memory only)
 template <int CH, bool SPANS, bool LONG>
 constexpr int fx_tile_cols() {
-   return (!LONG || (CH == 8 && SPANS && FX_DEFER_LONG == 0 && FX_HALF4 == 0)) ? CH + 1 : CH;
+   return (!LONG || (CH <= 8 && SPANS && FX_DEFER_LONG == 0 && FX_HALF4 == 0)) ? CH + 1 : CH;
 }
 template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
-__global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : ((LONG && CH == 8 && SPANS && FX_HALF4 != 0) ? 4 : 1)) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+__global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : ((LONG && CH <= 8 && SPANS && FX_HALF4 != 0) ? 4 : 1)) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
                                                         uint32_t Lr, uint32_t* __restrict__ clear_next, uint32_t* __restrict__ worklist) {
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    constexpr uint32_t SEGB = 16u * CH;                   // bytes of one LDS tile row = one segment of a long row
    const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // segments per row, the last one shorter when Lr % SEGB != 0
    constexpr bool ragged = RAGGED;
-   constexpr bool HALFROW = LONG && CH == 8;   // 256-byte rows staged as two 128-byte halves (the launcher guarantees Lr == 256)
+   constexpr bool HALFROW = LONG && (CH == 8 || CH == 4);   // 256-byte (128-byte) rows staged as two halves of CH chunks (the launcher guarantees Lr == 32 * CH)
    // Match compaction (segment-walking kernels with spans): the exact start and the forward pass are per-ROW work that only rows with a
    // hit need, but a wave pays for them per TILE -- at full price when one lane in 64 has a hit.  Such rows are queued (row, hit group,
    // state entering it) in a per-wave LDS queue instead, and when 64 have gathered -- and once more at the end -- every lane takes one
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    // The tile pass itself stores their flag (a hit inside the text always yields a span: flag 1); from / to follow at the flush.
    constexpr bool DEFER = FX_DEFER_LONG != 0 && LONG && SPANS;
    constexpr bool HALF4 = FX_HALF4 != 0 && HALFROW && SPANS && !DEFER;   // the four-waves-per-SIMD tuning of the half-row kernel (see FX_HALF4)
-   static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 or 8, first-pass / byte-level modes");
+   static_assert(!LONG || ((CH == 16 || CH == 8 || CH == 4) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, 8 or 4, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
@@ -1443,7 +1443,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    // three with half-row staging), so that the last round fills the chip too
    // (the gated passes -- marked tiles, worklist -- usually find nothing to do: a grid of what is resident, so that an empty pass is
    //  one round of blocks that leave at once)
-   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH == 8 && Lr > 16u * CH) ? 256 * 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : (FX_HALF4 != 0 ? 4 : 3)) : 256 * 8));
+   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH <= 8 && Lr > 16u * CH) ? 256 * 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : (FX_HALF4 != 0 ? 4 : 3)) : 256 * 8));
    if (blocks > cap) blocks = cap;
    // decode passes: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
@@ -1455,7 +1455,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
       if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 0)) {
          constexpr int CHN = SCH;
          const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds +
-                            ((FX_HALF4 != 0 && CH == 8 && spans) ? 64 : 0);   // (+ the four shared end-of-row cells)
+                            ((FX_HALF4 != 0 && CH <= 8 && spans) ? 64 : 0);   // (+ the four shared end-of-row cells)
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false, true>)
                                 : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {

@@ -15,8 +15,8 @@ FX_ONE_COMBOS(FX_Y, FX_INST_CH)
 template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;
 
 #if FX_INST_CH == 16
-template hipError_t launch_one_marked<0> FX_ONE_MARKED_SIG;
-template hipError_t launch_one_marked<1> FX_ONE_MARKED_SIG;
-template hipError_t launch_one_marked<2> FX_ONE_MARKED_SIG;
-template hipError_t launch_one_marked<3> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 0> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 1> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 2> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 3> FX_ONE_MARKED_SIG;
 #endif

@@ -27,10 +27,13 @@ FX_TILE_ALL(FX_X)
 #define FX_X(CH, S, B, G) extern template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_ALL(FX_X)
 #undef FX_X
-extern template hipError_t launch_one_marked<0> FX_ONE_MARKED_SIG;
-extern template hipError_t launch_one_marked<1> FX_ONE_MARKED_SIG;
-extern template hipError_t launch_one_marked<2> FX_ONE_MARKED_SIG;
-extern template hipError_t launch_one_marked<3> FX_ONE_MARKED_SIG;
+#define FX_Z(CH)                                                            \
+   extern template hipError_t launch_one_marked<CH, 0> FX_ONE_MARKED_SIG;   \
+   extern template hipError_t launch_one_marked<CH, 1> FX_ONE_MARKED_SIG;   \
+   extern template hipError_t launch_one_marked<CH, 2> FX_ONE_MARKED_SIG;   \
+   extern template hipError_t launch_one_marked<CH, 3> FX_ONE_MARKED_SIG;
+FX_Z(16)
+#undef FX_Z
 extern template hipError_t launch_multi<1> FX_MULTI_SIG;
 extern template hipError_t launch_multi<2> FX_MULTI_SIG;
 extern template hipError_t launch_multi<3> FX_MULTI_SIG;
@@ -455,8 +458,13 @@ struct PassOpts {
    bool half = false;              // first pass over 256-byte rows with the 8-state tables: stage HALF rows (CH = 8 segment walker)
 };
 // 256-byte rows on the 8-state tables: half-row staging (8 KB of LDS per wave: three waves per SIMD instead of two)
-static bool half_rows(int scheme, int64_t row_len) {
-   const bool off = std::getenv("FXAMD_NO_HALF") != nullptr;   // (test / experiment hook: 256-byte rows on the one-launch kernel)
+// (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
+//  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14)
+static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool spans = true, uint32_t out_mode = 0u) {
+   (void)h;
+   (void)spans;
+   (void)out_mode;
+   const bool off = std::getenv("FXAMD_NO_HALF") != nullptr;   // (test / experiment hook: these rows on the one-launch kernel)
    return !off && scheme == 0 && row_len == 256;
 }
 
@@ -682,7 +690,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(sc0, row_len)) && !std::getenv("FXAMD_MULTIPASS");
+                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(h, sc0, row_len, true, out_mode)) && !std::getenv("FXAMD_MULTIPASS");
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -721,7 +729,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // The counter groups alternate between calls, and it is a call's FIRST-PASS kernel that zeroes the other group for the call
       // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
-      const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len)) &&
+      const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(h, scheme, row_len, d_from != nullptr, out_mode)) &&
                               !std::getenv("FXAMD_MULTIPASS");
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
@@ -735,7 +743,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
       // 256-byte rows on the 8-state tables keep the multi-pass pipeline: its first pass stages HALF rows when spans are asked for
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
-      const bool keep_multipass = !is_match && half_rows(scheme, row_len);
+      const bool keep_multipass = !is_match && half_rows(h, scheme, row_len, d_from != nullptr, out_mode);
       first.half = keep_multipass && d_from != nullptr;
       if (one_launch) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
@@ -807,10 +815,15 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
          const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
-         if (ob == 3) FX_HIP(launch_one_marked<3>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
-         else if (ob == 2) FX_HIP(launch_one_marked<2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
-         else if (ob == 1) FX_HIP(launch_one_marked<1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
-         else FX_HIP(launch_one_marked<0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr));
+#define FX_MARKED(CH)                                                                                                              \
+   {                                                                                                                                  \
+      if (ob == 3) FX_HIP((launch_one_marked<CH, 3>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));          \
+      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
+      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
+      else FX_HIP((launch_one_marked<CH, 0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));                  \
+   }
+         FX_MARKED(16)
+#undef FX_MARKED
          p->last_path = 16;
          return FXAMD_OK;
       }
@@ -1101,7 +1114,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   po.half = half_rows(scheme, row_len) && d_from != nullptr;
+   po.half = half_rows(h, scheme, row_len, d_from != nullptr) && d_from != nullptr;
    if (scheme != 0 && bytes && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
