@@ -880,18 +880,25 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    const bool spans = from && to;   // (packed results: `from` / `to` are the narrow arrays)
    // Grid: with exception queues every wave ends with one pass over its queued rows, so the grid is sized to what is
    // RESIDENT (one tail per CU slot, not one per 1/8 of it); without them the usual cap with grid-stride beyond it.
+   // Grid: whole rounds of what is RESIDENT (asked of the runtime per kernel and LDS size).  How many rounds: a block costs its table
+   // staging and a first tile without overlap, and with exception queues every wave ends with one pass over its queued rows -- against
+   // that, a finer grid lets the hardware's block scheduler balance the tail.  Measured (profiles/r03_grid_ab.txt, interleaved
+   // repetitions in one allocation): config 5's shard (1.6 GB) 372-374 us with one round, 352-366 us with four, 356-367 us with seven or eight;
+   // configs 2 and 4 (67 / 201 MB: 19 / 101 us in all) are best with ONE round (config 4 with six: 144 us).  So: one round per
+   // 300 MB of rows.  FXAMD_ONE_GRID = blocks per CU in the grid, FXAMD_ONE_ROUND_MB = MB per round: experiment hooks.
    auto cap_grid = [&](const void* fn) {
       static const int env_mult = std::getenv("FXAMD_ONE_GRID") ? std::atoi(std::getenv("FXAMD_ONE_GRID")) : 0;
       const size_t per_block = lds + static_b;
       int64_t by_lds = per_block > 0 ? (int64_t)((160 * 1024) / per_block) : 8;   // blocks per CU by LDS alone (used when the runtime cannot say)
       if (by_lds < 1) by_lds = 1;
       if (by_lds > 8) by_lds = 8;
-      int64_t resident = 8;
-      if (env_mult <= 0 && (BSCH != 0 || GEN)) {
-         resident = resident_blocks_per_cu(fn, lds, (int)by_lds);
-         if (resident > 8) resident = 8;
-      }
-      const int64_t cap = 256 * (env_mult > 0 ? env_mult : resident);
+      int64_t resident = resident_blocks_per_cu(fn, lds, (int)by_lds);
+      if (resident > 8) resident = 8;
+      static const int env_mb = std::getenv("FXAMD_ONE_ROUND_MB") ? std::atoi(std::getenv("FXAMD_ONE_ROUND_MB")) : 0;
+      int64_t rounds = (n * (int64_t)Lr) / ((int64_t)(env_mb > 0 ? env_mb : 300) << 20);
+      if (rounds < 1) rounds = 1;
+      if (rounds > 64) rounds = 64;
+      const int64_t cap = 256 * (env_mult > 0 ? env_mult : resident * rounds);
       if (blocks > cap) blocks = cap;
    };
    if (is_match) {   // `.match.`: one verdict per row, no span

@@ -1440,11 +1440,26 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    const int64_t n_tiles = grid_tiles > 0 ? grid_tiles : (n + 63) >> 6;   // (worklist pass: the host only knows an upper bound)
    int64_t blocks = (n_tiles + 3) / 4;
    // grid-stride beyond the cap (guide §6 G11); a whole number of rounds of what is resident (two blocks per CU at 256-byte rows,
-   // three with half-row staging), so that the last round fills the chip too
+   // four with half-row staging), so that the last round fills the chip too.  Half-row kernel: TWELVE rounds (12288 blocks, three tiles
+   // per wave at 10 M rows) -- measured in one allocation, five interleaved repetitions each (profiles/r03_half4_ab.txt): 3 rounds
+   // 0.506 ms, 8: 0.478, 12: 0.474, 16: 0.482: the hardware's block scheduler balances the tail better than a long static stride
    // (the gated passes -- marked tiles, worklist -- usually find nothing to do: a grid of what is resident, so that an empty pass is
    //  one round of blocks that leave at once)
-   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH <= 8 && Lr > 16u * CH) ? 256 * 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : (FX_HALF4 != 0 ? 4 : 3)) : 256 * 8));
-   if (blocks > cap) blocks = cap;
+   const int64_t cap = MODE == 4 ? 256 : ((MODE == 1 || MODE == 3) ? 256 * 2 : ((CH <= 8 && Lr > 16u * CH) ? 256 * (FX_HALF4 != 0 && FX_DEFER_LONG == 0 ? 4 * 12 : 3 * (FX_DEFER_LONG != 0 ? FX_HALF_WAVES : 3)) : 256 * 8));
+   int64_t gcap = cap;
+   if (CH <= 8 && Lr > 16u * CH && MODE == 0 && FX_HALF4 != 0 && FX_DEFER_LONG == 0) {
+      // what a block costs (table staging, first tile without overlap) against what a finer grid gains at the tail: a round of about
+      // 50 us (11 rounds at 10 M rows; measured: 3 rounds 0.506 ms, 8: 0.478, 12: 0.474, 16: 0.482); FXAMD_HALF_ROUNDS: experiment hook
+      static const int env_rounds = std::getenv("FXAMD_HALF_ROUNDS") ? std::atoi(std::getenv("FXAMD_HALF_ROUNDS")) : 0;
+      int64_t rounds = env_rounds;
+      if (rounds <= 0) {   // one round per 225 MB of rows: a round of about 50 us (the same rule as the one-launch kernel's, fx_one.hpp)
+         rounds = (n * (int64_t)Lr) / ((int64_t)225 << 20);
+         if (rounds < 3) rounds = 3;
+         if (rounds > 64) rounds = 64;
+      }
+      gcap = (int64_t)256 * 4 * rounds;
+   }
+   if (blocks > gcap) blocks = gcap;
    // decode passes: the BMP class map rides behind the tiles when it fits
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * (CH + 1) * 16 + chain_bytes + map_lds;   // + the end-of-row chunk column

@@ -151,7 +151,7 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * one-launch kernel over the tiles that pass left.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
  * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,
- * FXAMD_MULTI_ALWAYS.) */
+ * FXAMD_MULTI_ALWAYS; grid experiments: FXAMD_ONE_GRID, FXAMD_ONE_ROUND_MB, FXAMD_HALF_ROUNDS.) */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);
 int fxamd_device_count(void);

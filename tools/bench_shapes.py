@@ -33,6 +33,16 @@ SHAPES = {
                      [r"[a-z]+\d+", r"\d+[a-z]", r"[a-z]+ \d", r"q[a-z]*\d", r"\d\d+", r"[a-z]\d[a-z]"], "cfg3", None, 10_000_000, False, True),
     "packed_cfg5":  ("config 5's shard with PACKED results (1 bit + 2 x uint8 per row, written by the search kernel)", "search", [r"[a-z]+\d+"], "cfg5", None, 12_500_000, True, True),
     "packed_cfg3":  ("config 3 with PACKED results (half-row pipeline + fx_pack)", "search", [r"[a-z]+\d+"], "cfg3", None, 10_000_000, True, True),
+    # config 4's text at other row lengths (whole characters: the first L // 5 five-byte slots of a config-4 row, blank-padded): the same automata at
+    # other occupancies (rows of 64 / 96 / 128 / 192 bytes: 4 / 3 / 3 / 2 blocks of the one-launch kernel per CU)
+    "utf8_64":      ("config 4's pattern and text in rows of 64 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 64), 3 << 20, False, True),
+    "utf8_96":      ("config 4's pattern and text in rows of 96 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 96), 2 << 20, False, True),
+    "utf8_128":     ("config 4's pattern and text in rows of 128 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 128), 3 << 19, False, True),
+    "utf8_192":     ("config 4 itself (rows of 192 B)", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 192), 1 << 20, False, True),
+    "utf8_192_clean": ("config 4 without its corrupted rows (each replaced by its predecessor): what the exception path costs", "search", ["[α-ωぁ-ん]+"], "cfg4", ("clean", 192), 1 << 20, False, True),
+    "utf8_192_flags": ("config 4, flags only", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 192), 1 << 20, False, False),
+    "utf8_128_flags": ("config 4's text in rows of 128 B, flags only", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 128), 3 << 19, False, False),
+    "utf8_64_flags": ("config 4's text in rows of 64 B, flags only", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 64), 3 << 20, False, False),
     "ragged_255":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 255 B (ragged loader)", "search", [r"[a-z]+\d+"], "cfg3", 255, 10_000_000, False, True),
 }
 
@@ -57,6 +67,20 @@ def main():
     if view is None:
         L = L0
         rows = synth.batch(cfg, 0, n, dev)
+    elif isinstance(view, tuple):
+        L = view[1]
+        keep = (L // 5) * 5 if L < L0 else L0
+        full = synth.batch(cfg, 0, n, dev)
+        rows = torch.full((n, L), 32, dtype=torch.uint8, device=dev)
+        rows[:, :keep] = full[:, :keep]
+        del full
+        if view[0] == "clean":
+            idx = torch.arange(n, dtype=torch.int64, device=dev)
+            corrupt = (synth._lsr(synth._rowhash(idx, synth.SEEDS[cfg], 0), 20) % 100) == 0
+            for _ in range(4):   # (runs of corrupted rows: a few passes)
+                src = torch.where(corrupt, (idx - 1).clamp(min=0), idx)
+                rows = rows[src]
+                corrupt = corrupt[src] & corrupt
     else:
         L = view
         n0 = (n * L + L0 - 1) // L0
