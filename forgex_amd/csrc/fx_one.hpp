@@ -20,6 +20,10 @@
 // automaton is in the v_perm format (BSCH 3, FXP_F_BYTE_A8).
 #pragma once
 #include "fx_tile.hpp"
+#include "fx_few.hpp"
+#ifndef FX_FEW_ROWS
+#define FX_FEW_ROWS 1   // gathered tiles of a few exception rows: chunk-parallel scan (fx_few.hpp) instead of one lane per row
+#endif
 
 // row accessors of the general procedure: the row in global memory / in lane r's cells of the LDS tile
 struct FxGlobalRow {
@@ -67,6 +71,12 @@ struct FxScanCtx {
 #endif
 #ifndef FX_FWD_ALIGNED_MIN
 #define FX_FWD_ALIGNED_MIN 12  // lanes still walking after the first window for that to pay
+#endif
+#ifndef FX_FWD_PIPE3
+#define FX_FWD_PIPE3 1        // the aligned forward walk with three lookup buffers (lookups two chains ahead) instead of two
+#endif
+#ifndef FX_FWD_DIRECT
+#define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
 #endif
 #ifndef FX_DEFER_DENSE
 #define FX_DEFER_DENSE 12   // tiles with more hit rows than this finish them in place (config 3 / 5: half of the rows match -- queueing those costs
@@ -197,138 +207,220 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          cur = fxstep(f, cur, TAp);
          mm = cur >= P.acc_min ? 2u : 0u;
       }
-      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
-         // first window: 32 symbols from j (16 for rows of up to 64 bytes, where the window is a large share of the tile's work),
-         // all lookups issued before the chain
-         constexpr int NG = CH <= 4 ? 2 : 4;
-         uint32_t o[2 * NG];
-         fetch_groups<RAGGED, NG>(o, tb, lane, j, (uint32_t)L);
-         constexpr int GB = NG;   // 8-symbol groups whose lookups are issued together
-         uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
+      // Long matches on many lanes (config 4: nine rows in ten match from their first character to their last): the row from each lane's
+      // start in ALIGNED 8-byte groups with the backward pass's lookup pipeline -- 3.9 instead of 5.3-7.6 instructions per byte.
+      constexpr bool ALN = !RAGGED && CH >= 4 && FX_FWD_ALIGNED != 0 && BYTES;   // (byte-level scans: UTF-8 text, where matches run long; the class-level
+                                                                                 //  scans of ASCII tiles keep the shorter code: config 5 lost 1 % to its mere presence)
+      auto aligned_walk = [&]() {
+         // (1) every lane to its next 8-byte boundary: up to 7 symbols, per lane
+         const uint32_t nrem = (0u - j) & 7u;
+         if (__builtin_amdgcn_ballot_w64(cur != 0 && nrem != 0u) != 0) {
+            uint32_t o1[2];
+            fetch_groups<RAGGED, 1>(o1, tb, lane, j, (uint32_t)L);
+            FA f8[8];
+            lookup8(f8, o1[0], o1[1], tabA);
 #pragma unroll
-         for (int gb = 0; gb < NG; gb += GB) {
-            FA f[8 * GB];
+            for (int q = 0; q < 7; ++q) {
+               const uint32_t nx = fxstep(f8[q], cur, TAp);
+               const bool on = (uint32_t)q < nrem;
+               cur = on ? nx : cur;
+               mm = (on && nx >= P.acc_min) ? j + (uint32_t)q + 3u : mm;
+            }
+            j += nrem;
+         }
+         // (2) aligned groups from this lane's group g0 on; the wave walks chunks c0 .. CH (chunk CH = the end-of-row column:
+         //     the trailing NUL, then KILL symbols), a lane joins at its own group; per group only "any accept" + entry state
+         const uint32_t g0 = j >> 3;
+         uint32_t c0 = 0;
+         while (c0 < (uint32_t)CH && __builtin_amdgcn_ballot_w64(cur != 0 && (g0 >> 1) <= c0) == 0) ++c0;
+         uint32_t gl2 = 0xFFFFFFFFu, el2 = 0;
+#if FX_FWD_PIPE3
+         // THREE lookup buffers, each group's lookups issued two chains ahead of its use: with one v_perm_b32 per step a chain is 32 cycles, and
+         // lookups issued one chain ahead (the backward pass's scheme, whose nibble chains are three times as long) come back late -- the
+         // walk with FEWER instructions ran SLOWER than the 32-symbol window it replaced (profiles/r03_few_ab.txt).  Six groups = three
+         // chunks per trip; chunks behind the end-of-row column read it again (KILL symbols: every lane is dead by then).
+         // (The same for the nibble BACKWARD pass of 192-byte rows -- chains of 24 instructions -- changed nothing: 95.4 -> 95.2 us,
+         //  profiles/r03_pipe3_ab.txt; not kept.)
+         auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c <= (uint32_t)CH ? c : (uint32_t)CH)]; };
+         auto step8 = [&](const FA (&f)[8], const uint32_t g) {
+            const uint32_t entry = cur;
+            uint32_t st[8], t = cur;
 #pragma unroll
-            for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
-#pragma unroll
-            for (int g = 0; g < GB; ++g) {
+            for (int q = 0; q < 8; ++q) {
+               t = fxstep(f[q], t, TAp);
+               st[q] = t;
+            }
+            const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+            const bool act = g >= g0;
+            cur = act ? t : cur;
+            const bool hit = act && mx >= P.acc_min;
+            gl2 = hit ? g : gl2;
+            el2 = hit ? entry : el2;
+         };
+         FA fa[8], fb[8], fc[8];
+         uint4 w0 = cellc(c0), w1 = cellc(c0 + 1u), w2 = cellc(c0 + 2u);
+         lookup8(fa, w0.x, w0.y, tabA);
+         lookup8(fb, w0.z, w0.w, tabA);
+#pragma unroll 1
+         for (uint32_t c = c0; c <= (uint32_t)CH; c += 3u) {
+            lookup8(fc, w1.x, w1.y, tabA);
+            __builtin_amdgcn_sched_barrier(0);
+            step8(fa, 2u * c);
+            __builtin_amdgcn_sched_barrier(0);
+            lookup8(fa, w1.z, w1.w, tabA);
+            w0 = cellc(c + 3u);
+            __builtin_amdgcn_sched_barrier(0);
+            step8(fb, 2u * c + 1u);
+            __builtin_amdgcn_sched_barrier(0);
+            lookup8(fb, w2.x, w2.y, tabA);
+            w1 = cellc(c + 4u);
+            __builtin_amdgcn_sched_barrier(0);
+            step8(fc, 2u * c + 2u);
+            __builtin_amdgcn_sched_barrier(0);
+            lookup8(fc, w2.z, w2.w, tabA);
+            w2 = cellc(c + 5u);
+            __builtin_amdgcn_sched_barrier(0);
+            step8(fa, 2u * c + 3u);
+            __builtin_amdgcn_sched_barrier(0);
+            lookup8(fa, w0.x, w0.y, tabA);
+            __builtin_amdgcn_sched_barrier(0);
+            step8(fb, 2u * c + 4u);
+            __builtin_amdgcn_sched_barrier(0);
+            lookup8(fb, w0.z, w0.w, tabA);
+            __builtin_amdgcn_sched_barrier(0);
+            step8(fc, 2u * c + 5u);
+            __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) break;
+         }
+#else
+         FA fa[8], fb[8];
+         uint4 wk = tile[tile_cell(lane, c0)], wn = tile[tile_cell(lane, c0 < (uint32_t)CH ? c0 + 1u : c0)];
+         lookup8(fa, wk.x, wk.y, tabA);
+#pragma unroll 1
+         for (uint32_t c = c0; c <= (uint32_t)CH; ++c) {
+            lookup8(fb, wk.z, wk.w, tabA);
+            __builtin_amdgcn_sched_barrier(0);
+            {
                const uint32_t entry = cur;
-               uint32_t st[8];
+               uint32_t st[8], t = cur;
 #pragma unroll
                for (int q = 0; q < 8; ++q) {
-                  cur = fxstep(f[8 * g + q], cur, TAp);
-                  st[q] = cur;
+                  t = fxstep(fa[q], t, TAp);
+                  st[q] = t;
                }
                const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-               const bool hit = mx >= P.acc_min;
-               gl = hit ? (uint32_t)(gb + g) : gl;
-               el = hit ? entry : el;
-               blo = hit ? o[2 * (gb + g)] : blo;
-               bhi = hit ? o[2 * (gb + g) + 1] : bhi;
+               const bool act = 2u * c >= g0;
+               cur = act ? t : cur;
+               const bool hit = act && mx >= P.acc_min;
+               gl2 = hit ? 2u * c : gl2;
+               el2 = hit ? entry : el2;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // (unconditional -- after the last chunk the end-of-row column once more, unused: behind a branch the lookups landed in
+                //  fresh registers and were copied back at the loop's end, twelve 64-bit moves per chunk)
+               wk = wn;
+               lookup8(fa, wk.x, wk.y, tabA);
+               wn = tile[tile_cell(lane, c + 2u <= (uint32_t)CH ? c + 2u : (uint32_t)CH)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+               const uint32_t entry = cur;
+               uint32_t st[8], t = cur;
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  t = fxstep(fb[q], t, TAp);
+                  st[q] = t;
+               }
+               const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+               const bool act = 2u * c + 1u >= g0;
+               cur = act ? t : cur;
+               const bool hit = act && mx >= P.acc_min;
+               gl2 = hit ? 2u * c + 1u : gl2;
+               el2 = hit ? entry : el2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) break;
          }
-         {
+#endif
+         // the exact symbol of the last accept: re-walk that group (every lane one group)
+         if (__builtin_amdgcn_ballot_w64(gl2 != 0xFFFFFFFFu) != 0) {
+            const uint32_t g = gl2 != 0xFFFFFFFFu ? gl2 : 0u;
+            const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
             FA fr8[8];
-            lookup8(fr8, blo, bhi, tabA);
-            uint32_t st = el, loc = 0;
+            lookup8(fr8, rw.x, rw.y, tabA);
+            uint32_t st = el2, loc = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                st = fxstep(fr8[q], st, TAp);
                loc = st >= P.acc_min ? (uint32_t)q : loc;
             }
-            mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+            mm = gl2 != 0xFFFFFFFFu ? 8u * g + loc + 3u : mm;
          }
-         j += 8u * NG;
-         // Matches longer than the window.  MANY lanes still walking (config 4: nine rows in ten match from their first character to
-         // their last): the rest of the row in ALIGNED 8-byte groups with the backward pass's lookup pipeline -- 5 instead of 7.6
-         // instructions per byte.  Few lanes: 8 symbols per round trip from wherever each lane stands (below).
+      };
+      (void)aligned_walk;
+      if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
          bool aligned_done = false;
-         if constexpr (!RAGGED && CH >= 4 && FX_FWD_ALIGNED != 0 && BYTES) {   // (byte-level scans: UTF-8 text, where matches run long; the class-level
-                                                                                //  scans of ASCII tiles keep the shorter code: config 5 lost 1 % to its mere presence)
+         // Many lanes walk and their starts lie within three chunks of each other (config 4: at the row's first bytes): straight into the
+         // aligned walk -- no window (370 instructions up to the loop against 126 for the same 32 bytes in it; scattered starts keep the
+         // window: the aligned loop runs from the first start to the last end, and lanes wait in it for their group)
+         if constexpr (ALN && FX_FWD_DIRECT != 0) {
             if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != 0)) >= (uint32_t)FX_FWD_ALIGNED_MIN) {
-               aligned_done = true;
-               // (1) every lane to its next 8-byte boundary: up to 7 symbols, per lane
-               const uint32_t nrem = (0u - j) & 7u;
-               if (__builtin_amdgcn_ballot_w64(cur != 0 && nrem != 0u) != 0) {
-                  uint32_t o1[2];
-                  fetch_groups<RAGGED, 1>(o1, tb, lane, j, (uint32_t)L);
-                  FA f8[8];
-                  lookup8(f8, o1[0], o1[1], tabA);
-#pragma unroll
-                  for (int q = 0; q < 7; ++q) {
-                     const uint32_t nx = fxstep(f8[q], cur, TAp);
-                     const bool on = (uint32_t)q < nrem;
-                     cur = on ? nx : cur;
-                     mm = (on && nx >= P.acc_min) ? j + (uint32_t)q + 3u : mm;
-                  }
-                  j += nrem;
+               uint32_t cmin = 0;
+               while (cmin < (uint32_t)CH && __builtin_amdgcn_ballot_w64(cur != 0 && (j >> 4) <= cmin) == 0) ++cmin;
+               if (__builtin_amdgcn_ballot_w64(cur != 0 && (j >> 4) > cmin + 2u) == 0) {
+                  aligned_walk();
+                  aligned_done = true;
                }
-               // (2) aligned groups from this lane's group g0 on; the wave walks chunks c0 .. CH (chunk CH = the end-of-row column:
-               //     the trailing NUL, then KILL symbols), a lane joins at its own group; per group only "any accept" + entry state
-               const uint32_t g0 = j >> 3;
-               uint32_t c0 = 0;
-               while (c0 < (uint32_t)CH && __builtin_amdgcn_ballot_w64(cur != 0 && (g0 >> 1) <= c0) == 0) ++c0;
-               uint32_t gl2 = 0xFFFFFFFFu, el2 = 0;
-               FA fa[8], fb[8];
-               uint4 wk = tile[tile_cell(lane, c0)], wn = tile[tile_cell(lane, c0 < (uint32_t)CH ? c0 + 1u : c0)];
-               lookup8(fa, wk.x, wk.y, tabA);
-#pragma unroll 1
-               for (uint32_t c = c0; c <= (uint32_t)CH; ++c) {
-                  lookup8(fb, wk.z, wk.w, tabA);
-                  __builtin_amdgcn_sched_barrier(0);
-                  {
-                     const uint32_t entry = cur;
-                     uint32_t st[8], t = cur;
+            }
+         }
+         if (!aligned_done) {
+            // first window: 32 symbols from j (16 for rows of up to 64 bytes, where the window is a large share of the tile's work),
+            // all lookups issued before the chain
+            constexpr int NG = CH <= 4 ? 2 : 4;
+            uint32_t o[2 * NG];
+            fetch_groups<RAGGED, NG>(o, tb, lane, j, (uint32_t)L);
+            constexpr int GB = NG;   // 8-symbol groups whose lookups are issued together
+            uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
-                     for (int q = 0; q < 8; ++q) {
-                        t = fxstep(fa[q], t, TAp);
-                        st[q] = t;
-                     }
-                     const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-                     const bool act = 2u * c >= g0;
-                     cur = act ? t : cur;
-                     const bool hit = act && mx >= P.acc_min;
-                     gl2 = hit ? 2u * c : gl2;
-                     el2 = hit ? entry : el2;
-                  }
-                  __builtin_amdgcn_sched_barrier(0);
-                  if (c < (uint32_t)CH) {
-                     wk = wn;
-                     lookup8(fa, wk.x, wk.y, tabA);
-                     wn = tile[tile_cell(lane, c + 2u <= (uint32_t)CH ? c + 2u : (uint32_t)CH)];
-                  }
-                  __builtin_amdgcn_sched_barrier(0);
-                  {
-                     const uint32_t entry = cur;
-                     uint32_t st[8], t = cur;
+            for (int gb = 0; gb < NG; gb += GB) {
+               FA f[8 * GB];
 #pragma unroll
-                     for (int q = 0; q < 8; ++q) {
-                        t = fxstep(fb[q], t, TAp);
-                        st[q] = t;
-                     }
-                     const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-                     const bool act = 2u * c + 1u >= g0;
-                     cur = act ? t : cur;
-                     const bool hit = act && mx >= P.acc_min;
-                     gl2 = hit ? 2u * c + 1u : gl2;
-                     el2 = hit ? entry : el2;
-                  }
-                  __builtin_amdgcn_sched_barrier(0);
-                  if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) break;
-               }
-               // the exact symbol of the last accept: re-walk that group (every lane one group)
-               if (__builtin_amdgcn_ballot_w64(gl2 != 0xFFFFFFFFu) != 0) {
-                  const uint32_t g = gl2 != 0xFFFFFFFFu ? gl2 : 0u;
-                  const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
-                  FA fr8[8];
-                  lookup8(fr8, rw.x, rw.y, tabA);
-                  uint32_t st = el2, loc = 0;
+               for (int g = 0; g < GB; ++g) lookup8(&f[8 * g], o[2 * (gb + g)], o[2 * (gb + g) + 1], tabA);
+#pragma unroll
+               for (int g = 0; g < GB; ++g) {
+                  const uint32_t entry = cur;
+                  uint32_t st[8];
 #pragma unroll
                   for (int q = 0; q < 8; ++q) {
-                     st = fxstep(fr8[q], st, TAp);
-                     loc = st >= P.acc_min ? (uint32_t)q : loc;
+                     cur = fxstep(f[8 * g + q], cur, TAp);
+                     st[q] = cur;
                   }
-                  mm = gl2 != 0xFFFFFFFFu ? 8u * g + loc + 3u : mm;
+                  const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+                  const bool hit = mx >= P.acc_min;
+                  gl = hit ? (uint32_t)(gb + g) : gl;
+                  el = hit ? entry : el;
+                  blo = hit ? o[2 * (gb + g)] : blo;
+                  bhi = hit ? o[2 * (gb + g) + 1] : bhi;
+               }
+            }
+            {
+               FA fr8[8];
+               lookup8(fr8, blo, bhi, tabA);
+               uint32_t st = el, loc = 0;
+#pragma unroll
+               for (int q = 0; q < 8; ++q) {
+                  st = fxstep(fr8[q], st, TAp);
+                  loc = st >= P.acc_min ? (uint32_t)q : loc;
+               }
+               mm = gl != 0xFFFFFFFFu ? j + 8u * gl + loc + 3u : mm;
+            }
+            j += 8u * NG;
+            // Matches longer than the window.  MANY lanes still walking: the aligned walk.  Few lanes: 8 symbols per round trip from wherever
+            // each lane stands (below).
+            if constexpr (ALN) {
+               if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != 0)) >= (uint32_t)FX_FWD_ALIGNED_MIN) {
+                  aligned_walk();
+                  aligned_done = true;
                }
             }
          }
@@ -495,6 +587,31 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    __shared__ uint32_t fwd_q[DEFERQ ? 4 * 128 : 1];   // per-wave queues of rows whose exact start + forward pass are finished 64 at a time
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   // Start-up: this thread's entries of the 256-entry tables are READ first, then the first tile's global loads go out, and only then are the
+   // table entries written to LDS -- the block's two start-up latencies (tables from L2, rows from HBM) overlap instead of adding up, and
+   // the wait for the table entries (the older loads: vmcnt counts in order) does not wait for the rows.  (The marked-tile follow-up reads the
+   // flags before it loads a tile.)
+   uint2 t_r = make_uint2(0, 0), t_a = make_uint2(0, 0), t_br = make_uint2(0, 0), t_ba = make_uint2(0, 0);
+   if (SCH == 2) {
+      t_r = reinterpret_cast<const uint2*>(prog + h->off_w16R)[threadIdx.x];
+      t_a = reinterpret_cast<const uint2*>(prog + h->off_w16A)[threadIdx.x];
+   } else if (SCH == 0) {
+      t_r = reinterpret_cast<const uint2*>(prog + h->off_fastR)[threadIdx.x];
+      t_a = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
+   }
+   if (BSCH == 2 || BSCH == 3) {
+      t_br = reinterpret_cast<const uint2*>(prog + h->off_bw16R)[threadIdx.x];
+      t_ba = reinterpret_cast<const uint2*>(prog + (BSCH == 2 ? h->off_bw16A : h->off_b8A))[threadIdx.x];
+   }
+   __builtin_amdgcn_sched_barrier(0);   // (the table reads stay ahead of the tile's loads: their addresses wait for the header's offsets)
+   uint4 stage[CH];
+   if constexpr (!MARKED) {
+      if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
+      else load_tile<CH>(stage, rows, wave_global << 6, n, lane, true);
+   }
    // ---- tables -> LDS ----
    uint8_t* dyn = reinterpret_cast<uint8_t*>(tiles + 4 * 64 * (CH + 1));
    uint16_t* cmap = reinterpret_cast<uint16_t*>(dyn);   // class-level chain: symbol -> 2*column map (512 B), then T_R, then T_A
@@ -510,11 +627,11 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const uint32_t nr = c_tr / 2, na = c_ta / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else if (SCH == 2) {
-      wideR[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_w16R)[threadIdx.x];
-      wideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_w16A)[threadIdx.x];
+      reinterpret_cast<uint2*>(wideR)[threadIdx.x] = t_r;
+      reinterpret_cast<uint2*>(wideA)[threadIdx.x] = t_a;
    } else {
-      permR[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastR)[threadIdx.x];
-      permA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_fastA)[threadIdx.x];
+      permR[threadIdx.x] = t_r;
+      permA[threadIdx.x] = t_a;
    }
    if (BSCH == 1) {
       const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + h->off_byte_cls);
@@ -523,9 +640,9 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       const uint32_t nr = b_tr / 2, na = b_ta / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) bmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else if (BSCH == 2 || BSCH == 3) {
-      bwideR[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16R)[threadIdx.x];
-      if (BSCH == 2) bwideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + h->off_bw16A)[threadIdx.x];
-      else bpermA[threadIdx.x] = reinterpret_cast<const uint2*>(prog + h->off_b8A)[threadIdx.x];
+      reinterpret_cast<uint2*>(bwideR)[threadIdx.x] = t_br;
+      if (BSCH == 2) reinterpret_cast<uint2*>(bwideA)[threadIdx.x] = t_ba;
+      else bpermA[threadIdx.x] = t_ba;
    }
    // BMP class map (page index + pages) of the in-LDS UTF-8 decode, behind the tables when it fits
    const uint16_t* page_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_page);
@@ -541,7 +658,6 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    const fxrow::ClassTables ct{page_p, pages_p, reinterpret_cast<const uint16_t*>(prog + h->off_bound_cls),
                                reinterpret_cast<const int32_t*>(prog + h->off_bounds), h->n_bounds};
    const uint32_t sym_ffff = 128u + h->cls_ffff;
-   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const bool raw = (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search: bytes are symbols, nothing is decoded
    uint4* tile = tiles + wave * (64 * (CH + 1));
    // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (see fx_search_fast)
@@ -550,8 +666,6 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    if (whole)
       for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
-   const int64_t n_tiles = (n + 63) >> 6;
-   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    uint32_t* myq = pool_q + (POOL ? wave * 64u : 0u);
 
    // results of one row.  `ordered`: the wave holds 64 consecutive rows (a tile of the batch): the packed flag word is its ballot;
@@ -676,9 +790,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
    };
    bool live = MARKED ? tile_marked(wave_global) : true;   // the tile in `stage` is to be scanned
-   uint4 stage[CH];
-   if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
-   else load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
+   if constexpr (MARKED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
    for (int64_t t = wave_global;;) {
       bool is_tile = false;
       uint32_t take = 0;
@@ -831,6 +943,15 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
                tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
                prev = cur.w;
                cur = nxt;
+            }
+         }
+         // a gathered tile of a FEW rows -- the usual end of a wave -- on the 8-state tables: the lanes share the rows' cells (fx_few.hpp).
+         // (Rows of 192 / 256 bytes only: those kernels run two waves per SIMD whatever their registers; with the 32 registers of a cell's
+         //  table rows the kernels of shorter rows would drop from three waves per SIMD to two -- CH 8: 163 -> 191 VGPRs.)
+         if constexpr (SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0) {
+            if (!is_tile && take <= fx_few_rows_max<CH>()) {
+               fx_scan_few_rows<CH, SPANS>(tile, permR, permA, fp, lane, take, myq, emit);
+               continue;
             }
          }
          (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, is_tile, except);

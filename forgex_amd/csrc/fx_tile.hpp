@@ -652,6 +652,32 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    __shared__ fx_nib wideR[WIDE ? 256 : 1];
    __shared__ fx_nib wideA[WIDE ? 256 : 1];
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*CH cells [+ chain tables] [+ class map]
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
+   const int64_t n_tiles = (n + 63) >> 6;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   // Start-up: this thread's entries of the 256-entry tables are READ first, then the first tiles' global loads go out, and only then are the
+   // entries written to LDS: the block's two start-up latencies -- tables from L2, rows from HBM -- overlap instead of adding up, and the wait
+   // for the table entries (the older loads: vmcnt counts in order) does not wait for the rows.  (The marked-tile passes read the flags first;
+   // the worklist pass gathers per tile.)
+   uint2 t_r = make_uint2(0, 0), t_a = make_uint2(0, 0);
+   if (!CHAIN) {
+      const FxpHeader* h0 = reinterpret_cast<const FxpHeader*>(prog);
+      t_r = reinterpret_cast<const uint2*>(prog + (WIDE ? (BYTES ? h0->off_bw16R : h0->off_w16R) : h0->off_fastR))[threadIdx.x];
+      t_a = reinterpret_cast<const uint2*>(prog + (WIDE ? (BYTES ? h0->off_bw16A : h0->off_w16A) : h0->off_fastA))[threadIdx.x];
+   }
+   __builtin_amdgcn_sched_barrier(0);   // (the table reads stay ahead of the tiles' loads: their addresses wait for the header's offsets)
+   constexpr int DEPTH = FX_PREFETCH_DEPTH;
+   constexpr bool EARLY = !MARKED && !LIST;
+   uint4 stage[LIST ? 1 : DEPTH][CH];
+   bool live[LIST ? 1 : DEPTH];
+   if constexpr (EARLY) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+         live[d] = true;
+         if constexpr (LONG) PREFETCH_SEG(stage[d], wave_global + d * wave_stride, S - 1u, true);
+         else PREFETCH_TILE(stage[d], wave_global + d * wave_stride, true);
+      }
+   }
    __shared__ uint32_t fwd_q[DEFER ? 4 * 64 * 2 : 1];   // match compaction: per wave 64 x (row, hit group | entry state << 16)
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
@@ -668,23 +694,17 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       const uint32_t nr = tr_bytes / 2, na = ta_bytes / 2;
       for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
    } else if (WIDE) {
-      const fx_nib* gR = reinterpret_cast<const fx_nib*>(prog + (BYTES ? h->off_bw16R : h->off_w16R));
-      const fx_nib* gA = reinterpret_cast<const fx_nib*>(prog + (BYTES ? h->off_bw16A : h->off_w16A));
-      wideR[threadIdx.x] = gR[threadIdx.x];
-      wideA[threadIdx.x] = gA[threadIdx.x];
+      reinterpret_cast<uint2*>(wideR)[threadIdx.x] = t_r;
+      reinterpret_cast<uint2*>(wideA)[threadIdx.x] = t_a;
    } else {
-      const uint2* gR = reinterpret_cast<const uint2*>(prog + h->off_fastR);
-      const uint2* gA = reinterpret_cast<const uint2*>(prog + h->off_fastA);
-      uint32_t t = threadIdx.x;   // 256 threads = 256 symbol ids (ids >= 128 are all-dead rows unless FXP_F_FAST_UTF8)
-      permR[t] = gR[t];
-      permA[t] = gA[t];
+      permR[threadIdx.x] = t_r;   // 256 threads = 256 symbol ids (ids >= 128 are all-dead rows unless FXP_F_FAST_UTF8)
+      permA[threadIdx.x] = t_a;
    }
    __syncthreads();
    // symbol -> F tables of the two directions (the chain scheme shares one class map)
    using TabT = typename std::conditional<CHAIN, uint16_t, typename std::conditional<WIDE, fx_nib, uint2>::type>::type;
    const TabT* tabR = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideR) : reinterpret_cast<const TabT*>(permR));
    const TabT* tabA = CHAIN ? reinterpret_cast<const TabT*>(cmap) : (WIDE ? reinterpret_cast<const TabT*>(wideA) : reinterpret_cast<const TabT*>(permA));
-   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
    const bool raw = BYTES || (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search, byte-level tables: bytes are symbols, nothing is decoded or deferred
    const bool utf8 = !raw && (FIXUP || fp.defer_tiles != 0);   // first pass: defer whole tiles that hold a byte >= 0x80
    // second pass only: BMP class map (page index + pages) for the in-LDS UTF-8 decode, placed behind the four tiles
@@ -715,8 +735,6 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    if (whole)
       for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
-   const int64_t n_tiles = (n + 63) >> 6;
-   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
 
    bool any_deferred = false;   // wave-uniform: this wave deferred at least one tile to the second pass
    STAMP_DECL;
@@ -1058,15 +1076,19 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                }
             }
          } else rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
-         F f[8];
-         lookup8(f, rw.x, rw.y, tabR);
-         uint32_t st = esel, loc = 8;
+         uint32_t loc = 8;
+         // (half-row staging: skipped when no lane's leftmost hit lies in the left half -- config 3: every match sits in the right one)
+         if (!HALFROW || __builtin_amdgcn_ballot_w64(gsel != 0xFFFFFFFFu && here) != 0) {
+            F f[8];
+            lookup8(f, rw.x, rw.y, tabR);
+            uint32_t st = esel;
 #pragma unroll
-         for (int i = 7; i >= 0; --i) {
-            const uint32_t nx = fxstep(f[i], st, TRp);
-            const bool on = !LONG || HALFROW || (uint32_t)i < nv;   // (per lane)
-            st = on ? nx : st;
-            loc = on && nx >= fp.hit_min ? (uint32_t)i : loc;
+            for (int i = 7; i >= 0; --i) {
+               const uint32_t nx = fxstep(f[i], st, TRp);
+               const bool on = !LONG || HALFROW || (uint32_t)i < nv;   // (per lane)
+               st = on ? nx : st;
+               loc = on && nx >= fp.hit_min ? (uint32_t)i : loc;
+            }
          }
          s = gsel != 0xFFFFFFFFu ? (here ? g * 8u + 2u + loc : s_half) : 0u;
          const F fz = tabR[0];   // leading NUL
@@ -1155,21 +1177,19 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          }
       }
    };
-   if (LIST) {
-      uint4 stage[CH];
-      bool live = true;
-      for (int64_t t = wave_global; (uint64_t)(t << 6) < list_count; t += wave_stride) do_tile(stage, live, t, t);
+   if constexpr (LIST) {
+      live[0] = true;
+      for (int64_t t = wave_global; (uint64_t)(t << 6) < list_count; t += wave_stride) do_tile(stage[0], live[0], t, t);
    } else {
       // DEPTH tiles of global loads in flight per wave (HBM latency under load is several microseconds).  The marked-tile passes
       // run the same pipeline: a tile they skip costs one read of its flags and 16 loads that are range-checked away.
-      constexpr int DEPTH = FX_PREFETCH_DEPTH;
-      uint4 stage[DEPTH][CH];
-      bool live[DEPTH];
+      if constexpr (!EARLY) {
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-         live[d] = MARKED ? tile_marked(wave_global + d * wave_stride) : true;
-         if constexpr (LONG) PREFETCH_SEG(stage[d], wave_global + d * wave_stride, S - 1u, live[d]);
-         else PREFETCH_TILE(stage[d], wave_global + d * wave_stride, live[d]);
+         for (int d = 0; d < DEPTH; ++d) {
+            live[d] = MARKED ? tile_marked(wave_global + d * wave_stride) : true;
+            if constexpr (LONG) PREFETCH_SEG(stage[d], wave_global + d * wave_stride, S - 1u, live[d]);
+            else PREFETCH_TILE(stage[d], wave_global + d * wave_stride, live[d]);
+         }
       }
       for (int64_t t = wave_global;;) {   // (leaving the loop from the middle keeps the staging registers free of merges)
          bool done = false;

@@ -325,7 +325,9 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
                 buf += rng.choice(pieces)
             mixed.append(np.frombuffer(buf[:L], dtype=np.uint8))
         rows_m = np.stack(mixed)
-        for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]])):
+        rows_few = rows_a.copy()   # a few broken rows among ASCII ones: the gathered tile of a FEW exception rows (fx_few.hpp at 192 / 256 bytes)
+        rows_few[[5, 6, 70, 130, 191]] = rows_m[[0, 1, 2, 3, 4]]
+        for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]]), rows_few):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             assert prog.last_path() in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16), (pat, L)   # (2: chain tables too large for LDS next to the tiles)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
@@ -1269,3 +1271,52 @@ def test_many_patterns_default_dispatch_by_row_length(fx):
             f1, a1, b1 = p.match_device(rows)
             torch.cuda.synchronize()
             assert torch.equal(f[i], f1) and torch.equal(a[i], a1) and torch.equal(b[i], b1), (cfg, pats[i])
+
+
+@pytest.mark.parametrize("L", [192, 256])
+def test_few_exception_rows_chunk_parallel_scan(fx, L, monkeypatch):
+    """The end of a wave of fx_search_one on rows of 192 / 256 bytes: a gathered tile of a FEW structurally invalid rows is scanned with
+    the lanes spread over the rows' cells (fx_few.hpp: maps of the 8-state tables composed by v_perm, segmented scans over the row's
+    lanes) instead of one lane per row.  Generated patterns on the 8-state tables with byte-level tables; 1..6 broken rows per tile
+    (4 / 5 fit one call at 256 / 192 bytes; more take the lane-per-row scan), starts at the leading NUL, matches that run to the row's end
+    and over broken bytes -- flags and spans vs the oracle, flags-only calls too."""
+    import random
+    import fuzz_diff
+    monkeypatch.setenv("FXAMD_NO_HALF", "1")   # (256-byte rows: the one-launch kernel, not the half-row first pass)
+    seed = int(os.environ.get("FX_FUZZ_SEED", "0"))   # (FX_FUZZ_SEED / FX_FUZZ_PATTERNS: soak runs)
+    want = int(os.environ.get("FX_FUZZ_PATTERNS", "30"))
+    rng = random.Random(7100 + L + 1000 * seed)
+    nrng = np.random.default_rng(7100 + L + 1000 * seed)
+    alpha = np.frombuffer(b"abcxyz019 .-\n\tAZ_@", dtype=np.uint8)
+    pieces = [b"a", b"b", b"c", b"x", b"0", b"9", b" ", b".", "あ".encode(), "ん".encode(), "α".encode(), "ω".encode(), "é".encode(),
+              b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n", b"\xce", b"\xe3\x81\x81\x81"]
+    fixed = [rb"[a-z]+\d+", "[α-ωぁ-ん]+".encode(), "[ぁ-ん]+[α-ω]".encode(), rb"^[a-c]*", rb"[^a]+", rb".+", rb"x*", "(あ|α)+.".encode(), rb"\d*$"]
+    n_run = 0
+    tried = 0
+    while n_run < want and tried < 20 * want:
+        tried += 1
+        pat = fixed[tried - 1] if tried <= len(fixed) else fuzz_diff.gen_pattern(rng).encode()
+        p = fx.Program(pat, fx.OP_SEARCH)
+        if p.status != 0:
+            continue
+        fl = p.info()["flags"]
+        if not (fl & 8) or not (fl & (1 << 12)):   # FXP_F_FAST_OK (8-state class-level tables) and FXP_F_BYTE_DFA
+            continue
+        n_run += 1
+        n = 256
+        rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+        # tiles 0..3 get 1, 3, 5 and 6 broken rows; a broken row = pieces (valid and invalid UTF-8) cut to the row length
+        for t, cnt in enumerate((1, 3, 5, 6)):
+            for r in rng.sample(range(64), cnt):
+                buf = b""
+                while len(buf) < L:
+                    buf += rng.choice(pieces)
+                rows[64 * t + r] = np.frombuffer(buf[:L], dtype=np.uint8)
+        prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14), (pat, prog.last_path())   # (12-14: candidate-list driver programs, their exception rows go to the general procedure)
+        of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+        bad = np.nonzero((f != of) | (a != oa) | (b != ob))[0]
+        assert bad.size == 0, (pat, L, int(bad[0]), int(f[bad[0]]), int(a[bad[0]]), int(b[bad[0]]), int(of[bad[0]]), int(oa[bad[0]]), int(ob[bad[0]]), rows[bad[0]].tobytes())
+        _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+        assert np.array_equal(f2, of), (pat, L, "flags only")
+    assert n_run >= 20
