@@ -75,6 +75,9 @@ struct FxScanCtx {
 #ifndef FX_FWD_PIPE3
 #define FX_FWD_PIPE3 1        // the aligned forward walk with three lookup buffers (lookups two chains ahead) instead of two
 #endif
+#ifndef FX_MATCH_PIPE3
+#define FX_MATCH_PIPE3 1      // `.match.` on the 8-state tables, rows of 192 / 256 bytes: three lookup buffers (lookups two chains ahead)
+#endif
 #ifndef FX_FWD_DIRECT
 #define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
 #endif
@@ -112,6 +115,9 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       uint32_t na = 0;
       if (PREPAD) na = c.pre_na;
       else if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);
+      // (Three lookup buffers -- a group's lookups two chains ahead, as in the forward walk and in fx_match_tile below -- do NOT pay here: with the
+      //  max tree and the selects a group's chain is ~60 cycles and the two-buffer distance already ~125, an LDS round trip; measured in rolled
+      //  trips: config 5 +1.3 %, 256-byte rows on this kernel +2.7 %; fully unrolled: +38 % -- profiles/r03_pipe3_ab.txt.)
       {
          F fa[8], fb[8];
          uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
@@ -239,10 +245,13 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          // lookups issued one chain ahead (the backward pass's scheme, whose nibble chains are three times as long) come back late -- the
          // walk with FEWER instructions ran SLOWER than the 32-symbol window it replaced (profiles/r03_few_ab.txt).  Six groups = three
          // chunks per trip; chunks behind the end-of-row column read it again (KILL symbols: every lane is dead by then).
-         // (The same for the nibble BACKWARD pass of 192-byte rows -- chains of 24 instructions -- changed nothing: 95.4 -> 95.2 us,
-         //  profiles/r03_pipe3_ab.txt; not kept.)
+         // (The same for the NIBBLE backward pass of 192-byte rows -- chains of 24 instructions -- changed nothing: 95.4 -> 95.2 us,
+         //  profiles/r03_pipe3_ab.txt.)
          auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c <= (uint32_t)CH ? c : (uint32_t)CH)]; };
-         auto step8 = [&](const FA (&f)[8], const uint32_t g) {
+         // (JOINED: every walking lane has reached its own group -- no per-lane "not yet" selects.  With clustered starts that is so after
+         //  the first trip.)
+         auto step8 = [&](auto joined, const FA (&f)[8], const uint32_t g) {
+            constexpr bool JOINED = decltype(joined)::value;
             const uint32_t entry = cur;
             uint32_t st[8], t = cur;
 #pragma unroll
@@ -251,7 +260,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                st[q] = t;
             }
             const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
-            const bool act = g >= g0;
+            const bool act = JOINED || g >= g0;
             cur = act ? t : cur;
             const bool hit = act && mx >= P.acc_min;
             gl2 = hit ? g : gl2;
@@ -261,36 +270,53 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          uint4 w0 = cellc(c0), w1 = cellc(c0 + 1u), w2 = cellc(c0 + 2u);
          lookup8(fa, w0.x, w0.y, tabA);
          lookup8(fb, w0.z, w0.w, tabA);
-#pragma unroll 1
-         for (uint32_t c = c0; c <= (uint32_t)CH; c += 3u) {
+         uint32_t c = c0;
+         auto trip = [&](auto joined) {   // six groups = chunks c, c + 1, c + 2
             lookup8(fc, w1.x, w1.y, tabA);
             __builtin_amdgcn_sched_barrier(0);
-            step8(fa, 2u * c);
+            step8(joined, fa, 2u * c);
             __builtin_amdgcn_sched_barrier(0);
             lookup8(fa, w1.z, w1.w, tabA);
             w0 = cellc(c + 3u);
             __builtin_amdgcn_sched_barrier(0);
-            step8(fb, 2u * c + 1u);
+            step8(joined, fb, 2u * c + 1u);
             __builtin_amdgcn_sched_barrier(0);
             lookup8(fb, w2.x, w2.y, tabA);
             w1 = cellc(c + 4u);
             __builtin_amdgcn_sched_barrier(0);
-            step8(fc, 2u * c + 2u);
+            step8(joined, fc, 2u * c + 2u);
             __builtin_amdgcn_sched_barrier(0);
             lookup8(fc, w2.z, w2.w, tabA);
             w2 = cellc(c + 5u);
             __builtin_amdgcn_sched_barrier(0);
-            step8(fa, 2u * c + 3u);
+            step8(joined, fa, 2u * c + 3u);
             __builtin_amdgcn_sched_barrier(0);
             lookup8(fa, w0.x, w0.y, tabA);
             __builtin_amdgcn_sched_barrier(0);
-            step8(fb, 2u * c + 4u);
+            step8(joined, fb, 2u * c + 4u);
             __builtin_amdgcn_sched_barrier(0);
             lookup8(fb, w0.z, w0.w, tabA);
             __builtin_amdgcn_sched_barrier(0);
-            step8(fc, 2u * c + 5u);
+            step8(joined, fc, 2u * c + 5u);
             __builtin_amdgcn_sched_barrier(0);
-            if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) break;
+         };
+         bool alive = true;
+#pragma unroll 1
+         for (; c <= (uint32_t)CH; c += 3u) {   // until every walking lane has joined
+            trip(std::false_type{});
+            alive = __builtin_amdgcn_ballot_w64(cur != 0) != 0;
+            if (!alive) break;
+            if (__builtin_amdgcn_ballot_w64(cur != 0 && g0 > 2u * (c + 3u)) == 0) {
+               c += 3u;
+               break;
+            }
+         }
+         if (alive) {
+#pragma unroll 1
+            for (; c <= (uint32_t)CH; c += 3u) {
+               trip(std::true_type{});
+               if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) break;
+            }
          }
 #else
          FA fa[8], fb[8];
@@ -509,6 +535,62 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
    uint32_t st = P.A_init;   // = M_start
    uint32_t na = 0;
    if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);   // pads (symbol 255) are the identity for A
+   if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= 12 && !RAGGED) {
+      // 8-state tables on rows of 192 / 256 bytes (two waves per SIMD): THREE lookup buffers, a group's lookups issued two chains ahead of its
+      // use (a chain of eight v_perm_b32 is 32 cycles: one chain ahead, the lookups come back late -- see the aligned forward walk of
+      // fx_scan_tile).  Three chunks per trip.
+      F fa[8], fb[8], fc[8];
+      auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c < (uint32_t)CH ? c : (uint32_t)CH - 1u)]; };
+      uint4 w0 = cellc(0), w1 = cellc(1), w2 = cellc(2);
+      lookup8(fa, w0.x, w0.y, tabA);
+      lookup8(fb, w0.z, w0.w, tabA);
+      constexpr uint32_t TRIPS = (uint32_t)CH / 3u, REST = (uint32_t)CH % 3u;   // whole trips of three chunks, then REST chunks (their lookups are in flight)
+#pragma unroll 1
+      for (uint32_t c = 0; c < 3u * TRIPS; c += 3u) {
+         na |= w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w | w2.x | w2.y | w2.z | w2.w;
+         lookup8(fc, w1.x, w1.y, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fa, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         lookup8(fa, w1.z, w1.w, tabA);
+         w0 = cellc(c + 3u);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fb, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         lookup8(fb, w2.x, w2.y, tabA);
+         w1 = cellc(c + 4u);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fc, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         lookup8(fc, w2.z, w2.w, tabA);
+         w2 = cellc(c + 5u);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fa, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         lookup8(fa, w0.x, w0.y, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fb, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         lookup8(fb, w0.z, w0.w, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fc, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (REST >= 1) {   // chunk 3 TRIPS: its lookups are in fa / fb, its words in w0
+         na |= w0.x | w0.y | w0.z | w0.w;
+         if constexpr (REST == 2) {
+            na |= w1.x | w1.y | w1.z | w1.w;
+            lookup8(fc, w1.x, w1.y, tabA);
+         }
+         chain8_fwd(fa, st, TAp);
+         if constexpr (REST == 2) lookup8(fa, w1.z, w1.w, tabA);
+         chain8_fwd(fb, st, TAp);
+         if constexpr (REST == 2) {
+            chain8_fwd(fc, st, TAp);
+            chain8_fwd(fa, st, TAp);
+         }
+      }
+   } else
    {
       F fa[8], fb[8];
       uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
