@@ -78,6 +78,9 @@ struct FxScanCtx {
 #ifndef FX_MATCH_PIPE3
 #define FX_MATCH_PIPE3 1      // `.match.` on the 8-state tables, rows of 192 / 256 bytes: three lookup buffers (lookups two chains ahead)
 #endif
+#ifndef FX_MATCH_P3_MINCH
+#define FX_MATCH_P3_MINCH 12
+#endif
 #ifndef FX_FWD_DIRECT
 #define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
 #endif
@@ -535,7 +538,7 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
    uint32_t st = P.A_init;   // = M_start
    uint32_t na = 0;
    if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);   // pads (symbol 255) are the identity for A
-   if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= 12 && !RAGGED) {
+   if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= FX_MATCH_P3_MINCH && !RAGGED) {
       // 8-state tables on rows of 192 / 256 bytes (two waves per SIMD): THREE lookup buffers, a group's lookups issued two chains ahead of its
       // use (a chain of eight v_perm_b32 is 32 cycles: one chain ahead, the lookups come back late -- see the aligned forward walk of
       // fx_scan_tile).  Three chunks per trip.
