@@ -76,10 +76,10 @@ struct FxScanCtx {
 #define FX_FWD_PIPE3 1        // the aligned forward walk with three lookup buffers (lookups two chains ahead) instead of two
 #endif
 #ifndef FX_MATCH_PIPE3
-#define FX_MATCH_PIPE3 1      // `.match.` on the 8-state tables, rows of 192 / 256 bytes: three lookup buffers (lookups two chains ahead)
+#define FX_MATCH_PIPE3 1      // `.match.` on the 8-state tables, rows of 96 bytes and longer: three lookup buffers (lookups two chains ahead)
 #endif
 #ifndef FX_MATCH_P3_MINCH
-#define FX_MATCH_P3_MINCH 12
+#define FX_MATCH_P3_MINCH 6   // rows of 96 bytes and longer (at least two trips of three chunks)
 #endif
 #ifndef FX_FWD_DIRECT
 #define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
@@ -539,9 +539,9 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
    uint32_t na = 0;
    if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);   // pads (symbol 255) are the identity for A
    if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= FX_MATCH_P3_MINCH && !RAGGED) {
-      // 8-state tables on rows of 192 / 256 bytes (two waves per SIMD): THREE lookup buffers, a group's lookups issued two chains ahead of its
-      // use (a chain of eight v_perm_b32 is 32 cycles: one chain ahead, the lookups come back late -- see the aligned forward walk of
-      // fx_scan_tile).  Three chunks per trip.
+      // 8-state tables: THREE lookup buffers, a group's lookups issued two chains ahead of its use (a chain of eight v_perm_b32 is 32 cycles:
+      // one chain ahead, the lookups come back late -- see the aligned forward walk of fx_scan_tile).  Three chunks per trip.  Measured
+      // (profiles/r03_pipe3_ab.txt): 10 M x 256 B 0.476-0.488 -> 0.415-0.430 ms (two waves per SIMD), 12.5 M x 128 B 0.290 -> 0.263 ms (three).
       F fa[8], fb[8], fc[8];
       auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c < (uint32_t)CH ? c : (uint32_t)CH - 1u)]; };
       uint4 w0 = cellc(0), w1 = cellc(1), w2 = cellc(2);
