@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_step(uint32_t* out, int iters, uint32_t
    t16[threadIdx.x] = make_uint4(threadIdx.x * 0x9E3779B9u & 0x07070707u, threadIdx.x * 0x85EBCA6Bu & 0x07070707u, 0x80808080u | (threadIdx.x * 77u & 0x07070707u), 0x80808080u | (threadIdx.x * 131u & 0x07070707u));
    __syncthreads();
    uint32_t x = threadIdx.x * 2654435761u + seed + blockIdx.x;
-   uint32_t st = KIND == 2 ? (x & 15u) : (KIND == 3 ? (x & 3u) * 0x01010101u : (x & 7u) * 0x01010101u);
+   uint32_t st = (KIND == 2 || KIND == 4 || KIND == 5) ? (x & 15u) : (KIND == 3 ? (x & 3u) * 0x01010101u : (x & 7u) * 0x01010101u);
    for (int i = 0; i < iters; ++i) {
       x ^= x << 13; x ^= x >> 17; x ^= x << 5;
       const uint32_t lo = x & mask, hi = (x * 0x01000193u) & mask;
@@ -42,6 +42,26 @@ __global__ __launch_bounds__(256) void k_step(uint32_t* out, int iters, uint32_t
          for (int k = 0; k < 8; ++k) f[k] = t8[((k < 4 ? lo : hi) >> ((k & 3) * 8)) & 0xFFu];
 #pragma unroll
          for (int k = 0; k < 8; ++k) st = (uint32_t)(((((uint64_t)f[k].y) << 32) | f[k].x) >> (st << 2)) & 15u;
+      } else if (KIND == 4) {   // nibbles without the 64-bit shift: half select (v_cmp + v_cndmask), v_lshlrev_b32, v_bfe_u32 (the offset uses 5 bits: 4 * (st & 7))
+         uint2 f[8];
+#pragma unroll
+         for (int k = 0; k < 8; ++k) f[k] = t8[((k < 4 ? lo : hi) >> ((k & 3) * 8)) & 0xFFu];
+#pragma unroll
+         for (int k = 0; k < 8; ++k) {
+            const uint32_t half = st > 7u ? f[k].y : f[k].x;
+            st = __builtin_amdgcn_ubfe(half, st << 2, 4u);
+         }
+      } else if (KIND == 5) {   // the same with the state kept pre-scaled (4 * id): v_cmp, v_cndmask, v_bfe_u32, v_lshlrev_b32
+         uint2 f[8];
+#pragma unroll
+         for (int k = 0; k < 8; ++k) f[k] = t8[((k < 4 ? lo : hi) >> ((k & 3) * 8)) & 0xFFu];
+         uint32_t s4 = st << 2;
+#pragma unroll
+         for (int k = 0; k < 8; ++k) {
+            const uint32_t half = s4 > 31u ? f[k].y : f[k].x;
+            s4 = __builtin_amdgcn_ubfe(half, s4, 4u) << 2;
+         }
+         st = s4 >> 2;
       } else {
          uint32_t f[8];   // <= 4 states: 4 next-state bytes per symbol, ds_read_b32 + v_perm_b32
 #pragma unroll
@@ -62,7 +82,7 @@ int main() {
    const int iters = 20000;
    const uint32_t masks[3] = {0x0F0F0F0Fu, 0x3F3F3F3Fu, 0xFFFFFFFFu};
    for (int m = 0; m < 3; ++m)
-      for (int kind = 0; kind < 4; ++kind)
+      for (int kind = 0; kind < 6; ++kind)
          for (int bpc = 2; bpc <= 4; bpc += 2) {
             const int blocks = 256 * bpc;
             for (int rep = 0; rep < 2; ++rep) {
@@ -71,6 +91,8 @@ int main() {
                if (kind == 1) hipLaunchKernelGGL(k_step<1>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
                if (kind == 2) hipLaunchKernelGGL(k_step<2>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
                if (kind == 3) hipLaunchKernelGGL(k_step<3>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
+               if (kind == 4) hipLaunchKernelGGL(k_step<4>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
+               if (kind == 5) hipLaunchKernelGGL(k_step<5>, dim3(blocks), dim3(256), 0, 0, d, iters, 3u, masks[m]);
                CK(hipEventRecord(b));
                CK(hipEventSynchronize(b));
             }
@@ -78,7 +100,7 @@ int main() {
             CK(hipEventElapsedTime(&ms, a, b));
             const double bytes = (double)blocks * 256 * iters * 8;   // input bytes stepped over
             printf("%-6s distinct byte values %3u, %d waves/SIMD: %.3f ms  %.2f T steps/s  (%.2f cycles per wave-step per CU at 2.4 GHz)\n",
-                   kind == 0 ? "perm8" : kind == 1 ? "wide16" : kind == 2 ? "nib16" : "perm4", (masks[m] & 0xFF) + 1, bpc, ms, bytes / (ms * 1e-3) / 1e12,
+                   kind == 0 ? "perm8" : kind == 1 ? "wide16" : kind == 2 ? "nib16" : kind == 3 ? "perm4" : kind == 4 ? "nib32" : "nib32s", (masks[m] & 0xFF) + 1, bpc, ms, bytes / (ms * 1e-3) / 1e12,
                    ms * 1e-3 * 2.4e9 / ((double)iters * 8 * bpc * 4));
          }
    return 0;
