@@ -16,8 +16,10 @@
 // and their multi-pass pipeline; 256-byte rows on the 8-state tables take fx_search_fast's half-row first pass and this kernel (MARKED)
 // as its one gated follow-up.
 // Round 3: `.match.` (fx_match_tile), match compaction for short rows (DEFERQ: the exact start + forward pass of sparse tiles' hit rows
-// are finished 64 at a time from global memory), the aligned forward loop for long matches, and byte-level tables whose forward
-// automaton is in the v_perm format (BSCH 3, FXP_F_BYTE_A8).
+// are finished 64 at a time from global memory), the aligned forward walk for long matches, byte-level tables whose forward
+// automaton is in the v_perm format (BSCH 3, FXP_F_BYTE_A8); then: lookups issued TWO chains ahead where a group's work is one short chain
+// (the aligned forward walk, `.match.` on the 8-state tables: three lookup buffers in rolled trips of three chunks), the chunk-parallel scan
+// of the few exception rows a wave ends with (fx_few.hpp), and a start-up that overlaps the tables (L2) with the first tile (HBM).
 #pragma once
 #include "fx_tile.hpp"
 #include "fx_few.hpp"
