@@ -87,6 +87,8 @@ def lib():
     L.fxamd_last_hip_error.restype = c.c_int
     L.fxamd_device_count.argtypes = []
     L.fxamd_device_count.restype = c.c_int
+    L.fxamd_reload_env.argtypes = []
+    L.fxamd_reload_env.restype = None
     L.fxamd_host_register.argtypes = [vp, i64]
     L.fxamd_host_register.restype = c.c_int
     L.fxamd_host_unregister.argtypes = [vp]
@@ -101,4 +103,4 @@ EXPORTED_SYMBOLS = [
     "fxamd_match_batch_device", "fxamd_packed_layout", "fxamd_match_batch_device_packed", "fxamd_unpack_results", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
     "fxamd_host_register", "fxamd_host_unregister", "fxamd_f_compile", "fxamd_f_program_free", "fxamd_f_strerror_copy", "fxamd_f_match_batch_host",
 ]
-BENCH_SYMBOLS = ["fxamd_launch_fast_only"]   # include/forgex_amd_bench.h: measurement hooks, not part of the boundary
+BENCH_SYMBOLS = ["fxamd_launch_fast_only", "fxamd_reload_env"]   # include/forgex_amd_bench.h: measurement hooks, not part of the boundary

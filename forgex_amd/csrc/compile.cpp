@@ -1428,6 +1428,29 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                if (!is_match)
                   for (int st = Rb.d.n - 1; st >= 0 && Rb.d.out[static_cast<size_t>(st)]; --st) hitmin = st;
                h.flags |= FXP_F_BYTE_DFA;
+               // FXP_F_NEEDS_NONASCII: no non-empty match consists of ASCII symbols only (walking A from its initial state over the classes
+               // of code points 0..127 -- the NUL sentinels included -- never reaches an accepting state): a row without a byte >= 0x80
+               // holds no match, whatever the driver (every reported match is an accepting walk of A over a piece of NUL // text // NUL).
+               if (!is_match && !(h.flags & FXP_F_INIT_ACCEPTING)) {
+                  std::vector<char> seen(static_cast<size_t>(A.n), 0);
+                  std::vector<int> todo{A.init};
+                  seen[static_cast<size_t>(A.init)] = 1;
+                  bool reach_acc = false;
+                  while (!todo.empty() && !reach_acc) {
+                     const int st = todo.back();
+                     todo.pop_back();
+                     for (int b = 0; b < 128 && !reach_acc; ++b) {
+                        const int d = TA(st, ac[static_cast<size_t>(b)]);
+                        if (d == 0) continue;
+                        if (A.out[static_cast<size_t>(d)]) reach_acc = true;
+                        if (!seen[static_cast<size_t>(d)]) {
+                           seen[static_cast<size_t>(d)] = 1;
+                           todo.push_back(d);
+                        }
+                     }
+                  }
+                  if (!reach_acc) h.flags |= FXP_F_NEEDS_NONASCII;
+               }
                h.byte_n_classes = nbc;
                h.byte_row_bytes = row_bytes;
                h.byte_A_init = static_cast<uint32_t>(Ab.d.init) * row_bytes;
@@ -1467,6 +1490,16 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                      h.flags |= FXP_F_BYTE_A8;
                      h.b8_A_init = static_cast<uint32_t>(Ab.d.init);
                      h.b8_acc_min = static_cast<uint32_t>(accmin);   // (== Ab.d.n when no state accepts: never reached)
+                     // FXP_F_SPEC_FWD: the tile kernels may try the row's FIRST character as the leftmost start with this automaton alone
+                     // (api_internal_m.F90:84-88,108-155: the candidates are the leading NUL, then the first character, ...).  Sound when
+                     //  * the leading NUL is no start: A dies on it from its initial state;
+                     //  * no state of A survives U+FFFF: at a structure error the reference feeds U+FFFF for the bytes of the broken
+                     //    sequence (:129-133) and the walk ends there -- as this automaton's does, whose structure errors are dead ends
+                     //    (no accept lies between the last character boundary and the error in either);
+                     //  * there is no candidate-list driver (its equivalence proof covers canonical UTF-8 only).
+                     bool ffff_dead = !prefilter && TA(A.init, static_cast<int>(h.cls_nul)) == 0;
+                     for (int st2 = 1; st2 < A.n && ffff_dead; ++st2) ffff_dead = TA(st2, static_cast<int>(h.cls_ffff)) == 0;
+                     if (ffff_dead) h.flags |= FXP_F_SPEC_FWD;
                   }
                }
             }
@@ -1581,7 +1614,7 @@ int validate_blob(const uint8_t* b, size_t size) {
    auto u16 = [&](uint32_t off, uint64_t i) { uint16_t v; std::memcpy(&v, b + off + 2 * i, 2); return v; };
    const uint32_t known = FXP_F_INIT_ACCEPTING | FXP_F_PREFILTER | FXP_F_HAS_SUFFIX | FXP_F_FAST_OK | FXP_F_HAS_R | FXP_F_MATCH_LITERAL |
                           FXP_F_FAST_UTF8 | FXP_F_NFA_SIM | FXP_F_CHAIN_OK | FXP_F_CHAIN_UTF8 | FXP_F_RAW_BYTES | FXP_F_RAGGED_OK | FXP_F_BYTE_DFA |
-                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8;
+                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8 | FXP_F_SPEC_FWD | FXP_F_NEEDS_NONASCII;
    if (h.flags & ~known) return 5;
    // chain-format table: rows of (ncls + 3) uint16, entries = row offsets of the same table; the 256-entry map holds 2 * column
    auto chain_ok = [&](uint32_t off_cls, uint32_t off_T, uint32_t T_bytes, uint32_t ncls, uint32_t row_bytes, bool final_col) {
@@ -1686,8 +1719,33 @@ int validate_blob(const uint8_t* b, size_t size) {
          const uint8_t* t = b + h.off_b8A;
          for (uint32_t i = 0; i < 2048u; ++i)
             if (t[i] >= 8u) return 72;
+         if (h.flags & FXP_F_SPEC_FWD) {   // the claim is checked against the tables: the NUL kills the initial state, U+FFFF kills every state
+            if ((h.flags & FXP_F_PREFILTER) || t[h.b8_A_init] != 0u) return 73;
+            for (uint32_t st = 1; st < h.nA; ++st)
+               if ((u16(h.off_TA, (uint64_t)st * h.n_classes + h.cls_ffff) & FXP_STATE_MASK) != 0u) return 74;
+         }
+      } else if (h.flags & FXP_F_SPEC_FWD) return 75;
+      if (h.flags & FXP_F_NEEDS_NONASCII) {   // the claim is checked against A: no accepting state is reachable over ASCII classes
+         if (h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & FXP_F_INIT_ACCEPTING) || h.A_init >= h.nA) return 76;
+         std::vector<char> seen(h.nA, 0);
+         std::vector<uint32_t> todo{h.A_init};
+         seen[h.A_init] = 1;
+         while (!todo.empty()) {
+            const uint32_t st = todo.back();
+            todo.pop_back();
+            for (uint32_t c = 0; c < 128; ++c) {
+               const uint16_t e = u16(h.off_TA, (uint64_t)st * h.n_classes + u16(h.off_ascii_cls, c));
+               const uint32_t d = e & FXP_STATE_MASK;
+               if (d == 0) continue;
+               if (e & FXP_FLAG_BIT) return 77;
+               if (!seen[d]) {
+                  seen[d] = 1;
+                  todo.push_back(d);
+               }
+            }
+         }
       }
-   } else if (h.flags & (FXP_F_BYTE_W16 | FXP_F_BYTE_A8)) return 69;
+   } else if (h.flags & (FXP_F_BYTE_W16 | FXP_F_BYTE_A8 | FXP_F_SPEC_FWD | FXP_F_NEEDS_NONASCII)) return 69;
    return 0;
 }
 

@@ -86,6 +86,15 @@ struct FxScanCtx {
 #ifndef FX_FWD_DIRECT
 #define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
 #endif
+#ifndef FX_SPEC_FWD
+#define FX_SPEC_FWD 1         // speculative forward pass from the row's first character (fx_spec_forward; programs with FXP_F_SPEC_FWD)
+#endif
+#ifndef FX_SPEC_FAIL_MAX
+#define FX_SPEC_FAIL_MAX 24   // rows of a tile (of 64) that may fail it and be queued; beyond that the tile is scanned in place and the pass pauses
+#endif
+#ifndef FX_SPEC_RETRY
+#define FX_SPEC_RETRY 16      // ... for this many tiles of the wave
+#endif
 #ifndef FX_DEFER_DENSE
 #define FX_DEFER_DENSE 12   // tiles with more hit rows than this finish them in place (config 3 / 5: half of the rows match -- queueing those costs
                             // scattered from / to stores and a second read of the rows' bytes: measured slower, profiles/r03_defer_ab.txt)
@@ -522,6 +531,87 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
    }
 }
 
+// ---- speculative forward pass (round 4; FXP_F_SPEC_FWD) ----------------------------------------------------------------
+// The reference tries the candidates in order: the leading NUL, the row's first character, the second, ... (api_internal_m.F90:84-88,
+// 108-155) and takes the first one with a NON-EMPTY match.  For programs whose anchored automaton dies on the leading NUL, a walk of A from
+// the row's first byte that reaches an accept therefore IS the answer: from = 1, to = the longest accept of that walk -- no backward
+// pass.  Every lane walks its row from byte 0 in aligned 8-byte groups with the 8-state v_perm byte-level tables (one v_perm_b32 per byte,
+// three lookup buffers as in the aligned forward walk of fx_scan_tile) until every lane is dead (flags only: dead or accepted).  Returns
+// max_match (SPANS: the wrapped index of the byte after the longest match; flags only: nonzero) or 0 when the first character starts no
+// match: such rows take the backward + forward scan (queued per wave, or in place when the tile is dense in them).
+template <int CH, bool SPANS>
+__device__ __forceinline__ uint32_t fx_spec_forward(const uint4* tile, const uint8_t* tb, const uint32_t lane, const uint2* __restrict__ tabA,
+                                                    const FastParams& P, const bool on) {
+   uint32_t cur = on ? P.A_init : 0u;
+   uint32_t gl2 = 0xFFFFFFFFu, el2 = 0;
+   auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c <= (uint32_t)CH ? c : (uint32_t)CH)]; };
+   auto step8 = [&](const uint2 (&f)[8], const uint32_t g) {
+      const uint32_t entry = cur;
+      uint32_t st[8], t = cur;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+         t = fxstep(f[q], t, nullptr);
+         st[q] = t;
+      }
+      const uint32_t mx = max(max(max(max(st[0], st[1]), st[2]), max(max(st[3], st[4]), st[5])), max(st[6], st[7]));
+      cur = t;
+      const bool hit = mx >= P.acc_min;
+      gl2 = hit ? g : gl2;
+      el2 = hit ? entry : el2;
+   };
+   uint2 fa[8], fb[8], fc[8];
+   uint4 w0 = cellc(0u), w1 = cellc(1u), w2 = cellc(2u);
+   lookup8(fa, w0.x, w0.y, tabA);
+   lookup8(fb, w0.z, w0.w, tabA);
+#pragma unroll 1
+   for (uint32_t c = 0; c <= (uint32_t)CH; c += 3u) {   // six groups = chunks c, c + 1, c + 2 (chunk CH = the end-of-row column: NUL, then KILL symbols)
+      lookup8(fc, w1.x, w1.y, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      step8(fa, 2u * c);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fa, w1.z, w1.w, tabA);
+      w0 = cellc(c + 3u);
+      __builtin_amdgcn_sched_barrier(0);
+      step8(fb, 2u * c + 1u);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fb, w2.x, w2.y, tabA);
+      w1 = cellc(c + 4u);
+      __builtin_amdgcn_sched_barrier(0);
+      step8(fc, 2u * c + 2u);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fc, w2.z, w2.w, tabA);
+      w2 = cellc(c + 5u);
+      __builtin_amdgcn_sched_barrier(0);
+      step8(fa, 2u * c + 3u);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fa, w0.x, w0.y, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      step8(fb, 2u * c + 4u);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fb, w0.z, w0.w, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      step8(fc, 2u * c + 5u);
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_amdgcn_ballot_w64(cur != 0 && (SPANS || gl2 == 0xFFFFFFFFu)) == 0) break;
+   }
+   if (!SPANS) return gl2 != 0xFFFFFFFFu ? 3u : 0u;
+   uint32_t mm = 0;
+   if (__builtin_amdgcn_ballot_w64(gl2 != 0xFFFFFFFFu) != 0) {   // the exact symbol of the last accept: re-walk that group
+      const uint32_t g = gl2 != 0xFFFFFFFFu ? gl2 : 0u;
+      const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
+      uint2 fr8[8];
+      lookup8(fr8, rw.x, rw.y, tabA);
+      uint32_t st = el2, loc = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+         st = fxstep(fr8[q], st, nullptr);
+         loc = st >= P.acc_min ? (uint32_t)q : loc;
+      }
+      mm = gl2 != 0xFFFFFFFFu ? 8u * g + loc + 3u : 0u;
+   }
+   return mm;
+}
+
 // ---- `.match.` on a tile in LDS: one forward pass of the anchored automaton over every byte of the row from M_start (the state after
 // the optional leading NUL, api_internal_m.F90:280-289), verdict = the final state's FINAL entry (accept at ci = n + 2 or after the
 // trailing NUL, :296-302), behind the reference's literal / prefix / suffix gate (`gate`: 2 = TRUE, 0 = FALSE, 1 = the automaton
@@ -667,6 +757,10 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    __shared__ fx_nib bwideA[BSCH == 2 ? 256 : 1];
    __shared__ uint2 bpermA[BSCH == 3 ? 256 : 1];   // BSCH 3: byte-level tables, nibble format backwards, 8-state v_perm format forwards (FXP_F_BYTE_A8)
    __shared__ uint32_t pool_q[POOL ? 4 * 64 : 1];   // per-wave queues of exception rows
+   // speculative forward pass (fx_spec_forward): byte-level tables with the 8-state forward automaton, programs that say it is sound
+   // (fpb.spec: FXP_F_SPEC_FWD); rows whose first character starts no match are queued per wave for the backward + forward scan
+   constexpr bool SPEC = FX_SPEC_FWD != 0 && BSCH == 3 && !MATCH && !GEN;
+   __shared__ uint32_t spec_q[SPEC ? 4 * 64 : 1];
    // match compaction (see fx_scan_tile): rows of up to 64 bytes, where the exact start + first forward window are a third of a tile's
    // instructions (config 2: 21.0 -> 18.8 us); on longer rows its bookkeeping cost more than it saved on the BASELINE shapes
    // (config 5: +2 %, config 4: +1 %, profiles/r03_defer_ab.txt)
@@ -754,6 +848,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    uint32_t* myq = pool_q + (POOL ? wave * 64u : 0u);
+   uint32_t* mysq = spec_q + (SPEC ? wave * 64u : 0u);
 
    // results of one row.  `ordered`: the wave holds 64 consecutive rows (a tile of the batch): the packed flag word is its ballot;
    // a gathered row (exception queue) sets its bit in the word its tile's wave stored earlier.
@@ -878,23 +973,45 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    };
    bool live = MARKED ? tile_marked(wave_global) : true;   // the tile in `stage` is to be scanned
    if constexpr (MARKED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
+   // speculative pass: on while it pays (wave-uniform).  A tile where more than FX_SPEC_FAIL_MAX rows fail is scanned in place and turns
+   // it off; it is tried again FX_SPEC_RETRY tiles later (batches are rarely uniform: sorted inputs, sections of a file).
+   bool spec_on = SPEC && (fpb.spec & 1u) != 0u;
+   uint32_t spec_wait = 0;     // tiles until the next try
+   uint32_t spec_n = 0;        // rows in this wave's queue of rows the speculative pass could not answer (wave-uniform)
+   uint64_t spec_mask = 0;     // lanes whose row of the last speculative pass failed and is not yet queued (wave-uniform)
+   uint32_t spec_base = 0;     // ... the first row of that tile (wave-uniform: the rows are spec_base + lane)
    for (int64_t t = wave_global;;) {
       bool is_tile = false;
+      bool spec_gather = false;   // the gathered tile holds rows of the speculative pass's queue: byte-level scan, not the decode
       uint32_t take = 0;
       if (POOL && pend_mask != 0 && pool_n + (uint32_t)__builtin_popcountll(pend_mask) <= 64u) {
          if ((pend_mask >> lane) & 1ull) myq[pool_n + (uint32_t)__builtin_popcountll(pend_mask & ((1ull << lane) - 1ull))] = pend_row;
          pool_n += (uint32_t)__builtin_popcountll(pend_mask);
          pend_mask = 0;
       }
+      if (SPEC && spec_mask != 0 && spec_n + (uint32_t)__builtin_popcountll(spec_mask) <= 64u) {
+         if ((spec_mask >> lane) & 1ull) mysq[spec_n + (uint32_t)__builtin_popcountll(spec_mask & ((1ull << lane) - 1ull))] = spec_base + lane;
+         spec_n += (uint32_t)__builtin_popcountll(spec_mask);
+         spec_mask = 0;
+      }
       if (POOL && pend_mask != 0) {
          take = pool_n;   // the queue has to be drained before the pending rows fit
+      } else if (SPEC && spec_mask != 0) {
+         take = spec_n;
+         spec_gather = true;
       } else if (t < n_tiles) {
          is_tile = true;
       } else {
-         // end of the wave's tiles: what is left in its queue (no merging across the block's waves: waiting for the slowest wave
-         // behind a barrier cost more than the three partial passes it saved -- config 4: 126.8 -> 118.7 us)
-         if (!POOL || pool_n == 0u) break;
-         take = pool_n;
+         // end of the wave's tiles: what is left in its queues (no merging across the block's waves: waiting for the slowest wave
+         // behind a barrier cost more than the three partial passes it saved -- config 4: 126.8 -> 118.7 us); the speculative pass's
+         // queue first: its scan may add exception rows
+         if (SPEC && spec_n != 0u) {
+            take = spec_n;
+            spec_gather = true;
+         } else {
+            if (!POOL || pool_n == 0u) break;
+            take = pool_n;
+         }
       }
       int64_t row;
       bool row_ok;
@@ -927,7 +1044,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          // would write the whole L2 back (measured: +50 us on a 1M-row batch when every wave did that once)
          if (out_mode != 0u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
          row_ok = lane < take;
-         const uint32_t ridx = (POOL && row_ok) ? myq[lane] : 0u;
+         const uint32_t ridx = (POOL && row_ok) ? (spec_gather ? mysq[lane] : myq[lane]) : 0u;
          row = (int64_t)ridx;
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
          // (up to twelve loads in flight -- the whole row when it has that many chunks, two rounds of eight at 256 bytes: each round
@@ -944,11 +1061,32 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             for (int i = 0; i < GD; ++i)
                if (k0 + i < CH) tile[tile_cell(lane, k0 + i)] = g4[i];
          }
-         pool_n = 0;
+         if (spec_gather) spec_n = 0;
+         else pool_n = 0;
       }
       if constexpr (MATCH) mgate = match_gate(h, prog, tb, lane, L);   // (on the raw bytes: before any decode rewrites the cells)
       bool except = false;
       bool redo = false;
+      // the OR of this lane's row (the tile in LDS): "any byte >= 0x80" tests of the FXP_F_NEEDS_NONASCII shortcuts
+      auto row_or = [&]() {
+         uint32_t na = 0;
+#pragma unroll
+         for (int k = 0; k < CH; ++k) {
+            const uint4 c = tile[tile_cell(lane, k)];
+            na |= c.x | c.y | c.z | c.w;
+         }
+         return na;
+      };
+      if constexpr (HAS_B && !MATCH && !GEN && !RAGGED) {
+         // FXP_F_NEEDS_NONASCII: no match is made of ASCII symbols only -- a pure-ASCII tile holds none (60 instructions instead of a scan)
+         if (is_tile && !ALLB && !hint && (fpb.spec & 2u) != 0u) {
+            if (__builtin_amdgcn_ballot_w64((row_or() & 0x80808080u) != 0u) == 0) {
+               emit(row, row_ok, true, 0u, 0, 0, true);
+               continue;
+            }
+            hint = true;
+         }
+      }
       if (is_tile && !ALLB && !hint) {
          redo = scan(FxScanCfg<SCH, false, false>{}, row, row_ok, true, except);
          if (GEN && !redo) {
@@ -958,10 +1096,37 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       }
       const bool nonascii = !is_tile || hint || redo;   // (gathered rows always take the decode)
       if constexpr (HAS_B) {
-         if (is_tile && (ALLB || nonascii)) {
-            (void)scan(BCfg{}, row, row_ok, true, except);
-            pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
-            pend_row = (uint32_t)row;
+         if ((is_tile && (ALLB || nonascii)) || spec_gather) {
+            bool done = false;
+            if constexpr (SPEC) {
+               if (is_tile && !spec_on && (fpb.spec & 1u) != 0u && ++spec_wait >= (uint32_t)FX_SPEC_RETRY) spec_on = true;
+               if (is_tile && spec_on) {
+                  const uint32_t mm = fx_spec_forward<CH, SPANS>(tile, tb, lane, reinterpret_cast<const uint2*>(bpermA), fpb, row_ok);
+                  const bool ok = mm != 0u;
+                  uint64_t failm = __builtin_amdgcn_ballot_w64(row_ok && !ok);
+                  bool no_match = false;   // FXP_F_NEEDS_NONASCII: a failed row without a byte >= 0x80 holds no match at all
+                  if (failm != 0 && (fpb.spec & 2u) != 0u) {
+                     no_match = !ok && (row_or() & 0x80808080u) == 0u;
+                     failm = __builtin_amdgcn_ballot_w64(row_ok && !ok && !no_match);
+                  }
+                  if ((uint32_t)__builtin_popcountll(failm) <= (uint32_t)FX_SPEC_FAIL_MAX) {
+                     // api_internal_m.F90:140-148 with start = 2 (the row's first character): from = 1, to = max_match - 2, clamped to the row
+                     const int32_t tt = mm >= L + 2u ? (int32_t)L : (int32_t)mm - 2;
+                     emit(row, row_ok && (ok || no_match), true, ok ? 1u : 0u, ok ? 1 : 0, ok ? tt : 0, true);
+                     spec_mask = failm;
+                     spec_base = __builtin_amdgcn_readfirstlane((uint32_t)row - lane);
+                     done = true;
+                  } else {
+                     spec_on = false;   // too many rows start their match elsewhere (or hold none): the full scan, in place, for all of them
+                     spec_wait = 0;
+                  }
+               }
+            }
+            if (!done) {
+               (void)scan(BCfg{}, row, row_ok, is_tile, except);
+               pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
+               pend_row = (uint32_t)row;
+            }
          }
       }
       if constexpr (GEN) {
@@ -980,7 +1145,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
             emit(row, true, false, res.flag, res.from, res.to);
          }
       }
-      if (!GEN && ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii))) {
+      if (!GEN && !spec_gather && ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii))) {
          // On-device UTF-8 decode, in place in LDS, into fast-path symbol ids (fxrow::translate_cell16); the 4 bytes before / after
          // a cell are taken from the ORIGINAL neighbours.
          if (HAS_B && !is_tile) {
@@ -1095,19 +1260,21 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    // configs 2 and 4 (67 / 201 MB: 19 / 101 us in all) are best with ONE round (config 4 with six: 144 us).  So: one round per
    // 300 MB of rows.  FXAMD_ONE_GRID = blocks per CU in the grid, FXAMD_ONE_ROUND_MB = MB per round: experiment hooks.
    auto cap_grid = [&](const void* fn) {
-      static const int env_mult = std::getenv("FXAMD_ONE_GRID") ? std::atoi(std::getenv("FXAMD_ONE_GRID")) : 0;
+      const int env_mult = fx_env().one_grid;
       const size_t per_block = lds + static_b;
       int64_t by_lds = per_block > 0 ? (int64_t)((160 * 1024) / per_block) : 8;   // blocks per CU by LDS alone (used when the runtime cannot say)
       if (by_lds < 1) by_lds = 1;
       if (by_lds > 8) by_lds = 8;
       int64_t resident = resident_blocks_per_cu(fn, lds, (int)by_lds);
       if (resident > 8) resident = 8;
-      static const int env_mb = std::getenv("FXAMD_ONE_ROUND_MB") ? std::atoi(std::getenv("FXAMD_ONE_ROUND_MB")) : 0;
+      const int env_mb = fx_env().one_round_mb;
       int64_t rounds = (n * (int64_t)Lr) / ((int64_t)(env_mb > 0 ? env_mb : 300) << 20);
       if (rounds < 1) rounds = 1;
       if (rounds > 64) rounds = 64;
       const int64_t cap = 256 * (env_mult > 0 ? env_mult : resident * rounds);
       if (blocks > cap) blocks = cap;
+      const int env_blocks = fx_env().one_blocks;   // FXAMD_ONE_BLOCKS, test hook: a tiny grid, many tiles per wave
+      if (env_blocks > 0 && blocks > env_blocks) blocks = env_blocks;
    };
    if (is_match) {   // `.match.`: one verdict per row, no span
      if constexpr (BSCH == 3) {

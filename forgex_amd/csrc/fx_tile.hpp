@@ -20,6 +20,16 @@
 #include "program.h"
 #include "row_engine.hpp"
 
+// Test / experiment hooks (environment variables FXAMD_*), read ONCE per process -- the library's scalar callers make match calls in
+// loops, and a dozen getenv per enqueue is host time on their path.  fxamd_reload_env() (C ABI, tests only) reads them again.
+struct FxEnv {
+   bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, multipass, no_cache, no_multi, multi_always, multi_no_bytes, multi_inq, multi_serial,
+      host_register;
+   int64_t slice_rows;                                      // rows per enqueue (a multiple of 64)
+   int one_grid, one_round_mb, one_blocks, half_rounds;     // launch-grid experiments (0 = the built-in rule)
+};
+const FxEnv& fx_env();   // (fxamd.hip)
+
 #define FX_NEEDS_GENERAL 0xFFu   // marker the fast kernel leaves in flags[] for rows with a byte >= 0x80
 
 // =========================================================================================================
@@ -251,6 +261,8 @@ struct FastParams {
    uint32_t defer_tiles;    // first pass: tiles holding a byte >= 0x80 are deferred whole (a later pass handles them)
    uint32_t gate_word;      // marked-tile passes: which of the call's two words says whether there is anything to do
    uint32_t lit_len;        // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
+   uint32_t spec;           // byte-level tables of fx_search_one: bit 0 = FXP_F_SPEC_FWD (the speculative forward pass from the row's first character is
+                            // sound), bit 1 = FXP_F_NEEDS_NONASCII (a row without a byte >= 0x80 holds no match)
 };
 
 // 8 independent table lookups for 8 bytes.  Three table schemes share the kernels (template parameter SCH):
@@ -1470,8 +1482,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    if (CH <= 8 && Lr > 16u * CH && MODE == 0 && FX_HALF4 != 0 && FX_DEFER_LONG == 0) {
       // what a block costs (table staging, first tile without overlap) against what a finer grid gains at the tail: a round of about
       // 50 us (11 rounds at 10 M rows; measured: 3 rounds 0.506 ms, 8: 0.478, 12: 0.474, 16: 0.482); FXAMD_HALF_ROUNDS: experiment hook
-      static const int env_rounds = std::getenv("FXAMD_HALF_ROUNDS") ? std::atoi(std::getenv("FXAMD_HALF_ROUNDS")) : 0;
-      int64_t rounds = env_rounds;
+      int64_t rounds = fx_env().half_rounds;
       if (rounds <= 0) {   // one round per 225 MB of rows: a round of about 50 us (the same rule as the one-launch kernel's, fx_one.hpp)
          rounds = (n * (int64_t)Lr) / ((int64_t)225 << 20);
          if (rounds < 3) rounds = 3;

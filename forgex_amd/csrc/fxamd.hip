@@ -44,6 +44,46 @@ extern template hipError_t launch_multi<12> FX_MULTI_SIG;
 extern template hipError_t launch_multi<16> FX_MULTI_SIG;
 #endif
 
+// ---- test / experiment hooks: the FXAMD_* environment variables, read once (FxEnv, fx_tile.hpp) ----
+static FxEnv g_env;
+static std::once_flag g_env_once;
+static void env_load() {
+   auto on = [](const char* name) { return std::getenv(name) != nullptr; };
+   auto num = [](const char* name) {
+      const char* e = std::getenv(name);
+      return e ? std::atoi(e) : 0;
+   };
+   FxEnv e{};
+   e.no_half = on("FXAMD_NO_HALF");
+   e.force_general = on("FXAMD_FORCE_GENERAL");
+   e.no_w16 = on("FXAMD_NO_W16");
+   e.no_byte_dfa = on("FXAMD_NO_BYTE_DFA");
+   e.no_a8 = on("FXAMD_NO_A8");
+   e.no_spec = on("FXAMD_NO_SPEC");
+   e.multipass = on("FXAMD_MULTIPASS");
+   e.no_cache = on("FXAMD_NO_CACHE");
+   e.no_multi = on("FXAMD_NO_MULTI");
+   e.multi_always = on("FXAMD_MULTI_ALWAYS");
+   e.multi_no_bytes = on("FXAMD_MULTI_NO_BYTES");
+   e.multi_inq = on("FXAMD_MULTI_INQ");
+   e.multi_serial = on("FXAMD_MULTI_SERIAL");
+   e.host_register = on("FXAMD_HOST_REGISTER");
+   {
+      const char* v = std::getenv("FXAMD_SLICE_ROWS");
+      int64_t r = v ? std::atoll(v) & ~int64_t(63) : int64_t(1) << 30;
+      e.slice_rows = r < 64 ? int64_t(64) : r;
+   }
+   e.one_grid = num("FXAMD_ONE_GRID");
+   e.one_round_mb = num("FXAMD_ONE_ROUND_MB");
+   e.one_blocks = num("FXAMD_ONE_BLOCKS");
+   e.half_rounds = num("FXAMD_HALF_ROUNDS");
+   g_env = e;
+}
+const FxEnv& fx_env() {
+   std::call_once(g_env_once, env_load);
+   return g_env;
+}
+
 // =========================================================================================================
 // general kernel: one lane = one row, fxrow::run_row
 // =========================================================================================================
@@ -464,7 +504,7 @@ static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool span
    (void)h;
    (void)spans;
    (void)out_mode;
-   const bool off = std::getenv("FXAMD_NO_HALF") != nullptr;   // (test / experiment hook: these rows on the one-launch kernel)
+   const bool off = fx_env().no_half;   // (test / experiment hook: these rows on the one-launch kernel)
    return !off && scheme == 0 && row_len == 256;
 }
 
@@ -475,7 +515,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
-   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, 0u, po.defer_tiles, po.gate_word, 0};
+   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, 0u, po.defer_tiles, po.gate_word, 0, 0};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
       fp.inv = BYTES ? h.bw16_inv_A : 0u;
@@ -505,10 +545,10 @@ static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
 // class-level table scheme for these rows: -1 = tile kernel not applicable, 0 = v_perm (<= 8 states), 2 = wide v_perm (<= 16),
 // 1 = chain (tables must fit the CU's LDS next to the tiles)   [the numbers are the kernels' SCH template argument]
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if (std::getenv("FXAMD_FORCE_GENERAL")) return -1;   // test hook: the general kernel (one lane per row) for everything
+   if (fx_env().force_general) return -1;   // test hook: the general kernel (one lane per row) for everything
    if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return -1;
    if (h.flags & FXP_F_FAST_OK) return 0;
-   if ((h.flags & FXP_F_W16_OK) && !std::getenv("FXAMD_NO_W16")) return 2;
+   if ((h.flags & FXP_F_W16_OK) && !fx_env().no_w16) return 2;
    if (h.flags & FXP_F_CHAIN_OK) {
       const size_t need = (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
       if (need <= 150 * 1024) return 1;
@@ -516,10 +556,10 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    return -1;
 }
 // scheme of the byte-level tables: 2 = wide v_perm when both automata have <= 16 states, else 1 = chain
-static int bytes_scheme(const FxpHeader& h) { return ((h.flags & FXP_F_BYTE_W16) && !std::getenv("FXAMD_NO_W16")) ? 2 : 1; }
+static int bytes_scheme(const FxpHeader& h) { return ((h.flags & FXP_F_BYTE_W16) && !fx_env().no_w16) ? 2 : 1; }
 // byte-level tables usable for these rows: whole chunks only (no inert pad byte exists: every byte value means something)
 static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
-   if (std::getenv("FXAMD_NO_BYTE_DFA")) return false;   // test hook: exercise the decode pass instead
+   if (fx_env().no_byte_dfa) return false;   // test hook: exercise the decode pass instead
    if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || (!long_row(row_len) && row_len != 16 * tile_chunks(row_len))) return false;
    return (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
@@ -532,7 +572,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TR_bytes + h.byte_TA_bytes : h.chain_TR_bytes + h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 0u, 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u};
+                 0u, 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u, 0u};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.R_start = BYTES ? h.bw16_R_start : h.w16_R_start;
       fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
@@ -571,11 +611,12 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
 // FastParams of one table family: class-level tables of scheme `sch`, or (bytes) the byte-level tables in the chain / wide format
 static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u};
+                 0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u, 0u};
    if (sch == 3) {   // byte-level tables, FXP_F_BYTE_A8: nibble format backwards, 8-state v_perm format (replicated state bytes) forwards
       fp = params_of(h, 2, true);
       fp.A_init = h.b8_A_init * 0x01010101u;
       fp.acc_min = h.b8_acc_min * 0x01010101u;
+      fp.spec |= ((h.flags & FXP_F_SPEC_FWD) && !fx_env().no_spec) ? 1u : 0u;   // (FXAMD_NO_SPEC: test / experiment hook)
       return fp;
    }
    if (sch == 2) {   // encoded state bytes, replicated like the 8-state scheme's
@@ -601,13 +642,14 @@ static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
       fp.inv = sch == 2 ? h.R_inv : (sch == 1 ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
    if (h.mode == FXP_MODE_MATCH_ENGINE) fp.inv = bytes ? (sch == 2 ? h.bw16_inv_A : h.byte_inv_A) : 0u;   // `.match.`: A only (A_init holds M_start)
+   if (bytes && (h.flags & FXP_F_NEEDS_NONASCII) && !fx_env().no_spec) fp.spec |= 2u;   // pure-ASCII rows hold no match (fx_search_one's shortcuts)
    return fp;
 }
 template <int SCH, int BSCH, bool GEN>
 static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                                 int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode) {
    const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
-   const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
+   const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t table_bytes = (SCH == 1 ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u) +
                                 (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
@@ -641,7 +683,7 @@ static int one_bytes_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t r
    const size_t tiles_b = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1);
    const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 4096 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
    if (bytes_scheme(h) == 2 && tiles_b + cls_b + 4096 + 2048 <= 80 * 1024)   // (3: with the forward automaton in the v_perm format, FXP_F_BYTE_A8)
-      return (sch == 0 && (h.flags & FXP_F_BYTE_A8) && h.mode == FXP_MODE_SEARCH_ENGINE && !std::getenv("FXAMD_NO_A8")) ? 3 : 2;
+      return (sch == 0 && (h.flags & FXP_F_BYTE_A8) && h.mode == FXP_MODE_SEARCH_ENGINE && !fx_env().no_a8) ? 3 : 2;
    if (tiles_b + cls_b + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 + 2048 <= 150 * 1024) return 1;
    return 0;
 }
@@ -690,7 +732,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(h, sc0, row_len, true, out_mode)) && !std::getenv("FXAMD_MULTIPASS");
+                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(h, sc0, row_len, true, out_mode)) && !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -730,7 +772,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
       const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(h, scheme, row_len, d_from != nullptr, out_mode)) &&
-                              !std::getenv("FXAMD_MULTIPASS");
+                              !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
@@ -757,7 +799,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
-      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && utf8_tables && !std::getenv("FXAMD_MULTIPASS");
+      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && utf8_tables && !fx_env().multipass;
       if ((bytes || !utf8_tables || first_pass != FX_FP_OWN) && !marked_followup) {
          const int rc = grow_worklist(sc, n);
          if (rc != FXAMD_OK) return rc;
@@ -812,7 +854,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       if (marked_followup) {
          FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
-         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0};
+         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
          const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
 #define FX_MARKED(CH)                                                                                                              \
@@ -899,9 +941,14 @@ static void destroy_program(fxamd_program* p) {
    delete p;
 }
 
+#pragma GCC visibility push(default)   // the library is built with -fvisibility=hidden: only the C ABI is exported
 extern "C" {
 
 int fxamd_last_hip_error(void) { return g_last_hip_error; }
+void fxamd_reload_env(void) {   // tests only: not synchronised with calls in flight on other threads
+   (void)fx_env();
+   env_load();
+}
 int fxamd_device_count(void) {
    int c = 0;
    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
@@ -915,7 +962,7 @@ int fxamd_compile(const char* pattern, int64_t pattern_len, int op, fxamd_progra
    std::vector<fxamd_program*> evicted;
    try {   // nothing may cross the C boundary: the library never aborts the process
       evicted.reserve(2);   // (one insertion evicts at most one entry: the push_back below cannot throw)
-      const bool cached = pattern_len <= 4096 && !std::getenv("FXAMD_NO_CACHE");
+      const bool cached = pattern_len <= 4096 && !fx_env().no_cache;
       std::string key;
       if (cached) {
          key.assign(1, (char)('0' + op));
@@ -1127,14 +1174,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
 // Rows per enqueue: worklists, exception queues and gate counters hold 32-bit row numbers, so a batch of more rows than this (288 GB
 // of HBM hold 2^34 sixteen-byte rows) is enqueued slice by slice on the same stream.  A multiple of 64: slices are whole tiles and whole
 // words of the packed flags.  (FXAMD_SLICE_ROWS: test hook.)
-static int64_t slice_rows() {
-   static const int64_t v = [] {
-      const char* e = std::getenv("FXAMD_SLICE_ROWS");
-      int64_t r = e ? std::atoll(e) & ~int64_t(63) : int64_t(1) << 30;
-      return r < 64 ? int64_t(64) : r;
-   }();
-   return v;
-}
+static int64_t slice_rows() { return fx_env().slice_rows; }
 
 int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags, int32_t* d_from,
                              int32_t* d_to, void* hip_stream) {
@@ -1321,7 +1361,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          }
    }
    std::vector<int32_t> fused;
-   if (!long_row(row_len) && !std::getenv("FXAMD_NO_MULTI") && n <= slice_rows())   // (more rows than one enqueue takes: pattern by pattern, each sliced)
+   if (!long_row(row_len) && !fx_env().no_multi && n <= slice_rows())   // (more rows than one enqueue takes: pattern by pattern, each sliced)
       for (int32_t i = 0; i < m; ++i) {
          const FxpHeader& h = progs[i]->prog.hdr();
          if (first_of[(size_t)i] == i && progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&
@@ -1332,14 +1372,14 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
    // over 100 M x 128 B 15.4 ms against 16.9 ms pattern by pattern -- and LOSES on longer rows, whose single-pattern kernels run at more
    // waves per SIMD (half-row staging at 256 bytes: 3.67 against 3.21 ms; config 4's UTF-8 rows: 0.68 against 0.58 ms;
    // tools/exp_multi.py, gpurun call r03_c11): those run one pipeline per pattern.  FXAMD_MULTI_ALWAYS=1: test hook.
-   if (row_len > 128 && !std::getenv("FXAMD_MULTI_ALWAYS")) fused.clear();
+   if (row_len > 128 && !fx_env().multi_always) fused.clear();
    const int ch = tile_chunks(row_len);
    // byte-level tables in the shared pass (nibble format; 8 KB of LDS per pattern then): when some fused pattern has them for these rows
    std::vector<int> obs((size_t)m, 0);
    bool any_bytes = false;
    for (int32_t i : fused) {
       const int ob = one_bytes_scheme(progs[i]->prog.hdr(), d_rows, row_len, 0);
-      obs[(size_t)i] = (ob == 2 || ob == 3) && progs[i]->prog.hdr().mode == FXP_MODE_SEARCH_ENGINE && !std::getenv("FXAMD_MULTI_NO_BYTES") ? ob : 0;
+      obs[(size_t)i] = (ob == 2 || ob == 3) && progs[i]->prog.hdr().mode == FXP_MODE_SEARCH_ENGINE && !fx_env().multi_no_bytes ? ob : 0;
       any_bytes = any_bytes || obs[(size_t)i] != 0;
    }
    const int gmax = ch > 0 ? multi_max_patterns(ch, any_bytes) : 0;
@@ -1397,7 +1437,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
             // (finishing the exception rows inside the shared pass -- one mixed-pattern queue per wave -- is built and tested but OFF: a
             //  drained row decodes through its pattern's class map in GLOBAL memory, there is no LDS left for six of them, and the
             //  pass got slower: 0.898 against 0.750 ms for 6 UTF-8 patterns on config 4's rows; FXAMD_MULTI_INQ=1 turns it on)
-            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && std::getenv("FXAMD_MULTI_INQ")) {
+            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && fx_env().multi_inq) {
                a.inq[a.m] = 1u;
                shs[k - g0].exc_in_shared = true;
             }
@@ -1430,7 +1470,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       //  defers them; the scratch -- counter words, worklist -- is the one PREPARE chose on the caller's stream)
       std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
       SideStreams* ss = nullptr;
-      if (!std::getenv("FXAMD_MULTI_SERIAL")) {
+      if (!fx_env().multi_serial) {
          side_lock.lock();
          ss = side_streams(dev, g1 - g0);
          if (ss && hipEventRecord(ss->fork, st) != hipSuccess) ss = nullptr;
@@ -1506,7 +1546,7 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
    int64_t chunk_rows = (int64_t)((size_t(64) << 20) / rl) & ~int64_t(63);
    if (chunk_rows < 64) chunk_rows = 64;
    if (chunk_rows > n) chunk_rows = n;
-   const bool reg = std::getenv("FXAMD_HOST_REGISTER") != nullptr && row_len > 0;   // pin the caller's rows in place for the call (experiment)
+   const bool reg = fx_env().host_register && row_len > 0;   // pin the caller's rows in place for the call (experiment)
    bool registered = false;
    if (reg) registered = hipHostRegister(const_cast<uint8_t*>(h_rows), (size_t)n * rl, hipHostRegisterDefault) == hipSuccess;
    int rc = FXAMD_OK;
@@ -1648,3 +1688,4 @@ int fxamd_debug_stamps(unsigned long long* out) {
 }
 #endif
 }   // extern "C"
+#pragma GCC visibility pop

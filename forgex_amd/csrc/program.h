@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 14u
+#define FXP_VERSION 15u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -39,6 +39,9 @@ enum FxpFlags {
    FXP_F_W16_UTF8 = 1u << 14,       // ... and they hold the 128+class / SKIP rows (the decode pass may use them)
    FXP_F_BYTE_W16 = 1u << 15,       // the byte-level automata also exist in the 16-state nibble format
    FXP_F_BYTE_A8 = 1u << 18,        // searches: the byte-level FORWARD automaton has <= 8 states and also exists in the v_perm format (b8A)
+   FXP_F_SPEC_FWD = 1u << 19,       // ... and a walk of it from the row's first character decides the leftmost start by itself when it finds a match
+                                    // (the leading NUL is no start, no state survives U+FFFF, no candidate-list driver): the tile kernels' speculative pass
+   FXP_F_NEEDS_NONASCII = 1u << 20, // searches with byte-level tables: no non-empty match is made of ASCII symbols only -- a row without a byte >= 0x80 holds no match
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match
    FXP_F_RAGGED_OK = 1u << 11,      // symbol 255 is inert at the end of a row: rows whose length is not a multiple of 16 may be padded with it

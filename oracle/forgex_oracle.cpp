@@ -397,6 +397,7 @@ std::string tohex(const std::string& s) {
 }   // namespace
 
 // ---- C ABI for ctypes (tests / bench cpu_baseline only) -----------------------------------------------------
+#pragma GCC visibility push(default)   // built with -fvisibility=hidden: the checker exports its C entry points only
 extern "C" {
 
 int fxo_in(const char* pat, int64_t plen, const char* txt, int64_t tlen) {

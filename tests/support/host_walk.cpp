@@ -69,6 +69,7 @@ std::string tohex(const std::string& s) {
 }
 }   // namespace
 
+#pragma GCC visibility push(default)   // built with -fvisibility=hidden: the checker exports its C entry points only
 extern "C" {
 // returns status; writes flag/from/to for ONE row
 int hw_run(const char* pat, int64_t plen, int op, const uint8_t* row, int64_t L, int32_t* flag, int32_t* from, int32_t* to) {

@@ -692,7 +692,7 @@ def test_many_patterns_utf8_tiles_in_the_shared_pass(fx, monkeypatch):
             assert np.array_equal(f[i][:k].cpu().numpy(), of) and np.array_equal(a[i][:k].cpu().numpy(), oa) and np.array_equal(b[i][:k].cpu().numpy(), ob), (bad_frac, p)
 
 
-def test_many_patterns_fuzz_groups(fx):
+def test_many_patterns_fuzz_groups(fx, monkeypatch):
     """fx_search_multi under random pattern GROUPS: 2..10 generated patterns (whatever path each one qualifies for: shared first pass,
     own one-launch kernel, general kernel) against the same rows -- ASCII, mixed with valid and broken UTF-8, whole-chunk and ragged
     row lengths, long rows (no shared pass) -- flags and spans of every pattern vs the oracle, and flags-only calls."""
@@ -708,7 +708,7 @@ def test_many_patterns_fuzz_groups(fx):
               b"\x80", b"\xe3\x81", b"\xc0\xaf", b"\xf0\x9f\x98\x80", b"\xff", b"-", b"\n"]
     dev = torch.device("cuda")
     shared = 0
-    os.environ["FXAMD_MULTI_ALWAYS"] = "1"   # (the shared pass at every row length, not only where it is the default)
+    monkeypatch.setenv("FXAMD_MULTI_ALWAYS", "1")   # (the shared pass at every row length, not only where it is the default)
     for _ in range(groups):
         pats = []
         while len(pats) < rng.randint(2, 10):
@@ -739,7 +739,7 @@ def test_many_patterns_fuzz_groups(fx):
             assert np.array_equal(f[i].cpu().numpy(), of), (pats, i, L, n, progs[i].last_path())
             assert np.array_equal(a[i].cpu().numpy(), oa) and np.array_equal(b[i].cpu().numpy(), ob), (pats, i, L, n, progs[i].last_path())
             assert np.array_equal(f2[i].cpu().numpy(), of), (pats, i, L, n, "flags only")
-    os.environ.pop("FXAMD_MULTI_ALWAYS", None)
+    monkeypatch.delenv("FXAMD_MULTI_ALWAYS")
     assert shared >= groups   # the shared pass did run (most generated patterns fit the 8-state tables)
 
 
@@ -1320,3 +1320,83 @@ def test_few_exception_rows_chunk_parallel_scan(fx, L, monkeypatch):
         _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
         assert np.array_equal(f2, of), (pat, L, "flags only")
     assert n_run >= 20
+
+
+@pytest.mark.parametrize("L", [64, 128, 192, 256])
+def test_speculative_forward_pass_vs_oracle_and_full_scan(fx, L, monkeypatch):
+    """Round 4: the speculative forward pass of fx_search_one (fx_spec_forward, programs with FXP_F_SPEC_FWD): a walk of the anchored
+    byte-level automaton from the row's first character decides rows whose match starts there (api_internal_m.F90:84-88, 108-155:
+    the candidates are tried left to right); rows it cannot answer are queued per wave and take the backward + forward scan; a tile
+    dense in them is scanned in place and pauses the pass.  Rows with the match at the first character, later, nowhere, behind
+    blanks / NUL / LF, with structure errors before, inside and after the match, in sections whose share of failing rows runs from
+    0 to 100 % -- on a tiny grid (many tiles per wave: queue overflow, pause and retry) and on the default one; spans and flags only;
+    against the oracle and against the same kernel without the pass (FXAMD_NO_SPEC).  Patterns with and without the flag."""
+    import random
+    import torch
+    rng = random.Random(9000 + L)
+    greek = [chr(c).encode() for c in range(0x3B1, 0x3CA)]
+    hira = [chr(c).encode() for c in range(0x3041, 0x3094)]
+    other = ["é".encode(), "漢".encode(), b"\xf0\x9f\x98\x80", b"\xc0\xaf", b"\xe0\x80\xaf"]   # valid elsewhere, 4-byte, overlong forms
+    junk = [b"\x80", b"\xbf", b"\xce", b"\xe3\x81", b"\xe3", b"\xf0\x9f", b"\xff", b"\xf8", b"\xc1"]   # structure errors
+
+    def text(k):
+        return b"".join(rng.choice(greek if rng.random() < 0.5 else hira) for _ in range(k))
+
+    def ascii_run(k):
+        return bytes(rng.choice(b"abcxyz 09-_") for _ in range(k))
+
+    def make_row(fail):
+        if not fail:   # the match starts at the first character
+            kind = rng.random()
+            body = text(rng.randint(1, L // 2))
+            if kind < 0.15:
+                body += rng.choice(junk) + text(rng.randint(0, 5))          # a structure error ends the match
+            elif kind < 0.25:
+                body += rng.choice(other) + text(rng.randint(0, 5))
+            elif kind < 0.35:
+                body = text(L)                                              # runs to the row's end (possibly cut inside a character)
+        else:
+            kind = rng.random()
+            if kind < 0.35:
+                body = ascii_run(L)                                          # no match at all
+            elif kind < 0.6:
+                body = ascii_run(rng.randint(1, 20)) + text(rng.randint(1, 30))   # a later match
+            elif kind < 0.7:
+                body = rng.choice([b" ", b"\n", b"\0", b"\r\n"]) + text(rng.randint(1, 30))
+            elif kind < 0.85:
+                body = rng.choice(junk) + text(rng.randint(1, 30))          # a structure error first: exception row of the full scan
+            else:
+                body = rng.choice(other) + text(rng.randint(0, 30)) + rng.choice(junk)
+        body += ascii_run(L)
+        return np.frombuffer(body[:L], dtype=np.uint8)
+
+    shares = [0.0, 0.03, 0.1, 0.2, 0.3, 0.45, 1.0, 0.05]
+    tiles = 96
+    rows = np.stack([make_row(rng.random() < shares[(t // 3) % len(shares)]) for t in range(tiles) for _ in range(64)])[:64 * tiles - 17]
+    rows[64 * 40:64 * 43] = np.stack([np.frombuffer(ascii_run(L), dtype=np.uint8) for _ in range(64 * 3)])   # three pure-ASCII tiles (FXP_F_NEEDS_NONASCII shortcut)
+    dev_rows = torch.from_numpy(np.ascontiguousarray(rows)).cuda()
+    pats = ["[α-ωぁ-ん]+", "ぁ*[α-ω]", "[α-ω]+\\d*", "[α-ωぁ-ん]+[a-c]", "[ぁ-ん]*[α-ω]+", "[α-ω][ぁ-ん]?[a-z ]*", "[α-ω]+[ぁ-ん]*", "(α|β|ぁ)[α-ωぁ-ん]{2,}", "[α-ωぁ-ん]+$", "[^a]+",
+            "^[α-ω]+", "(あ|α)+."]
+    n_spec = 0
+    for pat in pats:
+        pat = pat.encode()
+        of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+        for blocks in ("2", ""):
+            monkeypatch.delenv("FXAMD_NO_SPEC", raising=False)
+            monkeypatch.setenv("FXAMD_NO_HALF", "1") if blocks else monkeypatch.delenv("FXAMD_NO_HALF", raising=False)   # (256-byte rows: both pipelines)
+            monkeypatch.setenv("FXAMD_ONE_BLOCKS", blocks) if blocks else monkeypatch.delenv("FXAMD_ONE_BLOCKS", raising=False)
+            prog = fx.Program(pat, fx.OP_SEARCH)
+            n_spec += 1 if (prog.info()["flags"] & (1 << 19)) and blocks else 0   # FXP_F_SPEC_FWD
+            f, a, b = prog.match_device(dev_rows)
+            ff, _, _ = prog.match_device(dev_rows, spans=False)
+            torch.cuda.synchronize()
+            f, a, b, ff = f.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy(), ff.cpu().numpy()
+            bad = np.nonzero((f != of) | (a != oa) | (b != ob))[0]
+            assert bad.size == 0, (pat, L, blocks, int(bad[0]), int(f[bad[0]]), int(a[bad[0]]), int(b[bad[0]]), int(of[bad[0]]), int(oa[bad[0]]), int(ob[bad[0]]), rows[bad[0]].tobytes())
+            assert np.array_equal(ff, of), (pat, L, blocks, "flags only", int(np.nonzero(ff != of)[0][0]))
+            monkeypatch.setenv("FXAMD_NO_SPEC", "1")
+            f2, a2, b2 = prog.match_device(dev_rows)
+            torch.cuda.synchronize()
+            assert np.array_equal(f2.cpu().numpy(), f) and np.array_equal(a2.cpu().numpy(), a) and np.array_equal(b2.cpu().numpy(), b), (pat, L, blocks, "no spec")
+    monkeypatch.delenv("FXAMD_NO_SPEC", raising=False)
+    assert n_spec >= 4   # the pass did run for the patterns it is meant for (`[^a]+`, `^...`, `.` lack the flag: U+FFFF / the NUL survive)

@@ -16,6 +16,7 @@ def run(pat, rows, label):
 for wide in (True, False):
     if wide: os.environ.pop("FXAMD_NO_W16", None)
     else: os.environ["FXAMD_NO_W16"]="1"
+    forgex_amd.lib().fxamd_reload_env()   # (the hooks are read once per process)
     lab="wide" if wide else "chain"
     for pat in ("\\d{3}-\\d{4}", "\\w+@\\w+\\.[a-z]+", "[a-z]{3,5}\\d{2,4}x", "(19|20)\\d\\d-(0[1-9]|1[012])"):
         run(pat, rows3, lab)

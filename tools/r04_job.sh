@@ -1,0 +1,34 @@
+#!/bin/bash
+# round 4 GPU jobs, one script with named steps:  tools/r04_job.sh <tag> <step> [<step> ...]
+# Steps write under gpurun_out/<tag>/.  Steps: spec_tests, suite, smoke, ab_cfg4, bench_<cfg>, driver
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+line() { python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d.get("roofline", {})
+    print(sys.argv[2], "value", round(d["value"]), "step_ms", round(d["ms_per_step"], 4), "kernel_ms", round(r.get("kernel_ms", 0), 4), "frac", round(r.get("frac", 0), 3),
+          "parity", (d.get("parity") or {}).get("mismatches"), "settled", (d.get("settled") or {}).get("ms_per_step"))
+except Exception as e:
+    print(sys.argv[2], "no bench line:", e)
+PY
+}
+for step in "$@"; do
+  case $step in
+    spec_tests) timeout 1500 python -m pytest tests -m gpu -x -q -k "speculative or config_rows_vs_oracle or exception_queues or few_exception or utf8_rows" > $OUT/spec_tests.log 2>&1; echo "spec_tests rc $?"; tail -5 $OUT/spec_tests.log ;;
+    suite) timeout 3000 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "suite rc $?"; tail -5 $OUT/pytest.log ;;
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc $?"; tail -3 $OUT/smoke.log ;;
+    ab_cfg4)   # interleaved A/B in one allocation: the speculative forward pass on / off
+      for rep in 1 2 3; do
+        python bench.py --config cfg4 --no-cpu-baseline --no-extras > $OUT/cfg4_spec_$rep.json 2> $OUT/cfg4_spec_$rep.err; line $OUT/cfg4_spec_$rep.json "cfg4 spec   $rep"
+        FXAMD_NO_SPEC=1 python bench.py --config cfg4 --no-cpu-baseline --no-extras > $OUT/cfg4_nospec_$rep.json 2> $OUT/cfg4_nospec_$rep.err; line $OUT/cfg4_nospec_$rep.json "cfg4 nospec $rep"
+      done
+      python bench.py --config cfg4 --flags-only --no-cpu-baseline --no-extras > $OUT/cfg4_flags.json 2> $OUT/cfg4_flags.err; line $OUT/cfg4_flags.json "cfg4 flags-only spec"
+      FXAMD_NO_SPEC=1 python bench.py --config cfg4 --flags-only --no-cpu-baseline --no-extras > $OUT/cfg4_flags_nospec.json 2> $OUT/cfg4_flags_nospec.err; line $OUT/cfg4_flags_nospec.json "cfg4 flags-only nospec" ;;
+    bench_*) cfg=${step#bench_}; python bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; line $OUT/bench_$cfg.json "bench $cfg" ;;
+    driver) python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; line $OUT/bench_driver.json "driver protocol" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
