@@ -237,6 +237,8 @@ def dryrun(args, rank, world, emit):
     flags = (idx % 3 == 0).to(torch.uint8)
     frm = ((idx % row_len) + 1).to(torch.int32) * flags
     to = torch.full_like(frm, row_len) * flags
+    census = fxdist.job_census(torch.device("cpu"))
+    per_rank = fxdist.gather_floats(0.001 * (rank + 1), torch.device("cpu"))
     tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     res = fxdist.gather_results(flags, frm, to, rows_per_gpu * world, row_len)
@@ -249,7 +251,8 @@ def dryrun(args, rank, world, emit):
     dist.destroy_process_group()
     if rank == 0:
         emit({"metric": "input GB/s scanned (.in. over 10M strings)", "value": None, "unit": "GB/s", "n_gpus": world, "dryrun": True,
-              "ranks_joined": int(tt.item()), "gather_ok": ok, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+              "ranks_joined": int(tt.item()), "gather_ok": ok, "rccl_ranks": census["ranks"], "devices": census["devices"],
+              "devices_distinct": census["distinct"], "collective_backend": census["backend"], "per_rank_ms_per_step": [x * 1e3 for x in per_rank], "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
               "config": {"workload": "dry run of the %d-rank plumbing on CPU (gloo); no GPU work" % world, "parallelism": "shard%d" % world,
                          "rows_per_gpu": rows_per_gpu}})
     return 0
@@ -305,8 +308,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the match path has no CPU fallback"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    census = None
     if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # who takes part, as RCCL sees it (not as WORLD_SIZE claims): an all-reduce of 1 and an all-gather of every rank's device identity
+        census = fxdist.job_census(dev)
+        assert census["ranks"] == world, census
+        assert census["distinct"] or world == 1, "two ranks share one GPU: %r" % (census["devices"],)
 
     cfg = args.config
     n_cfg, row_len = synth.SHAPES[cfg]
@@ -356,16 +364,20 @@ def main():
             step()
         barrier()
         dt = time.perf_counter() - t0
+        per_rank = [dt]
         if use_dist:
+            per_rank = fxdist.gather_floats(dt, dev)   # every rank's own time; the job's time is the slowest rank's
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        timed.per_rank = per_rank
         return dt
 
     # ---- the contract's region: exactly W untimed steps, then exactly K timed ones, max over ranks ------------------------------
     for _ in range(args.warmup):
         step()
     dt = timed(args.steps)
+    per_rank_ms = [x / args.steps * 1e3 for x in timed.per_rank]
     n_matches = int((flags != 0).sum().item())
     rows_all = rows_per_gpu * world
     if use_dist and args.scaling == "strong":
@@ -487,6 +499,8 @@ def main():
     # what a multi-GPU host does after the scan: each rank's results as ONE packed image (1 bit per flag + spans narrowed to the row
     # length, written by the search kernel itself for rows of up to 256 bytes), one gather to rank 0, unpacked there
     gather_ms = packed_step_ms = None
+    gather_info = None
+    unpacked = sizes = None
     if use_dist:
         packed = prog.match_device_packed(rows, spans=spans)
         for _ in range(5):
@@ -515,6 +529,10 @@ def main():
             assert sum(sizes) == n_gather and sizes[0] == rows_per_gpu
             # the gathered shard of rank 0 is what rank 0's plain call computed
             assert torch.equal(unpacked[0][0], flags) and (not spans or (torch.equal(unpacked[0][1], frm) and torch.equal(unpacked[0][2], to)))
+            moved = sum(int(img.numel()) for img in shards[1:])   # bytes that crossed xGMI into the root (rank 0's own image stays on its GPU)
+            gather_info = {"ms": gather_ms, "bytes_into_root": moved, "gbs_into_root": (moved / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
+                           "shard_rows": sizes, "bytes_per_row": (moved / max(1, sum(sizes[1:]))) if world > 1 else None,
+                           "note": "one RCCL gather of every rank's packed image (1 bit per flag + spans narrowed to the row length) + unpack on the root, timed between barriers"}
 
     # the other ranks are done: rank 0's host-side legs (whole-batch parity, CPU baseline) need no collective
     if use_dist:
@@ -534,6 +552,9 @@ def main():
             "settled": {"value": total_bytes / dt_settled / 1e9, "ms_per_step": dt_settled / args.steps * 1e3,
                         "note": "the same %d timed steps after %d more untimed launches (clock transient over)" % (args.steps, SETTLE)},
             "roofline": roofline, "gather_ms": gather_ms, "packed_step_ms": packed_step_ms, "flags_only": flags_only, "host_path": host_path,
+            # multi-GPU runs prove themselves: ranks and devices as the collectives saw them, every rank's own step time, the gather's bytes
+            "rccl_ranks": census["ranks"] if census else None, "devices": census["devices"] if census else None,
+            "devices_distinct": census["distinct"] if census else None, "per_rank_ms_per_step": per_rank_ms if use_dist else None, "gather": gather_info,
         }
         threads = os.cpu_count() or 1
         if not args.no_parity:
@@ -541,6 +562,26 @@ def main():
                 line["parity"] = full_parity(pattern, rows, flags, frm, to, threads)
             except Exception as e:
                 line["parity"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
+            # every OTHER rank's shard as it arrived on the root: the gathered + unpacked image against the host walker on that shard's
+            # rows, regenerated here from (config, start, count) -- the RCCL gather and the unpack are inside what is checked
+            if unpacked is not None and world > 1:
+                shard_checks = []
+                try:
+                    del rows
+                    for r in range(1, world):
+                        if args.scaling == "strong" and not args.rows:
+                            s_r = fxdist.shard_bounds(n_cfg, r, world)[0]
+                        else:
+                            s_r = r * rows_per_gpu
+                        rows_r = synth.batch(cfg, s_r, sizes[r], dev)
+                        f_r, a_r, b_r = unpacked[r] if spans else (unpacked[r][0], None, None)
+                        res_r = full_parity(pattern, rows_r, f_r, a_r, b_r, threads)
+                        shard_checks.append({"rank": r, "first_row": int(s_r), "rows": res_r["rows"], "mismatches": res_r["mismatches"]})
+                        del rows_r
+                    line["parity"]["gathered_shards"] = shard_checks
+                    line["parity"]["gathered_mismatches"] = sum((c["mismatches"] or 0) for c in shard_checks)
+                except Exception as e:
+                    line["parity"]["gathered_shards"] = "failed: %r" % (e,)
         else:
             line["parity"] = None
         if not args.no_cpu_baseline:

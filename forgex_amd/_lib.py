@@ -89,6 +89,19 @@ def lib():
     L.fxamd_device_count.restype = c.c_int
     L.fxamd_reload_env.argtypes = []
     L.fxamd_reload_env.restype = None
+    L.fxamd_batch_upload.argtypes = [vp, i64, i64, c.POINTER(vp)]
+    L.fxamd_batch_wrap.argtypes = [vp, i64, i64, c.POINTER(vp)]
+    L.fxamd_batch_free.argtypes = [vp]
+    L.fxamd_batch_free.restype = None
+    L.fxamd_batch_info.argtypes = [vp, c.POINTER(i64), c.POINTER(i64)]
+    L.fxamd_batch_run.argtypes = [c.POINTER(vp), c.c_int32, vp, c.c_int]
+    L.fxamd_batch_sync.argtypes = [vp]
+    L.fxamd_batch_fetch.argtypes = [vp, c.c_int32, vp, vp, vp]
+    L.fxamd_batch_count.argtypes = [vp, c.c_int32, c.POINTER(i64)]
+    L.fxamd_batch_results.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), c.POINTER(vp), i32p, c.POINTER(vp)]
+    for name in ("fxamd_batch_upload", "fxamd_batch_wrap", "fxamd_batch_info", "fxamd_batch_run", "fxamd_batch_sync", "fxamd_batch_fetch",
+                 "fxamd_batch_count", "fxamd_batch_results"):
+        getattr(L, name).restype = c.c_int
     L.fxamd_host_register.argtypes = [vp, i64]
     L.fxamd_host_register.restype = c.c_int
     L.fxamd_host_unregister.argtypes = [vp]
@@ -102,5 +115,8 @@ EXPORTED_SYMBOLS = [
     "fxamd_program_blob", "fxamd_program_from_blob", "fxamd_program_info", "fxamd_strerror", "fxamd_strerror_copy", "fxamd_program_upload", "fxamd_program_reserve",
     "fxamd_match_batch_device", "fxamd_packed_layout", "fxamd_match_batch_device_packed", "fxamd_unpack_results", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
     "fxamd_host_register", "fxamd_host_unregister", "fxamd_f_compile", "fxamd_f_program_free", "fxamd_f_strerror_copy", "fxamd_f_match_batch_host",
+    "fxamd_batch_upload", "fxamd_batch_wrap", "fxamd_batch_free", "fxamd_batch_info", "fxamd_batch_run", "fxamd_batch_sync", "fxamd_batch_fetch",
+    "fxamd_batch_count", "fxamd_batch_results", "fxamd_f_batch_upload", "fxamd_f_batch_wrap", "fxamd_f_batch_free", "fxamd_f_batch_run",
+    "fxamd_f_batch_sync", "fxamd_f_batch_fetch", "fxamd_f_batch_count",
 ]
 BENCH_SYMBOLS = ["fxamd_launch_fast_only", "fxamd_reload_env"]   # include/forgex_amd_bench.h: measurement hooks, not part of the boundary

@@ -294,3 +294,68 @@ def regex(pattern, text):
 def regex_f(pattern, text):
     """`regex_f(pattern, text)` -> matched substring ('' when none or when the pattern is invalid)."""
     return regex(pattern, text)[0]
+
+
+class Batch:
+    """Rows resident in HBM across calls and patterns, for hosts without a device runtime (what the Fortran module's type(fx_batch)
+    binds: fxamd_batch_* of include/forgex_amd.h).  `rows`: a C-contiguous uint8 numpy array [n, row_len] (uploaded once) or a torch
+    CUDA tensor (wrapped, not copied).  run() enqueues one or more programs and leaves the results on the device; fetch() / count()
+    bring back one result set / the number of matching rows."""
+
+    def __init__(self, rows):
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        self._keep = None
+        if isinstance(rows, np.ndarray):
+            if rows.dtype != np.uint8 or rows.ndim != 2 or not rows.flags.c_contiguous:
+                raise ValueError("rows must be a C-contiguous uint8 array [n, row_len]")
+            n, rl = rows.shape
+            rc = L.fxamd_batch_upload(rows.ctypes.data_as(ctypes.c_void_p), n, rl, ctypes.byref(h))
+        else:
+            if not rows.is_cuda or rows.dim() != 2 or not rows.is_contiguous():
+                raise ValueError("rows must be a contiguous uint8 CUDA tensor [n, row_len]")
+            n, rl = rows.shape
+            self._keep = rows
+            rc = L.fxamd_batch_wrap(ctypes.c_void_p(rows.data_ptr()), n, rl, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError("fxamd_batch_upload / _wrap failed: %d" % rc)
+        self._h, self.n, self.row_len = h, int(n), int(rl)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().fxamd_batch_free(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def run(self, progs, spans=True):
+        progs = [progs] if isinstance(progs, Program) else list(progs)
+        arr = (ctypes.c_void_p * len(progs))(*[p._h for p in progs])
+        rc = _lib.lib().fxamd_batch_run(arr, len(progs), self._h, 1 if spans else 0)
+        if rc != 0:
+            raise RuntimeError("fxamd_batch_run failed: %d" % rc)
+
+    def sync(self):
+        rc = _lib.lib().fxamd_batch_sync(self._h)
+        if rc != 0:
+            raise RuntimeError("fxamd_batch_sync failed: %d" % rc)
+
+    def fetch(self, which=0, spans=True):
+        flags = np.empty(self.n, np.uint8)
+        frm = np.empty(self.n, np.int32) if spans else None
+        to = np.empty(self.n, np.int32) if spans else None
+        vp = ctypes.c_void_p
+        rc = _lib.lib().fxamd_batch_fetch(self._h, which, flags.ctypes.data_as(vp), frm.ctypes.data_as(vp) if spans else None,
+                                          to.ctypes.data_as(vp) if spans else None)
+        if rc != 0:
+            raise RuntimeError("fxamd_batch_fetch failed: %d" % rc)
+        return flags, frm, to
+
+    def count(self, which=0):
+        c = ctypes.c_int64(0)
+        rc = _lib.lib().fxamd_batch_count(self._h, which, ctypes.byref(c))
+        if rc != 0:
+            raise RuntimeError("fxamd_batch_count failed: %d" % rc)
+        return int(c.value)

@@ -62,6 +62,7 @@ struct FxScanCtx {
    uint32_t lane, L, Lr;
    bool whole, raw;
    uint32_t pre_na;
+   const FxTail* tl = nullptr;   // TAIL scans (ragged rows of fx_search_one, fx_tile.hpp "Ragged rows, round 4"): L = Lr, the cells are walked as 16*CH bytes
 };
 // Match compaction (DEFERQ): the exact start and the forward pass are per-ROW work that only rows with a hit need, but a
 // wave pays for them per TILE -- at full price when a few lanes in 64 have a hit (config 2: one row in ten matches).  Unless the tile
@@ -86,6 +87,9 @@ struct FxScanCtx {
 #ifndef FX_FWD_DIRECT
 #define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
 #endif
+#ifndef FX_ONE_MINW
+#define FX_ONE_MINW 1   // minimum waves per SIMD fx_search_one is compiled for (experiment hook: tools/ru_one.sh)
+#endif
 #ifndef FX_SPEC_FWD
 #define FX_SPEC_FWD 1         // speculative forward pass from the row's first character (fx_spec_forward; programs with FXP_F_SPEC_FWD)
 #endif
@@ -108,7 +112,7 @@ struct FxNoFlush {
    __device__ __forceinline__ void operator()() const {}
 };
 template <int CH, bool SPANS, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool PREPAD, bool DEFERQ = false, int S_A = S_,
-          class TabT, class TabTA, class Emit, class Flush = FxNoFlush>
+          bool TAIL = false, class TabT, class TabTA, class Emit, class Flush = FxNoFlush>
 __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __restrict__ tabR, const TabTA* __restrict__ tabA, const uint8_t* TRp,
                                              const uint8_t* TAp, const FastParams& P, const int64_t row, const bool row_ok, const bool ordered,
                                              bool& except, Emit& emit, FxFwdQueue* fq = nullptr, Flush flush = Flush()) {
@@ -124,11 +128,64 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       const bool whole = c.whole, raw = c.raw;
       (void)Lr;
       (void)whole;
+      static_assert(!TAIL || (!RAGGED && !PREPAD && !DEFERQ), "TAIL: the round-4 ragged scheme (no pad symbol, no match compaction)");
+      const uint32_t Lc = TAIL ? 16u * (uint32_t)CH : L;   // what the left-to-right fetches address: the cells (TAIL: the NUL and KILL symbols sit behind the text)
       uint32_t state = P.R_start;
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
       uint32_t na = 0;
       if (PREPAD) na = c.pre_na;
       else if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);
+      if constexpr (TAIL) {
+         // right-to-left from the row's LAST byte: the chunk the row ends in over its valid bytes, then whole chunks in a rolled loop
+         // (the chunk count is a run-time value here); same two lookup buffers as below
+         const FxTail& T = *c.tl;
+         F fa[8], fb[8];
+         if (T.nb != 0u) {
+            const uint4 wp = tile[tile_cell(lane, T.kt)];
+            if (!DECODED) na |= fx_tail_or(wp, T.nb);
+            if (T.nb > 8u) {
+               lookup8(fa, wp.z, wp.w, tabR);
+               const uint32_t entry = state;
+               const uint32_t mx = chain8_back_n(fa, state, TRp, T.nb - 8u);
+               gsel = mx >= P.hit_min ? 2u * T.kt + 1u : gsel;
+               esel = mx >= P.hit_min ? entry : esel;
+            }
+            lookup8(fb, wp.x, wp.y, tabR);
+            const uint32_t entry = state;
+            const uint32_t nv0 = T.nb < 8u ? T.nb : 8u;
+            const uint32_t mx = nv0 == 8u ? chain8_back(fb, state, TRp) : chain8_back_n(fb, state, TRp, nv0);
+            gsel = mx >= P.hit_min ? 2u * T.kt : gsel;
+            esel = mx >= P.hit_min ? entry : esel;
+         }
+         if (T.kt != 0u) {
+            uint4 wk = tile[tile_cell(lane, T.kt - 1u)];
+            lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll 1
+            for (uint32_t k = T.kt - 1u;; --k) {
+               if (!DECODED) na |= wk.x | wk.y | wk.z | wk.w;
+               lookup8(fb, wk.x, wk.y, tabR);
+               __builtin_amdgcn_sched_barrier(0);
+               {
+                  const uint32_t entry = state;
+                  const uint32_t mx = chain8_back(fa, state, TRp);
+                  gsel = mx >= P.hit_min ? 2u * k + 1u : gsel;
+                  esel = mx >= P.hit_min ? entry : esel;
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               wk = tile[tile_cell(lane, k != 0u ? k - 1u : 0u)];   // (after the last chunk: chunk 0 once more, unused)
+               lookup8(fa, wk.z, wk.w, tabR);
+               __builtin_amdgcn_sched_barrier(0);
+               {
+                  const uint32_t entry = state;
+                  const uint32_t mx = chain8_back(fb, state, TRp);
+                  gsel = mx >= P.hit_min ? 2u * k : gsel;
+                  esel = mx >= P.hit_min ? entry : esel;
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               if (k == 0u) break;
+            }
+         }
+      } else
       // (Three lookup buffers -- a group's lookups two chains ahead, as in the forward walk and in fx_match_tile below -- do NOT pay here: with the
       //  max tree and the selects a group's chain is ~60 cycles and the two-buffer distance already ~125, an LDS round trip; measured in rolled
       //  trips: config 5 +1.3 %, 256-byte rows on this kernel +2.7 %; fully unrolled: +38 % -- profiles/r03_pipe3_ab.txt.)
@@ -212,8 +269,15 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          uint32_t st = esel, loc = 8;
 #pragma unroll
          for (int i = 7; i >= 0; --i) {
-            st = fxstep(f[i], st, TRp);
-            loc = st >= P.hit_min ? (uint32_t)i : loc;
+            if constexpr (TAIL) {   // the group the row ends in: only its text bytes were walked
+               const uint32_t nx = fxstep(f[i], st, TRp);
+               const bool in_text = g * 8u + (uint32_t)i < L;
+               st = in_text ? nx : st;
+               loc = (in_text && nx >= P.hit_min) ? (uint32_t)i : loc;
+            } else {
+               st = fxstep(f[i], st, TRp);
+               loc = st >= P.hit_min ? (uint32_t)i : loc;
+            }
          }
          s = hit ? g * 8u + 2u + loc : 0u;
       }
@@ -236,7 +300,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          const uint32_t nrem = (0u - j) & 7u;
          if (__builtin_amdgcn_ballot_w64(cur != 0 && nrem != 0u) != 0) {
             uint32_t o1[2];
-            fetch_groups<RAGGED, 1>(o1, tb, lane, j, (uint32_t)L);
+            fetch_groups<RAGGED, 1>(o1, tb, lane, j, Lc);
             FA f8[8];
             lookup8(f8, o1[0], o1[1], tabA);
 #pragma unroll
@@ -418,7 +482,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             // all lookups issued before the chain
             constexpr int NG = CH <= 4 ? 2 : 4;
             uint32_t o[2 * NG];
-            fetch_groups<RAGGED, NG>(o, tb, lane, j, (uint32_t)L);
+            fetch_groups<RAGGED, NG>(o, tb, lane, j, Lc);
             constexpr int GB = NG;   // 8-symbol groups whose lookups are issued together
             uint32_t gl = 0xFFFFFFFFu, el = 0, blo = 0, bhi = 0;
 #pragma unroll
@@ -469,14 +533,14 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
             uint32_t gb = j & ~7u;
             uint32_t t0[2], t1[2];
-            group_words<RAGGED, false>(t0[0], t0[1], tb, lane, gb, (uint32_t)L);
-            group_words<RAGGED, false>(t1[0], t1[1], tb, lane, gb + 8u, (uint32_t)L);
+            group_words<RAGGED, false>(t0[0], t0[1], tb, lane, gb, Lc);
+            group_words<RAGGED, false>(t1[0], t1[1], tb, lane, gb + 8u, Lc);
             // per round only "any accept" (one max tree) + the entry state and the round's symbols are kept; the last accepting round
             // is re-walked afterwards for the exact symbol (as in the window above) -- 4 instructions per round instead of 16
             uint32_t jl = 0xFFFFFFFFu, el2 = 0, lo2 = 0, hi2 = 0;
             do {
                uint32_t t2[2];
-               group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, (uint32_t)L);
+               group_words<RAGGED, false>(t2[0], t2[1], tb, lane, gb + 16u, Lc);
                const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
                const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
                FA f8[8];
@@ -617,7 +681,7 @@ __device__ __forceinline__ uint32_t fx_spec_forward(const uint4* tile, const uin
 // trailing NUL, :296-302), behind the reference's literal / prefix / suffix gate (`gate`: 2 = TRUE, 0 = FALSE, 1 = the automaton
 // decides; fxrow::match_gate, evaluated by the caller on the RAW bytes).  Table families, REDO_TILE / ROW_EXC / `except` as in
 // fx_scan_tile; byte-level tables: a row whose walk ends inside a character or in the INVALID state (FINAL = 2) is an exception.
-template <int CH, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, class TabT, class Emit>
+template <int CH, bool RAGGED, int S_, bool BYTES, bool DECODED, bool REDO_TILE, bool ROW_EXC, bool TAIL = false, class TabT, class Emit>
 __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __restrict__ tabA, const uint8_t* TAp, const FastParams& P, const FxpHeader* h,
                                               const uint32_t gate, const int64_t row, const bool row_ok, const bool ordered, bool& except, Emit& emit) {
    constexpr bool CHAIN = S_ == 1, WIDE = S_ == 2;
@@ -630,7 +694,34 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
    uint32_t st = P.A_init;   // = M_start
    uint32_t na = 0;
    if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);   // pads (symbol 255) are the identity for A
-   if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= FX_MATCH_P3_MINCH && !RAGGED) {
+   static_assert(!TAIL || !RAGGED, "TAIL: the round-4 ragged scheme (no pad symbol)");
+   if constexpr (TAIL) {
+      // ragged rows (fx_tile.hpp, "Ragged rows, round 4"): whole chunks in a rolled loop, then the chunk the row ends in over its text bytes
+      const FxTail& T = *c.tl;
+      F fa[8], fb[8];
+      uint4 wk = tile[tile_cell(lane, 0)];
+      lookup8(fa, wk.x, wk.y, tabA);
+#pragma unroll 1
+      for (uint32_t k = 0; k < T.kt; ++k) {
+         if (!DECODED) na |= wk.x | wk.y | wk.z | wk.w;
+         lookup8(fb, wk.z, wk.w, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fa, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+         wk = tile[tile_cell(lane, k + 1u)];   // (k + 1 <= kt <= CH - 1: a ragged row is shorter than 16 * CH bytes)
+         lookup8(fa, wk.x, wk.y, tabA);
+         __builtin_amdgcn_sched_barrier(0);
+         chain8_fwd(fb, st, TAp);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (T.nb != 0u) {   // `wk` is chunk kt, `fa` the lookups of its first group
+         if (!DECODED) na |= fx_tail_or(wk, T.nb);
+         if (T.nb > 8u) lookup8(fb, wk.z, wk.w, tabA);
+         if (T.nb >= 8u) chain8_fwd(fa, st, TAp);
+         else chain8_fwd_n(fa, st, TAp, T.nb);
+         if (T.nb > 8u) chain8_fwd_n(fb, st, TAp, T.nb - 8u);
+      }
+   } else if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= FX_MATCH_P3_MINCH && !RAGGED) {
       // 8-state tables: THREE lookup buffers, a group's lookups issued two chains ahead of its use (a chain of eight v_perm_b32 is 32 cycles:
       // one chain ahead, the lookups come back late -- see the aligned forward walk of fx_scan_tile).  Three chunks per trip.  Measured
       // (profiles/r03_pipe3_ab.txt): 10 M x 256 B 0.476-0.488 -> 0.415-0.430 ms (two waves per SIMD), 12.5 M x 128 B 0.290 -> 0.263 ms (three).
@@ -736,14 +827,15 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 // FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
 // and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
-__global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
+__global__ __launch_bounds__(256, FX_ONE_MINW) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr) {
    if (MARKED && gate[0] == 0u) return;   // nothing was deferred
    // out_mode 0: flags u8[n], from / to int32[n].  out_mode 1 / 2 / 4: PACKED results (what a multi-GPU host gathers):
    // `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit word i >> 6: the ballot of the tile's wave, one store per tile),
    // `from` / `to` = arrays of that many bytes per row (uint8 / uint16 / int32).
-   static_assert(!(RAGGED && BSCH != 0), "byte-level tables: whole chunks (no inert pad byte exists)");
+   // RAGGED: rows of any length 2 <= Lr < 16 * CH, left-aligned in their cells with the trailing NUL and KILL symbols behind the text
+   // (fx_tile.hpp, "Ragged rows, round 4"): no pad symbol, so every table family -- the byte-level ones too -- runs on them
    static_assert(!MATCH || (!SPANS && !MARKED), "`.match.` has no span and no multi-pass first pass");
    constexpr bool HAS_B = BSCH != 0, ALLB = HAS_B && SCH != 0, POOL = HAS_B || GEN;
    using BCfg = FxScanCfg<(BSCH == 3 ? 2 : (BSCH != 0 ? BSCH : 1)), true, false, (BSCH == 3 ? 0 : (BSCH != 0 ? BSCH : 1))>;   // the byte-level tables' scan
@@ -764,7 +856,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    // match compaction (see fx_scan_tile): rows of up to 64 bytes, where the exact start + first forward window are a third of a tile's
    // instructions (config 2: 21.0 -> 18.8 us); on longer rows its bookkeeping cost more than it saved on the BASELINE shapes
    // (config 5: +2 %, config 4: +1 %, profiles/r03_defer_ab.txt)
-   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED && !MATCH && CH <= 4;
+   constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED && !MATCH && CH <= 4 && !RAGGED;
    __shared__ uint32_t fwd_q[DEFERQ ? 4 * 128 : 1];   // per-wave queues of rows whose exact start + forward pass are finished 64 at a time
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
@@ -789,8 +881,9 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    }
    __builtin_amdgcn_sched_barrier(0);   // (the table reads stay ahead of the tile's loads: their addresses wait for the header's offsets)
    uint4 stage[CH];
+   const FxTail tl = fx_tail_of(RAGGED ? Lr : 16u * CH);
    if constexpr (!MARKED) {
-      if (RAGGED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, true, Lr);
+      if (RAGGED) load_tile_rag<CH>(stage, rows, wave_global << 6, n, lane, tl);
       else load_tile<CH>(stage, rows, wave_global << 6, n, lane, true);
    }
    // ---- tables -> LDS ----
@@ -842,10 +935,11 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    const bool raw = (h->flags & FXP_F_RAW_BYTES) != 0;   // literal search: bytes are symbols, nothing is decoded
    uint4* tile = tiles + wave * (64 * (CH + 1));
    // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (see fx_search_fast)
-   tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
-   const bool whole = RAGGED && (Lr & 15u) == 0u;
-   if (whole)
-      for (uint32_t k = Lr >> 4; k < (uint32_t)CH; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+   // (ragged rows: the NUL sits inside the row's cells, right behind the text, and this column holds KILL symbols only -- a second NUL would
+   //  be a second line end to patterns like `$$`)
+   tile[tile_cell(lane, CH)] = make_uint4(RAGGED ? 0xFEFEFEFEu : 0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   const bool whole = false;
+   if (RAGGED) fx_tail_init<CH>(tile, lane, tl);   // chunks behind the text: the trailing NUL / KILL symbols, written once
    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
    uint32_t* myq = pool_q + (POOL ? wave * 64u : 0u);
    uint32_t* mysq = spec_q + (SPEC ? wave * 64u : 0u);
@@ -886,7 +980,7 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
    };
 
    // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
-   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u};
+   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u, &tl};
    // tables of one family (class-level / byte-level) in the scheme `S_`, handed to `fn(tabR, tabA, TRp, TAp, P)`
    auto with_tables = [&](auto cfg, auto&& fn) {
       using C = decltype(cfg);
@@ -954,10 +1048,10 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          if constexpr (MATCH) {
             (void)tabR;
             (void)TRp;
-            return fx_match_tile<CH, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN>(sctx, tabA, TAp, P, h, mgate, row, row_ok, ordered, except, emit);
+            return fx_match_tile<CH, false, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, RAGGED>(sctx, tabA, TAp, P, h, mgate, row, row_ok, ordered, except, emit);
          } else {
-            return fx_scan_tile<CH, SPANS, RAGGED, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ, C::sch_a>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok, ordered,
-                                                                                                             except, emit, &fwdq, flush_fwd);
+            return fx_scan_tile<CH, SPANS, false, S_, BYTES, DECODED, (HAS_B || !GEN), GEN, false, DEFERQ, C::sch_a, RAGGED>(sctx, tabR, tabA, TRp, TAp, P, row, row_ok,
+                                                                                                                  ordered, except, emit, &fwdq, flush_fwd);
          }
       });
    };
@@ -1022,19 +1116,21 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          const bool process = live;
          if (MARKED) hint = true;   // (that is why the first pass left the tile)
          else if (!ALLB && !raw && (HAS_B || !GEN)) {
-            const uint32_t smp = stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z;
+            // (ragged rows: the staging registers behind chunk nch - 1 were not loaded)
+            const uint32_t smp = RAGGED ? (stage[0].x | stage[0].y | stage[0].w) : (stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z);
             hint = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
          }
          if (process) {
-            if (RAGGED && (Lr & 15u) == 0u) store_tile_rt<CH>(stage, tile, lane, Lr >> 4);
-            else if (RAGGED) store_tile_relayout<CH>(stage, tile, lane, Lr);
-            else store_tile<CH>(stage, tile, lane);
+            if (RAGGED) {
+               store_tile_rag<CH>(stage, tile, lane, tl);
+               fx_tail_patch(tile, lane, tl);
+            } else store_tile<CH>(stage, tile, lane);
          }
          // the ONE place the staging registers are reloaded; a tile behind the last one, or one this pass skips, is "loaded" with
          // zero valid bytes
          t += wave_stride;
          if (MARKED) live = tile_marked(t);
-         if (RAGGED) load_tile<CH>(stage, rows, t << 6, n, lane, true, Lr);
+         if (RAGGED) load_tile_rag<CH>(stage, rows, t << 6, n, lane, tl, live);
          else load_tile<CH>(stage, rows, t << 6, n, lane, live);
          if (!process) continue;
       } else {
@@ -1047,6 +1143,12 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          const uint32_t ridx = (POOL && row_ok) ? (spec_gather ? mysq[lane] : myq[lane]) : 0u;
          row = (int64_t)ridx;
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
+         // (ragged rows: whole chunks as unaligned 16-byte loads, the chunk the row ends in from the row's last 16 bytes; GEN: the general
+         //  procedure reads its rows from global memory)
+         if (RAGGED && !GEN) {
+            gather_row_rag<CH>(tile, lane, rows + row * (int64_t)L, row_ok, tl);
+            fx_tail_patch(tile, lane, tl);
+         }
          // (up to twelve loads in flight -- the whole row when it has that many chunks, two rounds of eight at 256 bytes: each round
          //  is a trip to L2 / HBM that the end of the kernel waits for; the staging registers hold the next tile's loads and stay
          //  untouched)
@@ -1070,14 +1172,22 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
       // the OR of this lane's row (the tile in LDS): "any byte >= 0x80" tests of the FXP_F_NEEDS_NONASCII shortcuts
       auto row_or = [&]() {
          uint32_t na = 0;
+         if constexpr (RAGGED) {   // text bytes only: the NUL / KILL symbols behind the text are not the row's
+            for (uint32_t k = 0; k < tl.kt; ++k) {
+               const uint4 c = tile[tile_cell(lane, k)];
+               na |= c.x | c.y | c.z | c.w;
+            }
+            if (tl.nb != 0u) na |= fx_tail_or(tile[tile_cell(lane, tl.kt)], tl.nb);
+         } else {
 #pragma unroll
-         for (int k = 0; k < CH; ++k) {
-            const uint4 c = tile[tile_cell(lane, k)];
-            na |= c.x | c.y | c.z | c.w;
+            for (int k = 0; k < CH; ++k) {
+               const uint4 c = tile[tile_cell(lane, k)];
+               na |= c.x | c.y | c.z | c.w;
+            }
          }
          return na;
       };
-      if constexpr (HAS_B && !MATCH && !GEN && !RAGGED) {
+      if constexpr (HAS_B && !MATCH && !GEN) {
          // FXP_F_NEEDS_NONASCII: no match is made of ASCII symbols only -- a pure-ASCII tile holds none (60 instructions instead of a scan)
          if (is_tile && !ALLB && !hint && (fpb.spec & 2u) != 0u) {
             if (__builtin_amdgcn_ballot_w64((row_or() & 0x80808080u) != 0u) == 0) {
@@ -1189,7 +1299,8 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
          } else {
             uint32_t prev = 0;   // lane r rewrites its own row cell by cell
             uint4 cur = tile[tile_cell(lane, 0)];
-            for (int k = 0; k < CH; ++k) {
+            const int kd = RAGGED ? (int)tl.nch : CH;   // (ragged rows: the chunks that hold text)
+            for (int k = 0; k < kd; ++k) {
                const uint4 nxt = k + 1 < CH ? tile[tile_cell(lane, k + 1)] : make_uint4(0, 0, 0, 0);
                const fxrow::Cell16 o = fxrow::translate_cell16(prev, cur.x, cur.y, cur.z, cur.w, nxt.x, ct, sym_ffff);
                tile[tile_cell(lane, k)] = make_uint4(o.x, o.y, o.z, o.w);
@@ -1197,10 +1308,14 @@ __global__ __launch_bounds__(256) void fx_search_one(const uint8_t* __restrict__
                cur = nxt;
             }
          }
+         if (RAGGED) {   // the decode rewrote the NUL / KILL symbols behind the text as well (0xFE is a broken byte to it): put them back
+            fx_tail_init<CH>(tile, lane, tl);
+            fx_tail_patch(tile, lane, tl);
+         }
          // a gathered tile of a FEW rows -- the usual end of a wave -- on the 8-state tables: the lanes share the rows' cells (fx_few.hpp).
          // (Rows of 192 / 256 bytes only: those kernels run two waves per SIMD whatever their registers; with the 32 registers of a cell's
          //  table rows the kernels of shorter rows would drop from three waves per SIMD to two -- CH 8: 163 -> 191 VGPRs.)
-         if constexpr (SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0) {
+         if constexpr (SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0 && !RAGGED) {
             if (!is_tile && take <= fx_few_rows_max<CH>()) {
                fx_scan_few_rows<CH, SPANS>(tile, permR, permA, fp, lane, take, myq, emit);
                continue;
@@ -1246,7 +1361,8 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
-   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64 + ((FX_DEFER_FWD != 0 && CH <= 4) ? 2048 : 0);
+   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64 + ((FX_DEFER_FWD != 0 && CH <= 4) ? 2048 : 0) +
+                           ((FX_SPEC_FWD != 0 && BSCH == 3) ? 1024 : 0);
    const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
@@ -1276,58 +1392,22 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       const int env_blocks = fx_env().one_blocks;   // FXAMD_ONE_BLOCKS, test hook: a tiny grid, many tiles per wave
       if (env_blocks > 0 && blocks > env_blocks) blocks = env_blocks;
    };
-   if (is_match) {   // `.match.`: one verdict per row, no span
-     if constexpr (BSCH == 3) {
-      return hipErrorInvalidValue;   // (never dispatched: FXP_F_BYTE_A8 is a search program's table)
-     } else {
-      if (ragged) {
-         if constexpr (BSCH == 0) {
-            const void* fn = reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN, false, true>);
-            if (lds > 64 * 1024) {
-               hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-               if (e != hipSuccess) return e;
-            }
-            cap_grid(fn);
-            hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, nullptr);
-            return hipGetLastError();
-         } else {
-            return hipErrorInvalidValue;   // (never dispatched: byte-level tables need whole chunks)
-         }
-      }
-      const void* fn = reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>);
+   auto go = [&](auto kern) -> hipError_t {
+      const void* fn = reinterpret_cast<const void*>(kern);
       if (lds > 64 * 1024) {
          hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e != hipSuccess) return e;
       }
       cap_grid(fn);
-      hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, nullptr);
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, (const uint32_t*)nullptr);
       return hipGetLastError();
-     }
+   };
+   if (is_match) {   // `.match.`: one verdict per row, no span
+      if constexpr (BSCH == 3) return hipErrorInvalidValue;   // (never dispatched: FXP_F_BYTE_A8 is a search program's table)
+      else return ragged ? go(&fx_search_one<CH, false, SCH, BSCH, true, GEN, false, true>) : go(&fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>);
    }
-   if (ragged) {
-      if constexpr (BSCH == 0) {
-         const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, 0, true, GEN>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, 0, true, GEN>);
-         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-         }
-         cap_grid(fn);
-         if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
-         else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, 0, true, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
-         return hipGetLastError();
-      } else {
-         return hipErrorInvalidValue;   // (never dispatched: byte-level tables need whole chunks)
-      }
-   }
-   const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, SCH, BSCH, false, GEN>) : reinterpret_cast<const void*>(&fx_search_one<CH, false, SCH, BSCH, false, GEN>);
-   if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-   }
-   cap_grid(fn);
-   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
-   else hipLaunchKernelGGL((fx_search_one<CH, false, SCH, BSCH, false, GEN>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode);
-   return hipGetLastError();
+   if (ragged) return spans ? go(&fx_search_one<CH, true, SCH, BSCH, true, GEN>) : go(&fx_search_one<CH, false, SCH, BSCH, true, GEN>);
+   return spans ? go(&fx_search_one<CH, true, SCH, BSCH, false, GEN>) : go(&fx_search_one<CH, false, SCH, BSCH, false, GEN>);
 }
 
 // the gated follow-up of the half-row first pass: 256-byte rows, 8-state class-level tables, marked tiles only

@@ -249,6 +249,136 @@ __device__ __forceinline__ void store_tile_relayout(uint4 (&v)[CH], uint4* tile,
 }
 
 // =========================================================================================================
+// Ragged rows, round 4 (fx_search_one): rows of ANY length 2 <= Lr < 16*CH stay LEFT-ALIGNED in their cells and nothing is
+// padded with a symbol.  The bytes behind the text hold what follows the text in the wrapped string -- the trailing NUL, then KILL
+// symbols -- so every left-to-right walk (forward pass, windows, re-walks, the speculative pass) is the aligned kernels' code; the
+// right-to-left pass starts at the row's last byte: chunks behind the text are skipped and the chunk the row ends in is walked over its
+// valid bytes only (chain8_back_n).  No inert symbol is involved, so the byte-level tables run on ragged rows as well, and the work
+// follows the row length, not the instantiation's chunk count.  Staging: the tile is still one contiguous run of 64*Lr bytes; piece
+// p = q*64 + lane is the 16 bytes at row p / nch, chunk p % nch (nch = chunks that hold text) -- an UNALIGNED 16-byte buffer load straight
+// into the swizzled cell.  The linear LDS image + per-lane relayout of rounds 1-3 (store_tile_relayout: 4-way bank conflicts at
+// Lr = 255, unused chunk columns scanned at Lr = 100 / 132) remains only in the multi-pass kernels of this file.
+// =========================================================================================================
+struct FxTail {
+   uint32_t Lr;    // row length in bytes
+   uint32_t kt;    // the chunk position Lr falls in: Lr >> 4 (chunks 0 .. kt-1 are whole text)
+   uint32_t nb;    // text bytes in chunk kt: Lr & 15 (0: the row ends on a chunk boundary, chunk kt holds the NUL and KILL symbols only)
+   uint32_t nch;   // chunks that hold text: (Lr + 15) >> 4
+   uint32_t inv;   // 2^16 / nch + 1: p / nch == (p * inv) >> 16 for p < 1024, nch <= 16 (the error p / 2^16 stays below 1 / nch)
+   uint32_t padb;  // 16 * nch - Lr
+};
+__device__ __forceinline__ FxTail fx_tail_of(const uint32_t Lr) {
+   const uint32_t nch = (Lr + 15u) >> 4;
+   return FxTail{Lr, Lr >> 4, Lr & 15u, nch, 65536u / nch + 1u, 16u * nch - Lr};
+}
+// tile loads: piece p = q*64 + lane = row R = p / nch, chunk k = p - R*nch: the 16 bytes at tile byte R*Lr + 16k = 16p - R*padb.  The
+// extent is the tile's bytes + 3: a dword is dropped whole when it straddles the extent, and the last row's last dword does unless
+// Lr % 4 == 0 (at most 3 bytes behind the batch's last row are read, never used -- as in load_tile).
+template <int CH>
+__device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, const FxTail& T,
+                                              bool enable = true) {
+   const int64_t rows_left = n - row0;
+   const uint32_t valid = (!enable || rows_left <= 0) ? 0u : (rows_left >= 64 ? 64u : (uint32_t)rows_left) * T.Lr + 3u;
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)T.Lr;
+   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      if ((uint32_t)q < T.nch) {   // wave-uniform
+         const uint32_t p = (uint32_t)q * 64u + lane;
+         const uint32_t R = (p * T.inv) >> 16;
+         const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 16u * p - R * T.padb, 0, FX_LOAD_AUX);
+         v[q] = make_uint4(t.x, t.y, t.z, t.w);
+      }
+   }
+}
+template <int CH>
+__device__ __forceinline__ void store_tile_rag(const uint4 (&v)[CH], uint4* tile, uint32_t lane, const FxTail& T) {
+#pragma unroll
+   for (int q = 0; q < CH; ++q) {
+      if ((uint32_t)q < T.nch) {
+         const uint32_t p = (uint32_t)q * 64u + lane;
+         const uint32_t R = (p * T.inv) >> 16, k = p - R * T.nch;
+         tile[tile_cell(R, k)] = v[q];
+      }
+   }
+}
+// what follows the text in lane r's own cells: the trailing NUL at byte Lr, KILL symbols (0xFE) behind it.  Chunks behind chunk kt are
+// written ONCE per kernel (the loader never touches them); chunk kt -- the text's last bytes, rewritten with every tile -- is patched here.
+__device__ __forceinline__ uint32_t fx_tail_word(const uint32_t w, const uint32_t at, const uint32_t nb) {   // dword at chunk byte `at` of chunk kt
+   if (at + 4u <= nb) return w;
+   if (at >= nb) return at == nb ? 0xFEFEFE00u : 0xFEFEFEFEu;
+   const uint32_t sh = 8u * (nb - at);   // 8, 16 or 24: that many low bits are text
+   return (w & ~(0xFFFFFFFFu << sh)) | (0xFEFEFE00u << sh);
+}
+__device__ __forceinline__ void fx_tail_patch(uint4* tile, uint32_t lane, const FxTail& T) {
+   if (T.nb == 0u) return;
+   uint4 c = tile[tile_cell(lane, T.kt)];
+   c.x = fx_tail_word(c.x, 0u, T.nb);
+   c.y = fx_tail_word(c.y, 4u, T.nb);
+   c.z = fx_tail_word(c.z, 8u, T.nb);
+   c.w = fx_tail_word(c.w, 12u, T.nb);
+   tile[tile_cell(lane, T.kt)] = c;
+}
+template <int CH>
+__device__ __forceinline__ void fx_tail_init(uint4* tile, uint32_t lane, const FxTail& T) {   // once per kernel
+   for (uint32_t k = T.nch; k < (uint32_t)CH; ++k)
+      tile[tile_cell(lane, k)] = (k == T.kt) ? make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu) : make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+}
+// the text bytes of chunk kt OR-ed (the ">= 0x80 anywhere" tests look at text only)
+__device__ __forceinline__ uint32_t fx_tail_or(const uint4 c, const uint32_t nb) {
+   auto m = [&](uint32_t w, uint32_t at) -> uint32_t { return at + 4u <= nb ? w : (at >= nb ? 0u : (w & ~(0xFFFFFFFFu << (8u * (nb - at))))); };
+   return m(c.x, 0u) | m(c.y, 4u) | m(c.z, 8u) | m(c.w, 12u);
+}
+// one row gathered from global memory into lane r's cells (exception queues): whole chunks are plain unaligned 16-byte loads; the chunk
+// the row ends in is read as the row's LAST 16 bytes and shifted down (nothing behind the row is read), rows shorter than 16 bytes byte by byte
+struct __attribute__((packed, aligned(1))) fx_u4_unaligned {
+   uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint4 fx_shr128_bytes(const uint4 v, const uint32_t nbytes) {   // nbytes wave-uniform, 1..15
+   const uint32_t d = nbytes >> 2, b = nbytes & 3u;
+   uint32_t a0, a1, a2, a3;
+   if (d == 0u) { a0 = v.x; a1 = v.y; a2 = v.z; a3 = v.w; }
+   else if (d == 1u) { a0 = v.y; a1 = v.z; a2 = v.w; a3 = 0u; }
+   else if (d == 2u) { a0 = v.z; a1 = v.w; a2 = 0u; a3 = 0u; }
+   else { a0 = v.w; a1 = 0u; a2 = 0u; a3 = 0u; }
+   if (b == 0u) return make_uint4(a0, a1, a2, a3);
+   return make_uint4(fxrow::fx_alignbyte(a1, a0, b), fxrow::fx_alignbyte(a2, a1, b), fxrow::fx_alignbyte(a3, a2, b), fxrow::fx_alignbyte(0u, a3, b));
+}
+template <int CH>
+__device__ __forceinline__ void gather_row_rag(uint4* tile, uint32_t lane, const uint8_t* __restrict__ rp, bool on, const FxTail& T) {
+#pragma unroll 1
+   for (uint32_t k = 0; k < T.kt; ++k) {
+      uint4 c = make_uint4(0, 0, 0, 0);
+      if (on) {
+         const fx_u4_unaligned u = *reinterpret_cast<const fx_u4_unaligned*>(rp + 16u * k);
+         c = make_uint4(u.x, u.y, u.z, u.w);
+      }
+      tile[tile_cell(lane, k)] = c;
+   }
+   if (T.nb != 0u) {
+      uint4 c = make_uint4(0, 0, 0, 0);
+      if (T.Lr >= 16u) {
+         if (on) {
+            const fx_u4_unaligned u = *reinterpret_cast<const fx_u4_unaligned*>(rp + T.Lr - 16u);
+            c = make_uint4(u.x, u.y, u.z, u.w);
+         }
+         c = fx_shr128_bytes(c, 16u - T.nb);
+      } else if (on) {
+         uint64_t lo = 0, hi = 0;   // (no run-time indexed array: that would live in scratch)
+         for (uint32_t j = 0; j < T.Lr; ++j) {
+            const uint64_t b = rp[j];
+            if (j < 8u) lo |= b << (8u * j);
+            else hi |= b << (8u * (j - 8u));
+         }
+         c = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+      }
+      tile[tile_cell(lane, T.kt)] = c;
+   }
+}
+
+// =========================================================================================================
 // fast search kernel
 // =========================================================================================================
 // every value is a state id replicated into all four bytes (id * 0x01010101): v_perm_b32 then advances four identical

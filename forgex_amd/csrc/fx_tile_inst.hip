@@ -1,22 +1,30 @@
-// Explicit instantiation of the tile-kernel launchers (and with them the kernels) for ONE chunk count: compiled once per
-// -DFX_INST_CH=<1|2|3|4|6|8|12|16> so that the variants build in parallel (forgex_amd/csrc/Makefile).
+// Explicit instantiation of the tile-kernel launchers (and with them the kernels) for ONE chunk count: compiled per
+// -DFX_INST_CH=<1|2|3|4|6|8|12|16> and, so that the few hundred variants build in parallel on all cores, per -DFX_INST_PART=<1|2|3>:
+// 1 = the multi-pass kernels (fx_search_fast / fx_match_fast), 2 = the one-launch kernel for programs whose tables decode, 3 = the
+// one-launch kernel with the general row procedure for queued rows (GEN), the many-pattern kernel and the gated follow-up
+// (forgex_amd/csrc/Makefile).
 #include "fx_multi.hpp"
 
+#if FX_INST_PART == 1
 #define FX_X(CH, M, S)                                           \
    template hipError_t launch_fast<CH, M, S> FX_TILE_SIG_FAST;   \
    template hipError_t launch_match<CH, M, S> FX_TILE_SIG_MATCH;
 FX_TILE_COMBOS(FX_X, FX_INST_CH)
 #undef FX_X
+#endif
 
 #define FX_Y(CH, S, B, G) template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
-FX_ONE_COMBOS(FX_Y, FX_INST_CH)
-#undef FX_Y
-
+#if FX_INST_PART == 2
+FX_ONE_COMBOS_G(FX_Y, FX_INST_CH, false)
+#endif
+#if FX_INST_PART == 3
+FX_ONE_COMBOS_G(FX_Y, FX_INST_CH, true)
 template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;
-
 #if FX_INST_CH == 16
 template hipError_t launch_one_marked<FX_INST_CH, 0> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<FX_INST_CH, 1> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<FX_INST_CH, 2> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<FX_INST_CH, 3> FX_ONE_MARKED_SIG;
 #endif
+#endif
+#undef FX_Y

@@ -244,6 +244,23 @@ __global__ __launch_bounds__(64) void fx_nfa(const uint8_t* __restrict__ rows, i
    if (to) to[row] = res.to;
 }
 
+// number of nonzero flag bytes (fxamd_batch_count): 16 flags per thread and step, one atomic per wave
+__global__ void fx_count_flags(const uint8_t* __restrict__ flags, int64_t n, unsigned long long* __restrict__ out) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 16;
+   uint32_t c = 0;
+   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += stride) {
+      if (i + 16 <= n && (reinterpret_cast<uintptr_t>(flags + i) & 15u) == 0) {
+         const uint4 v = *reinterpret_cast<const uint4*>(flags + i);
+         auto nz = [](uint32_t w) { return (uint32_t)__builtin_popcount(((w | (w >> 1) | (w >> 2) | (w >> 3) | (w >> 4) | (w >> 5) | (w >> 6) | (w >> 7)) & 0x01010101u)); };
+         c += nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+      } else {
+         for (int64_t j = i; j < n && j < i + 16; ++j) c += flags[j] != 0 ? 1u : 0u;
+      }
+   }
+   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+   if ((threadIdx.x & 63u) == 0 && c != 0) atomicAdd(out, (unsigned long long)c);
+}
+
 __global__ void fx_fill(uint8_t* flags, int32_t* from, int32_t* to, int64_t n) {
    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
@@ -558,9 +575,11 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
 // scheme of the byte-level tables: 2 = wide v_perm when both automata have <= 16 states, else 1 = chain
 static int bytes_scheme(const FxpHeader& h) { return ((h.flags & FXP_F_BYTE_W16) && !fx_env().no_w16) ? 2 : 1; }
 // byte-level tables usable for these rows: whole chunks only (no inert pad byte exists: every byte value means something)
-static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
+// (`ragged_too`: the one-launch kernel keeps ragged rows left-aligned with the NUL / KILL symbols behind the text -- no pad symbol, so
+//  the byte-level tables run on them too; the multi-pass kernels pad with the inert symbol 255, which byte-level tables do not have)
+static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, bool ragged_too = false) {
    if (fx_env().no_byte_dfa) return false;   // test hook: exercise the decode pass instead
-   if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || (!long_row(row_len) && row_len != 16 * tile_chunks(row_len))) return false;
+   if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || (!long_row(row_len) && !ragged_too && row_len != 16 * tile_chunks(row_len))) return false;
    return (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
 
@@ -679,7 +698,7 @@ static hipError_t launch_one_any(int sch, int bsch, bool gen, const FxpHeader& h
 // Which byte-level format rides along in the one-launch kernel: wide v_perm when the tables exist in it and two blocks per CU still
 // fit next to it (4 tiles + class-level tables + 8 KB), else the chain format (a few hundred bytes to a few KB), 0 = none.
 static int one_bytes_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, int sch) {
-   if (!bytes_ok(h, d_rows, row_len)) return 0;
+   if (!bytes_ok(h, d_rows, row_len, true)) return 0;
    const size_t tiles_b = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1);
    const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 4096 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
    if (bytes_scheme(h) == 2 && tiles_b + cls_b + 4096 + 2048 <= 80 * 1024)   // (3: with the forward automaton in the v_perm format, FXP_F_BYTE_A8)
@@ -1672,6 +1691,208 @@ void fxamd_f_strerror_copy(int32_t status, char* buf, int64_t capacity, int64_t*
    const int64_t r = fxamd_strerror_copy(status, buf, capacity);
    if (n) *n = r;
 }
+// ---- device-resident batches for hosts without a device runtime of their own (the Fortran module's type(fx_batch)) ------------------
+// The rows are uploaded once (or a caller's device pointer is wrapped) and stay in HBM across calls and patterns; every run leaves its
+// results in device buffers the batch owns (m result sets of n flags and, with spans, n from / to values); the host fetches, counts or
+// ignores them.  One stream per batch; the entries are serialised per batch.
+struct fxamd_batch {
+   uint8_t* d_rows = nullptr;
+   bool owns_rows = false;
+   int64_t n = 0, row_len = 0;
+   int dev = 0;
+   hipStream_t st = nullptr;
+   uint8_t* d_flags = nullptr;
+   int32_t *d_from = nullptr, *d_to = nullptr;
+   int64_t cap_flags = 0, cap_spans = 0;   // result sets the buffers hold (in rows: sets * n)
+   unsigned long long* d_count = nullptr;
+   int32_t sets = 0;                        // result sets of the last run
+   bool spans = false;                      // ... and whether it wrote from / to
+   std::mutex mu;
+};
+static int batch_make(const uint8_t* d_rows, bool owns, int64_t n, int64_t row_len, fxamd_batch** out) {
+   fxamd_batch* b = new (std::nothrow) fxamd_batch();
+   if (!b) return FXAMD_E_NOMEM;
+   b->d_rows = const_cast<uint8_t*>(d_rows);
+   b->owns_rows = owns;
+   b->n = n;
+   b->row_len = row_len;
+   if (hipGetDevice(&b->dev) != hipSuccess || hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess ||
+       hipMalloc((void**)&b->d_count, sizeof(unsigned long long)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError();
+      if (b->st) (void)hipStreamDestroy(b->st);
+      delete b;
+      return FXAMD_E_HIP;
+   }
+   *out = b;
+   return FXAMD_OK;
+}
+int fxamd_batch_upload(const uint8_t* h_rows, int64_t n, int64_t row_len, fxamd_batch** out) {
+   if (!out || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || (n > 0 && row_len > 0 && !h_rows)) return FXAMD_E_ARG;
+   *out = nullptr;
+   uint8_t* d = nullptr;
+   const size_t bytes = (size_t)n * (size_t)row_len;
+   FX_HIP(hipMalloc((void**)&d, bytes + 16));   // (+16: never a zero-byte allocation)
+   if (bytes != 0) {
+      const hipError_t e = hipMemcpy(d, h_rows, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+         g_last_hip_error = (int)e;
+         (void)hipFree(d);
+         return FXAMD_E_HIP;
+      }
+   }
+   const int rc = batch_make(d, true, n, row_len, out);
+   if (rc != FXAMD_OK) (void)hipFree(d);
+   return rc;
+}
+int fxamd_batch_wrap(const uint8_t* d_rows, int64_t n, int64_t row_len, fxamd_batch** out) {
+   if (!out || n < 0 || row_len < 0 || row_len > 0x3FFFFFFF || (n > 0 && row_len > 0 && !d_rows)) return FXAMD_E_ARG;
+   *out = nullptr;
+   return batch_make(d_rows, false, n, row_len, out);
+}
+void fxamd_batch_free(fxamd_batch* b) {
+   if (!b) return;
+   if (b->st) {
+      (void)hipStreamSynchronize(b->st);
+      (void)hipStreamDestroy(b->st);
+   }
+   if (b->owns_rows && b->d_rows) (void)hipFree(b->d_rows);
+   if (b->d_flags) (void)hipFree(b->d_flags);
+   if (b->d_from) (void)hipFree(b->d_from);
+   if (b->d_to) (void)hipFree(b->d_to);
+   if (b->d_count) (void)hipFree(b->d_count);
+   delete b;
+}
+int fxamd_batch_info(const fxamd_batch* b, int64_t* n, int64_t* row_len) {
+   if (!b) return FXAMD_E_ARG;
+   if (n) *n = b->n;
+   if (row_len) *row_len = b->row_len;
+   return FXAMD_OK;
+}
+static int batch_reserve(fxamd_batch* b, int32_t sets, bool spans) {
+   const int64_t need = (int64_t)sets * std::max<int64_t>(b->n, 1);
+   if (b->cap_flags < need) {
+      if (b->d_flags) (void)hipFree(b->d_flags);
+      b->d_flags = nullptr;
+      b->cap_flags = 0;
+      FX_HIP(hipMalloc((void**)&b->d_flags, (size_t)need + 16));
+      b->cap_flags = need;
+   }
+   if (spans && b->cap_spans < need) {
+      if (b->d_from) (void)hipFree(b->d_from);
+      if (b->d_to) (void)hipFree(b->d_to);
+      b->d_from = b->d_to = nullptr;
+      b->cap_spans = 0;
+      FX_HIP(hipMalloc((void**)&b->d_from, (size_t)need * 4 + 16));
+      FX_HIP(hipMalloc((void**)&b->d_to, (size_t)need * 4 + 16));
+      b->cap_spans = need;
+   }
+   return FXAMD_OK;
+}
+// m patterns over the resident rows (m = 1: fxamd_match_batch_device, else fxamd_match_multi_device); asynchronous on the batch's stream.
+// `.match.` programs write no spans.  The results stay on the device: fxamd_batch_fetch / _count / _results.
+int fxamd_batch_run(fxamd_program* const* progs, int32_t m, fxamd_batch* b, int with_spans) {
+   if (!progs || m < 1 || !b) return FXAMD_E_ARG;
+   for (int32_t i = 0; i < m; ++i)
+      if (!progs[i]) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(b->mu);
+   int cur = -1;
+   FX_HIP(hipGetDevice(&cur));
+   if (cur != b->dev) FX_HIP(hipSetDevice(b->dev));
+   bool spans = with_spans != 0;
+   for (int32_t i = 0; i < m; ++i)
+      if (progs[i]->prog.hdr().mode == FXP_MODE_MATCH_ENGINE) spans = false;
+   int rc = batch_reserve(b, m, spans);
+   if (rc == FXAMD_OK) {
+      if (m == 1) rc = fxamd_match_batch_device(progs[0], b->d_rows, b->n, b->row_len, b->d_flags, spans ? b->d_from : nullptr, spans ? b->d_to : nullptr, b->st);
+      else rc = fxamd_match_multi_device(progs, m, b->d_rows, b->n, b->row_len, b->d_flags, spans ? b->d_from : nullptr, spans ? b->d_to : nullptr, b->st);
+   }
+   if (rc == FXAMD_OK) {
+      b->sets = m;
+      b->spans = spans;
+   }
+   if (cur != b->dev) (void)hipSetDevice(cur);
+   return rc;
+}
+int fxamd_batch_sync(fxamd_batch* b) {
+   if (!b) return FXAMD_E_ARG;
+   FX_HIP(hipStreamSynchronize(b->st));
+   return FXAMD_OK;
+}
+// results of pattern `which` (0-based) of the last run, copied to host arrays (h_from / h_to may both be NULL); synchronous
+int fxamd_batch_fetch(fxamd_batch* b, int32_t which, uint8_t* h_flags, int32_t* h_from, int32_t* h_to) {
+   if (!b || which < 0 || (h_from == nullptr) != (h_to == nullptr)) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(b->mu);
+   if (which >= b->sets || (h_from && !b->spans)) return FXAMD_E_ARG;
+   const size_t o = (size_t)which * (size_t)b->n;
+   if (b->n != 0) {
+      if (h_flags) FX_HIP(hipMemcpyAsync(h_flags, b->d_flags + o, (size_t)b->n, hipMemcpyDeviceToHost, b->st));
+      if (h_from) {
+         FX_HIP(hipMemcpyAsync(h_from, b->d_from + o, (size_t)b->n * 4, hipMemcpyDeviceToHost, b->st));
+         FX_HIP(hipMemcpyAsync(h_to, b->d_to + o, (size_t)b->n * 4, hipMemcpyDeviceToHost, b->st));
+      }
+   }
+   FX_HIP(hipStreamSynchronize(b->st));
+   return FXAMD_OK;
+}
+// number of matching rows of pattern `which` of the last run (a reduction on the device: 8 bytes cross the bus); synchronous
+int fxamd_batch_count(fxamd_batch* b, int32_t which, int64_t* n_matches) {
+   if (!b || which < 0 || !n_matches) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(b->mu);
+   if (which >= b->sets) return FXAMD_E_ARG;
+   unsigned long long c = 0;
+   if (b->n != 0) {
+      FX_HIP(hipMemsetAsync(b->d_count, 0, sizeof(unsigned long long), b->st));
+      int64_t blocks = (b->n + 16 * 256 - 1) / (16 * 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(fx_count_flags, dim3((unsigned)blocks), dim3(256), 0, b->st, b->d_flags + (size_t)which * (size_t)b->n, b->n, b->d_count);
+      FX_HIP(hipGetLastError());
+      FX_HIP(hipMemcpyAsync(&c, b->d_count, sizeof(c), hipMemcpyDeviceToHost, b->st));
+      FX_HIP(hipStreamSynchronize(b->st));
+   }
+   *n_matches = (int64_t)c;
+   return FXAMD_OK;
+}
+// the device buffers of the last run, for hosts that can use device pointers: sets * n flags (and from / to when it had spans)
+int fxamd_batch_results(fxamd_batch* b, const uint8_t** d_flags, const int32_t** d_from, const int32_t** d_to, int32_t* sets, void** hip_stream) {
+   if (!b) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(b->mu);
+   if (d_flags) *d_flags = b->d_flags;
+   if (d_from) *d_from = b->spans ? b->d_from : nullptr;
+   if (d_to) *d_to = b->spans ? b->d_to : nullptr;
+   if (sets) *sets = b->sets;
+   if (hip_stream) *hip_stream = (void*)b->st;
+   return FXAMD_OK;
+}
+// subroutine forms for Fortran hosts (see fxamd_f_compile)
+void fxamd_f_batch_upload(const uint8_t* h_rows, int64_t n, int64_t row_len, fxamd_batch** out, int32_t* rc) {
+   const int r = fxamd_batch_upload(h_rows, n, row_len, out);
+   if (rc) *rc = r;
+}
+void fxamd_f_batch_wrap(const uint8_t* d_rows, int64_t n, int64_t row_len, fxamd_batch** out, int32_t* rc) {
+   const int r = fxamd_batch_wrap(d_rows, n, row_len, out);
+   if (rc) *rc = r;
+}
+void fxamd_f_batch_free(fxamd_batch* b, int32_t* rc) {
+   fxamd_batch_free(b);
+   if (rc) *rc = 0;
+}
+void fxamd_f_batch_run(fxamd_program* const* progs, int32_t m, fxamd_batch* b, int32_t with_spans, int32_t* rc) {
+   const int r = fxamd_batch_run(progs, m, b, with_spans);
+   if (rc) *rc = r;
+}
+void fxamd_f_batch_sync(fxamd_batch* b, int32_t* rc) {
+   const int r = fxamd_batch_sync(b);
+   if (rc) *rc = r;
+}
+void fxamd_f_batch_fetch(fxamd_batch* b, int32_t which, uint8_t* h_flags, int32_t* h_from, int32_t* h_to, int32_t* rc) {
+   const int r = fxamd_batch_fetch(b, which, h_flags, h_from, h_to);
+   if (rc) *rc = r;
+}
+void fxamd_f_batch_count(fxamd_batch* b, int32_t which, int64_t* n_matches, int32_t* rc) {
+   const int r = fxamd_batch_count(b, which, n_matches);
+   if (rc) *rc = r;
+}
+
 void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, int64_t row_len, uint8_t* h_flags, int32_t* h_from,
                               int32_t* h_to, int32_t* rc) {
    const int r = fxamd_match_batch_host(p, h_rows, n, row_len, h_flags, h_from, h_to);

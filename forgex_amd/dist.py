@@ -6,6 +6,9 @@ links in parallel.  Works with any torch.distributed backend (nccl on GPUs, gloo
 On GPUs the packed image comes straight from the match call (Program.match_device_packed: the search kernel stores the
 tile's ballot as the flag word and the spans narrow) and travels with gather_packed; pack_results / unpack_results here are
 the same layout written with torch ops -- the CPU tests' implementation and the cross-check of the kernels' packing."""
+import os
+import socket
+
 import torch
 import torch.distributed as dist
 
@@ -138,3 +141,45 @@ def gather_packed(packed, n_total, row_len, spans=True, dst=0, buffers=None):
         return None
     dist.gather(buf, recv, dst=dst)
     return [recv[r][:max(_packed_total(sizes[r], row_len, spans), 16)] for r in range(world)], sizes
+
+
+def device_identity(device):
+    """What tells one GPU of a node from another, as a string: name, UUID and PCI address where torch exposes them, host name; for
+    the CPU dry runs the process id."""
+    device = torch.device(device)
+    parts = []
+    if device.type == "cuda":
+        p = torch.cuda.get_device_properties(device)
+        parts.append("name=%s" % p.name)
+        for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"):
+            if hasattr(p, k):
+                parts.append("%s=%s" % (k, getattr(p, k)))
+        parts.append("index=%d" % (device.index if device.index is not None else torch.cuda.current_device()))
+    else:
+        parts.append("cpu pid=%d" % os.getpid())
+    parts.append("host=%s" % socket.gethostname())
+    return " ".join(parts)
+
+
+def job_census(device):
+    """Who takes part in this job, as the COLLECTIVES see it (not as the environment claims): `ranks` = an all-reduce of 1 over the
+    group, `devices` = every rank's device_identity (an all-gather of fixed-size byte tensors: byte tensors are the one dtype every
+    backend moves), `distinct` = no two ranks on one device.  Every rank gets the same answer."""
+    device = torch.device(device)
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one)
+    me = device_identity(device).encode()[:159]
+    buf = torch.zeros(160, dtype=torch.uint8, device=device)
+    buf[:len(me)] = torch.tensor(list(me), dtype=torch.uint8, device=device)
+    got = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, buf)
+    devices = [bytes(g.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for g in got]
+    return {"ranks": int(one.item()), "devices": devices, "distinct": len(set(devices)) == len(devices), "backend": dist.get_backend()}
+
+
+def gather_floats(x, device):
+    """One float per rank -> the list of all ranks' values on every rank (per-rank step times of the bench)."""
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    got = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    return [float(g.item()) for g in got]

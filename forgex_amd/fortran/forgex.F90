@@ -17,6 +17,12 @@
 !     instead of re-parsing the pattern per element (reference src/forgex.F90:98,139-140); `patterns(:) .in. strs(:)`
 !     compiles every DISTINCT pattern once and matches the rows of each in one batch.
 !   * `regex` gains a batch form returning from(:)/to(:) for a rank-1 text array.
+!   * type(fx_batch) (round 4) keeps a batch RESIDENT in HBM across calls and patterns: `batch = fx_batch_upload(strs)` (or
+!     fx_batch_wrap of a device pointer the caller owns), then the SAME operators and `regex` with the batch in place of the character
+!     array -- `pattern .in. batch`, `pattern .match. batch`, `patterns(:) .in. batch`, `call regex(pattern, batch, from, to)` -- copy
+!     the results back, while `call fx_batch_search(pattern, batch)` / `fx_batch_match` leave them on the device for
+!     fx_batch_count (a reduction on the device) and fx_batch_fetch.  The host-buffer specifics above move every row over PCIe on
+!     every call (about 45 GB/s); a resident batch is scanned at the kernels' rate.
 !   * There is no CPU matching path: without a HIP device the calls stop with an error message.
 #if defined(IMPURE)
 #define PURE_
@@ -35,6 +41,18 @@ module forgex
    public :: operator(.match.)
    public :: regex
    public :: regex_f
+   ! device-resident batches (an extension of the reference's surface, src/forgex.F90:24-54: the same generics accept a batch)
+   public :: fx_batch
+   public :: fx_batch_upload, fx_batch_wrap, fx_batch_free, fx_batch_size
+   public :: fx_batch_search, fx_batch_match, fx_batch_sync, fx_batch_count, fx_batch_fetch
+
+   !> rows resident in HBM (uploaded once, or a caller's device pointer); results of the last run stay on the device with it
+   type :: fx_batch
+      private
+      type(c_ptr) :: h = c_null_ptr
+      integer :: n = 0
+      integer :: row_len = 0
+   end type fx_batch
 
    integer(c_int), parameter :: FXAMD_OP_SEARCH = 0, FXAMD_OP_MATCH = 1
    integer, parameter :: INVALID_CHAR_INDEX = -9999
@@ -63,6 +81,52 @@ module forgex
          integer(c_int64_t), value :: n, row_len
          integer(c_int32_t), intent(out) :: rc
       end subroutine
+      subroutine fxamd_f_batch_upload(rows, n, row_len, batch, rc) bind(C, name='fxamd_f_batch_upload')
+         import :: c_ptr, c_int64_t, c_int32_t
+         type(c_ptr), value :: rows
+         integer(c_int64_t), value :: n, row_len
+         type(c_ptr), intent(out) :: batch
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      subroutine fxamd_f_batch_wrap(d_rows, n, row_len, batch, rc) bind(C, name='fxamd_f_batch_wrap')
+         import :: c_ptr, c_int64_t, c_int32_t
+         type(c_ptr), value :: d_rows
+         integer(c_int64_t), value :: n, row_len
+         type(c_ptr), intent(out) :: batch
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      subroutine fxamd_f_batch_free(batch, rc) bind(C, name='fxamd_f_batch_free')
+         import :: c_ptr, c_int32_t
+         type(c_ptr), value :: batch
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      subroutine fxamd_f_batch_run(progs, m, batch, with_spans, rc) bind(C, name='fxamd_f_batch_run')
+         import :: c_ptr, c_int32_t
+         type(c_ptr), intent(in) :: progs(*)
+         integer(c_int32_t), value :: m
+         type(c_ptr), value :: batch
+         integer(c_int32_t), value :: with_spans
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      subroutine fxamd_f_batch_sync(batch, rc) bind(C, name='fxamd_f_batch_sync')
+         import :: c_ptr, c_int32_t
+         type(c_ptr), value :: batch
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      subroutine fxamd_f_batch_fetch(batch, which, flags, from, to, rc) bind(C, name='fxamd_f_batch_fetch')
+         import :: c_ptr, c_int32_t
+         type(c_ptr), value :: batch
+         integer(c_int32_t), value :: which
+         type(c_ptr), value :: flags, from, to
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
+      subroutine fxamd_f_batch_count(batch, which, n_matches, rc) bind(C, name='fxamd_f_batch_count')
+         import :: c_ptr, c_int32_t, c_int64_t
+         type(c_ptr), value :: batch
+         integer(c_int32_t), value :: which
+         integer(c_int64_t), intent(out) :: n_matches
+         integer(c_int32_t), intent(out) :: rc
+      end subroutine
       PURE_ subroutine fxamd_f_strerror_copy(status, buf, cap, n) bind(C, name='fxamd_f_strerror_copy')
          import :: c_int32_t, c_char, c_int64_t
          integer(c_int32_t), value :: status
@@ -80,17 +144,22 @@ module forgex
       module procedure :: operator__in
       module procedure :: operator__in_batch
       module procedure :: operator__in_patterns
+      module procedure :: operator__in_resident
+      module procedure :: operator__in_patterns_resident
    end interface
 
    interface operator(.match.)
       module procedure :: operator__match
       module procedure :: operator__match_batch
       module procedure :: operator__match_patterns
+      module procedure :: operator__match_resident
+      module procedure :: operator__match_patterns_resident
    end interface
 
    interface regex
       module procedure :: subroutine__regex
       module procedure :: subroutine__regex_batch
+      module procedure :: subroutine__regex_resident
    end interface
 
    interface regex_f
@@ -347,6 +416,215 @@ contains
       end if
       call release(prog)
    end subroutine subroutine__regex_batch
+
+   !---------------------------------------------------------------------------------------------------------------
+   ! device-resident batches
+   !> upload the storage of `character(L) :: str(n)` once; free with fx_batch_free
+   function fx_batch_upload(str) result(batch)
+      character(*), intent(in), target, contiguous :: str(:)
+      type(fx_batch) :: batch
+      integer(c_int32_t) :: rc
+      call fxamd_f_batch_upload(c_loc(str), int(size(str), c_int64_t), int(len(str), c_int64_t), batch%h, rc)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_batch_upload failed (the match path needs a HIP device; there is no CPU fallback)'
+      batch%n = size(str)
+      batch%row_len = len(str)
+   end function fx_batch_upload
+
+   !> wrap n rows of row_len bytes that already live in device memory (the caller keeps owning them)
+   function fx_batch_wrap(d_rows, n, row_len) result(batch)
+      type(c_ptr), intent(in) :: d_rows
+      integer, intent(in) :: n, row_len
+      type(fx_batch) :: batch
+      integer(c_int32_t) :: rc
+      call fxamd_f_batch_wrap(d_rows, int(n, c_int64_t), int(row_len, c_int64_t), batch%h, rc)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_batch_wrap failed'
+      batch%n = n
+      batch%row_len = row_len
+   end function fx_batch_wrap
+
+   subroutine fx_batch_free(batch)
+      type(fx_batch), intent(inout) :: batch
+      integer(c_int32_t) :: rc
+      if (c_associated(batch%h)) call fxamd_f_batch_free(batch%h, rc)
+      batch%h = c_null_ptr
+      batch%n = 0
+      batch%row_len = 0
+   end subroutine fx_batch_free
+
+   pure function fx_batch_size(batch) result(n)
+      type(fx_batch), intent(in) :: batch
+      integer :: n
+      n = batch%n
+   end function fx_batch_size
+
+   !> m patterns over the resident rows; the results stay on the device.  status(i) /= 0: pattern i is invalid -- its rows read
+   !> "no match" (reference forgex.F90:101-104); ok = .false. when that is so for at least one pattern
+   subroutine run_resident(pattern, batch, op, spans, status)
+      character(*), intent(in) :: pattern(:)
+      type(fx_batch), intent(in) :: batch
+      integer(c_int), intent(in) :: op
+      logical, intent(in) :: spans
+      integer, intent(out) :: status(:)
+      type(c_ptr) :: progs(size(pattern))
+      integer(c_int32_t) :: rc
+      integer :: i
+      if (.not. c_associated(batch%h)) error stop 'forgex (amd): the batch is not resident (fx_batch_upload / fx_batch_wrap first)'
+      do i = 1, size(pattern)
+         call compile(pattern(i), op, progs(i), status(i))
+      end do
+      ! (an invalid pattern's program fills its result set with "no match": the library handles it like any other)
+      call fxamd_f_batch_run(progs, int(size(pattern), c_int32_t), batch%h, merge(1_c_int32_t, 0_c_int32_t, spans), rc)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_batch_run failed'
+      do i = 1, size(pattern)
+         call release(progs(i))
+      end do
+   end subroutine run_resident
+
+   !> `.in.` / regex over the resident rows, results LEFT ON THE DEVICE (fx_batch_count, fx_batch_fetch); asynchronous
+   subroutine fx_batch_search(pattern, batch, spans, status)
+      character(*), intent(in) :: pattern
+      type(fx_batch), intent(in) :: batch
+      logical, intent(in), optional :: spans
+      integer, intent(out), optional :: status
+      integer :: st(1)
+      logical :: sp
+      sp = .true.
+      if (present(spans)) sp = spans
+      call run_resident([character(len(pattern)) :: pattern], batch, FXAMD_OP_SEARCH, sp, st)
+      if (present(status)) status = st(1)
+   end subroutine fx_batch_search
+
+   !> `.match.` over the resident rows, verdicts left on the device
+   subroutine fx_batch_match(pattern, batch, status)
+      character(*), intent(in) :: pattern
+      type(fx_batch), intent(in) :: batch
+      integer, intent(out), optional :: status
+      integer :: st(1)
+      call run_resident([character(len(pattern)) :: pattern], batch, FXAMD_OP_MATCH, .false., st)
+      if (present(status)) status = st(1)
+   end subroutine fx_batch_match
+
+   subroutine fx_batch_sync(batch)
+      type(fx_batch), intent(in) :: batch
+      integer(c_int32_t) :: rc
+      call fxamd_f_batch_sync(batch%h, rc)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_batch_sync failed'
+   end subroutine fx_batch_sync
+
+   !> matching rows of result set `which` (1-based, default 1) of the last run: a reduction on the device
+   function fx_batch_count(batch, which) result(n)
+      type(fx_batch), intent(in) :: batch
+      integer, intent(in), optional :: which
+      integer(c_int64_t) :: n
+      integer(c_int32_t) :: rc
+      integer :: w
+      w = 1
+      if (present(which)) w = which
+      call fxamd_f_batch_count(batch%h, int(w - 1, c_int32_t), n, rc)
+      if (rc /= 0) error stop 'forgex (amd): fxamd_batch_count failed'
+   end function fx_batch_count
+
+   !> result set `which` of the last run copied to host arrays (flags: 0 / 1; from / to: 1-based byte spans, 0 = none)
+   subroutine fx_batch_fetch(batch, flags, from, to, which)
+      type(fx_batch), intent(in) :: batch
+      integer(c_int8_t), intent(out), target, contiguous :: flags(:)
+      integer(c_int32_t), intent(out), target, contiguous, optional :: from(:), to(:)
+      integer, intent(in), optional :: which
+      integer(c_int32_t) :: rc
+      integer :: w
+      w = 1
+      if (present(which)) w = which
+      if (size(flags) < batch%n) error stop 'forgex (amd): fx_batch_fetch: flags(:) is shorter than the batch'
+      if (present(from) .and. present(to)) then
+         if (size(from) < batch%n .or. size(to) < batch%n) error stop 'forgex (amd): fx_batch_fetch: from(:) / to(:) are shorter than the batch'
+         call fxamd_f_batch_fetch(batch%h, int(w - 1, c_int32_t), c_loc(flags), c_loc(from), c_loc(to), rc)
+      else
+         call fxamd_f_batch_fetch(batch%h, int(w - 1, c_int32_t), c_loc(flags), c_null_ptr, c_null_ptr, rc)
+      end if
+      if (rc /= 0) error stop 'forgex (amd): fxamd_batch_fetch failed'
+   end subroutine fx_batch_fetch
+
+   !> the operators with a resident batch in place of the character array: verdicts copied back
+   function operator__in_resident(pattern, batch) result(res)
+      character(*), intent(in) :: pattern
+      type(fx_batch), intent(in) :: batch
+      logical :: res(batch%n)
+      res = flags_resident(pattern, batch, FXAMD_OP_SEARCH)
+   end function operator__in_resident
+
+   function operator__match_resident(pattern, batch) result(res)
+      character(*), intent(in) :: pattern
+      type(fx_batch), intent(in) :: batch
+      logical :: res(batch%n)
+      res = flags_resident(pattern, batch, FXAMD_OP_MATCH)
+   end function operator__match_resident
+
+   function flags_resident(pattern, batch, op) result(res)
+      character(*), intent(in) :: pattern
+      type(fx_batch), intent(in) :: batch
+      integer(c_int), intent(in) :: op
+      logical :: res(batch%n)
+      integer(c_int8_t), allocatable, target :: flags(:)
+      integer :: st(1)
+      call run_resident([character(len(pattern)) :: pattern], batch, op, .false., st)
+      allocate(flags(max(1, batch%n)))
+      call fx_batch_fetch(batch, flags)
+      res = flags(1:batch%n) /= 0
+   end function flags_resident
+
+   !> an array of patterns against ONE resident batch: res(i, j) = pattern(j) .in. row i (every row meets every pattern: the rows
+   !> are read from HBM once for the patterns that share a pass)
+   function operator__in_patterns_resident(pattern, batch) result(res)
+      character(*), intent(in) :: pattern(:)
+      type(fx_batch), intent(in) :: batch
+      logical :: res(batch%n, size(pattern))
+      res = flags_patterns_resident(pattern, batch, FXAMD_OP_SEARCH)
+   end function operator__in_patterns_resident
+
+   function operator__match_patterns_resident(pattern, batch) result(res)
+      character(*), intent(in) :: pattern(:)
+      type(fx_batch), intent(in) :: batch
+      logical :: res(batch%n, size(pattern))
+      res = flags_patterns_resident(pattern, batch, FXAMD_OP_MATCH)
+   end function operator__match_patterns_resident
+
+   function flags_patterns_resident(pattern, batch, op) result(res)
+      character(*), intent(in) :: pattern(:)
+      type(fx_batch), intent(in) :: batch
+      integer(c_int), intent(in) :: op
+      logical :: res(batch%n, size(pattern))
+      integer(c_int8_t), allocatable, target :: flags(:)
+      integer :: st(size(pattern)), j
+      if (size(pattern) == 0) return
+      call run_resident(pattern, batch, op, .false., st)
+      allocate(flags(max(1, batch%n)))
+      do j = 1, size(pattern)
+         call fx_batch_fetch(batch, flags, which=j)
+         res(:, j) = flags(1:batch%n) /= 0
+      end do
+   end function flags_patterns_resident
+
+   !> `call regex(pattern, batch, from, to [, status])`: 1-based byte spans of every resident row (0,0 = none; -9999 = invalid pattern)
+   subroutine subroutine__regex_resident(pattern, batch, from, to, status)
+      character(*), intent(in) :: pattern
+      type(fx_batch), intent(in) :: batch
+      integer, intent(inout) :: from(:), to(:)
+      integer, optional, intent(inout) :: status
+      integer(c_int8_t), allocatable, target :: flags(:)
+      integer(c_int32_t), allocatable, target :: f(:), t(:)
+      integer :: st(1)
+      call run_resident([character(len(pattern)) :: pattern], batch, FXAMD_OP_SEARCH, .true., st)
+      if (present(status)) status = st(1)
+      if (st(1) /= 0) then
+         from = INVALID_CHAR_INDEX
+         to = INVALID_CHAR_INDEX
+         return
+      end if
+      allocate(flags(max(1, batch%n)), f(max(1, batch%n)), t(max(1, batch%n)))
+      call fx_batch_fetch(batch, flags, f, t)
+      from(1:batch%n) = int(f(1:batch%n))
+      to(1:batch%n) = int(t(1:batch%n))
+   end subroutine subroutine__regex_resident
 
    PURE_ function function__regex(pattern, text) result(res)
       character(*), intent(in)  :: pattern, text

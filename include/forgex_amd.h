@@ -131,6 +131,32 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
 int fxamd_host_register(void* p, int64_t bytes);
 int fxamd_host_unregister(void* p);
 
+/* ---- device-resident batches for hosts without a device runtime of their own ---------------------------------------------------
+ * (the Fortran module's type(fx_batch); extends the surface of reference src/forgex.F90:24-54 instead of replacing it: the same
+ * operators and `regex` accept a batch in place of a character array).  The rows are uploaded once -- or a caller's device pointer is
+ * wrapped, not owned -- and stay in HBM across calls and patterns.  fxamd_batch_run enqueues m >= 1 patterns over the rows on the
+ * batch's own stream (asynchronous) and leaves the results in device buffers the batch owns: result set i = flags[i*n .. i*n+n) and,
+ * with spans, from / to likewise (`.match.` programs: flags only).  fxamd_batch_fetch copies one result set to host arrays,
+ * fxamd_batch_count reduces its flags on the device (8 bytes cross the bus), fxamd_batch_results hands out the device pointers.
+ * fetch / count / sync are synchronous; the entries of one batch are serialised. */
+typedef struct fxamd_batch fxamd_batch;
+int fxamd_batch_upload(const uint8_t* h_rows, int64_t n, int64_t row_len, fxamd_batch** out);
+int fxamd_batch_wrap(const uint8_t* d_rows, int64_t n, int64_t row_len, fxamd_batch** out);
+void fxamd_batch_free(fxamd_batch* b);
+int fxamd_batch_info(const fxamd_batch* b, int64_t* n, int64_t* row_len);
+int fxamd_batch_run(fxamd_program* const* progs, int32_t m, fxamd_batch* b, int with_spans);
+int fxamd_batch_sync(fxamd_batch* b);
+int fxamd_batch_fetch(fxamd_batch* b, int32_t which, uint8_t* h_flags, int32_t* h_from, int32_t* h_to);
+int fxamd_batch_count(fxamd_batch* b, int32_t which, int64_t* n_matches);
+int fxamd_batch_results(fxamd_batch* b, const uint8_t** d_flags, const int32_t** d_from, const int32_t** d_to, int32_t* sets, void** hip_stream);
+void fxamd_f_batch_upload(const uint8_t* h_rows, int64_t n, int64_t row_len, fxamd_batch** out, int32_t* rc);
+void fxamd_f_batch_wrap(const uint8_t* d_rows, int64_t n, int64_t row_len, fxamd_batch** out, int32_t* rc);
+void fxamd_f_batch_free(fxamd_batch* b, int32_t* rc);
+void fxamd_f_batch_run(fxamd_program* const* progs, int32_t m, fxamd_batch* b, int32_t with_spans, int32_t* rc);
+void fxamd_f_batch_sync(fxamd_batch* b, int32_t* rc);
+void fxamd_f_batch_fetch(fxamd_batch* b, int32_t which, uint8_t* h_flags, int32_t* h_from, int32_t* h_to, int32_t* rc);
+void fxamd_f_batch_count(fxamd_batch* b, int32_t which, int64_t* n_matches, int32_t* rc);
+
 /* Subroutine forms of four entries above for Fortran `pure` hosts (forgex_amd/fortran/forgex.F90 binds these): a PURE FUNCTION may
  * only have INTENT(IN) / VALUE dummies (F2018 C1590; gfortran rejects the function forms in a pure interface) and a compiler may
  * merge or drop pure-function calls, so every output -- the return code included -- is a pointer argument here.  Same semantics. */

@@ -132,6 +132,10 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "1001"])
     assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True
     assert line["config"]["parallelism"] == "shard2" and line["scaling"] == "weak"
+    # the self-proving fields of a multi-rank run: ranks as the collectives counted them, one identity per rank (all distinct),
+    # every rank's own time
+    assert line["rccl_ranks"] == 2 and len(line["devices"]) == 2 and line["devices_distinct"] is True and len(set(line["devices"])) == 2
+    assert len(line["per_rank_ms_per_step"]) == 2 and line["per_rank_ms_per_step"][1] > line["per_rank_ms_per_step"][0]
     line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong", "--config", "cfg5"])
     assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True and line["scaling"] == "strong"
 

@@ -1400,3 +1400,54 @@ def test_speculative_forward_pass_vs_oracle_and_full_scan(fx, L, monkeypatch):
             assert np.array_equal(f2.cpu().numpy(), f) and np.array_equal(a2.cpu().numpy(), a) and np.array_equal(b2.cpu().numpy(), b), (pat, L, blocks, "no spec")
     monkeypatch.delenv("FXAMD_NO_SPEC", raising=False)
     assert n_spec >= 4   # the pass did run for the patterns it is meant for (`[^a]+`, `^...`, `.` lack the flag: U+FFFF / the NUL survive)
+
+
+def test_fortran_resident_batches(fx):
+    """Round 4: type(fx_batch) of the Fortran module -- rows uploaded once, `pattern .in. batch`, `.match.`, `patterns(:) .in. batch`,
+    `call regex(pattern, batch, from, to)`, fx_batch_search + fx_batch_count / fx_batch_fetch -- against the host-buffer forms of the same
+    module on the same rows (reference surface: src/forgex.F90:24-54), and the rate of fx_batch_search over resident config-3-like rows
+    (results left on the device), which has to be the kernels' rate, not the PCIe link's."""
+    import re
+    import subprocess
+    fdir = os.path.join(golden.ROOT, "forgex_amd", "fortran")
+    exe = os.path.join(fdir, "build", "fortran_batch_test")
+    if not os.path.exists(exe):
+        if not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
+            pytest.skip("flang not available")
+        subprocess.check_call(["make", "-C", fdir])
+    r = subprocess.run([exe, str(4 * 1024 * 1024)], capture_output=True, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "FORTRAN BATCH OK" in out, (out[-1500:], r.stderr[-500:])
+    m = re.search(r"RESIDENT RATE rows \d+ x 256 B\s+([0-9.]+) GB/s", out)
+    assert m, out
+    assert float(m.group(1)) > 2500.0, out   # (4 M x 256 B: 1 GB per call; the host-buffer forms manage about 45 GB/s)
+
+
+def test_python_resident_batch_mirror(fx):
+    """forgex_amd.Batch (the Python mirror of fxamd_batch_*): uploaded numpy rows and a wrapped CUDA tensor, one and several programs,
+    fetch / count against match_device on the same rows."""
+    import torch
+    from forgex_amd import synth
+    rows_t = synth.batch("cfg5", 0, 50_000, torch.device("cuda"))
+    rows_np = rows_t.cpu().numpy()
+    p1 = fx.Program(rb"[a-z]+\d+", fx.OP_SEARCH)
+    p2 = fx.Program(rb"\d\d", fx.OP_SEARCH)
+    pm = fx.Program(rb"[a-z ]+", fx.OP_MATCH)
+    f1, a1, b1 = p1.match_device(rows_t)
+    f2, a2, b2 = p2.match_device(rows_t)
+    fm = pm.match_device(rows_t, spans=False)[0]
+    torch.cuda.synchronize()
+    for batch in (fx.Batch(rows_np), fx.Batch(rows_t)):
+        batch.run(p1)
+        f, a, b = batch.fetch()
+        assert np.array_equal(f, f1.cpu().numpy()) and np.array_equal(a, a1.cpu().numpy()) and np.array_equal(b, b1.cpu().numpy())
+        assert batch.count() == int(f1.sum())
+        batch.run([p1, p2])
+        for w, (ef, ea, eb) in enumerate(((f1, a1, b1), (f2, a2, b2))):
+            f, a, b = batch.fetch(w)
+            assert np.array_equal(f, ef.cpu().numpy()) and np.array_equal(a, ea.cpu().numpy()) and np.array_equal(b, eb.cpu().numpy()), w
+            assert batch.count(w) == int(ef.sum())
+        batch.run(pm, spans=False)
+        assert np.array_equal(batch.fetch(spans=False)[0], fm.cpu().numpy())
+        with pytest.raises(RuntimeError):
+            batch.fetch(1)   # only one result set in the last run

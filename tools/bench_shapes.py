@@ -45,6 +45,17 @@ SHAPES = {
     "utf8_128_flags": ("config 4's text in rows of 128 B, flags only", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 128), 3 << 19, False, False),
     "utf8_64_flags": ("config 4's text in rows of 64 B, flags only", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 64), 3 << 20, False, False),
     "ragged_255":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 255 B (ragged loader)", "search", [r"[a-z]+\d+"], "cfg3", 255, 10_000_000, False, True),
+    # row lengths Fortran programs declare (character(80), (100), (132), (200)): 2.56 GB of config-3 bytes viewed at that length
+    "ragged_80":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 80 B", "search", [r"[a-z]+\d+"], "cfg3", 80, 32_000_000, False, True),
+    "ragged_100":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 100 B", "search", [r"[a-z]+\d+"], "cfg3", 100, 25_600_000, False, True),
+    "ragged_132":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 132 B", "search", [r"[a-z]+\d+"], "cfg3", 132, 19_393_939, False, True),
+    "ragged_200":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 200 B", "search", [r"[a-z]+\d+"], "cfg3", 200, 12_800_000, False, True),
+    "ragged_20":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 20 B", "search", [r"[a-z]+\d+"], "cfg3", 20, 64_000_000, False, True),
+    "ragged_255_flags": ("the same at 255 B, flags only", "search", [r"[a-z]+\d+"], "cfg3", 255, 10_000_000, False, False),
+    # config 4's pattern and text at ragged row lengths (byte-level tables on ragged rows: round 4)
+    "utf8_100":     ("config 4's pattern and text in rows of 100 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 100), 2 << 20, False, True),
+    "utf8_132":     ("config 4's pattern and text in rows of 132 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 132), 3 << 19, False, True),
+    "utf8_255":     ("config 4's pattern and text in rows of 255 B (190 B of text, blank-padded)", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 255), 1 << 20, False, True),
 }
 
 

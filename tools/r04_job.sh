@@ -29,6 +29,16 @@ for step in "$@"; do
       FXAMD_NO_SPEC=1 python bench.py --config cfg4 --flags-only --no-cpu-baseline --no-extras > $OUT/cfg4_flags_nospec.json 2> $OUT/cfg4_flags_nospec.err; line $OUT/cfg4_flags_nospec.json "cfg4 flags-only nospec" ;;
     bench_*) cfg=${step#bench_}; python bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; line $OUT/bench_$cfg.json "bench $cfg" ;;
     driver) python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; line $OUT/bench_driver.json "driver protocol" ;;
+    k:*) expr=${step#k:}; timeout 2400 python -m pytest tests -m gpu -x -q -k "$expr" > $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; echo "pytest -k '$expr' rc $?"; tail -4 $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log ;;
+    shape:*) sh=${step#shape:}; python tools/bench_shapes.py --shape $sh > $OUT/shape_$sh.json 2> $OUT/shape_$sh.err; python3 - $OUT/shape_$sh.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("shape %-16s L %4d  %.4f ms  %.0f GB/s  frac %.3f  path %s  matches %s" % (d["shape"], d["row_len"], d["ms_per_step"], d["input_gbs"], d["frac_of_hbm_peak"], d["last_path"], d["matches"]))
+except Exception as e:
+    print("shape: no line:", e, open(sys.argv[1].replace(".json", ".err")).read()[-400:])
+PY
+      ;;
     *) echo "unknown step $step" ;;
   esac
 done
