@@ -88,7 +88,9 @@ struct FxScanCtx {
 #define FX_FWD_DIRECT 1       // clustered starts on many lanes: straight into the aligned walk, no 32-symbol window
 #endif
 #ifndef FX_ONE_MINW
-#define FX_ONE_MINW 1   // minimum waves per SIMD fx_search_one is compiled for (experiment hook: tools/ru_one.sh)
+#define FX_ONE_MINW 1   // minimum waves per SIMD fx_search_one is compiled for (experiment hook: tools/ru_one.sh).  The built-in rule: THREE
+                        // for rows of 96 / 128 bytes -- three blocks fit a CU by LDS, the variants use 139-169 VGPRs and the step from 168 to 169
+                        // costs a wave per SIMD (config 5: 0.36 -> 0.42 ms when one more live value crossed it); every variant fits without scratch
 #endif
 #ifndef FX_SPEC_FWD
 #define FX_SPEC_FWD 1         // speculative forward pass from the row's first character (fx_spec_forward; programs with FXP_F_SPEC_FWD)
@@ -136,8 +138,8 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       if (PREPAD) na = c.pre_na;
       else if (RAGGED && (!whole || DECODED)) na |= pad_rows<CH>(tile, lane, Lr);
       if constexpr (TAIL) {
-         // right-to-left from the row's LAST byte: the chunk the row ends in over its valid bytes, then whole chunks in a rolled loop
-         // (the chunk count is a run-time value here); same two lookup buffers as below
+         // right-to-left from the row's LAST byte: the chunk the row ends in over its valid bytes, then the whole chunks; same two
+         // lookup buffers as below
          const FxTail& T = *c.tl;
          F fa[8], fb[8];
          if (T.nb != 0u) {
@@ -158,31 +160,39 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             esel = mx >= P.hit_min ? entry : esel;
          }
          if (T.kt != 0u) {
-            uint4 wk = tile[tile_cell(lane, T.kt - 1u)];
+            // whole chunks kt - 1 .. 0: the aligned kernels' unrolled loop (cell addresses are immediates) behind wave-uniform guards;
+            // only the first chunk's words are read through a run-time address
+            uint4 wk = tile[tile_cell(lane, T.kt - 1u)], wn = tile[tile_cell(lane, T.kt >= 2u ? T.kt - 2u : 0u)];
             lookup8(fa, wk.z, wk.w, tabR);
-#pragma unroll 1
-            for (uint32_t k = T.kt - 1u;; --k) {
-               if (!DECODED) na |= wk.x | wk.y | wk.z | wk.w;
-               lookup8(fb, wk.x, wk.y, tabR);
-               __builtin_amdgcn_sched_barrier(0);
-               {
-                  const uint32_t entry = state;
-                  const uint32_t mx = chain8_back(fa, state, TRp);
-                  gsel = mx >= P.hit_min ? 2u * k + 1u : gsel;
-                  esel = mx >= P.hit_min ? entry : esel;
+#pragma unroll
+            for (int k = CH - 2; k >= 0; --k) {   // (kt <= CH - 1: a ragged row is shorter than 16 * CH bytes)
+               if ((uint32_t)k < T.kt) {
+                  if (!DECODED) na |= wk.x | wk.y | wk.z | wk.w;
+                  lookup8(fb, wk.x, wk.y, tabR);
+                  __builtin_amdgcn_sched_barrier(0);
+                  {
+                     const uint32_t entry = state;
+                     const uint32_t mx = chain8_back(fa, state, TRp);
+                     gsel = mx >= P.hit_min ? (uint32_t)(2 * k + 1) : gsel;
+                     esel = mx >= P.hit_min ? entry : esel;
+                     asm volatile("" : "+v"(esel));
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  if (k >= 1) {
+                     wk = wn;
+                     lookup8(fa, wk.z, wk.w, tabR);
+                     if (k >= 2) wn = tile[tile_cell(lane, k - 2)];
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                  {
+                     const uint32_t entry = state;
+                     const uint32_t mx = chain8_back(fb, state, TRp);
+                     gsel = mx >= P.hit_min ? (uint32_t)(2 * k) : gsel;
+                     esel = mx >= P.hit_min ? entry : esel;
+                     asm volatile("" : "+v"(esel));
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
                }
-               __builtin_amdgcn_sched_barrier(0);
-               wk = tile[tile_cell(lane, k != 0u ? k - 1u : 0u)];   // (after the last chunk: chunk 0 once more, unused)
-               lookup8(fa, wk.z, wk.w, tabR);
-               __builtin_amdgcn_sched_barrier(0);
-               {
-                  const uint32_t entry = state;
-                  const uint32_t mx = chain8_back(fb, state, TRp);
-                  gsel = mx >= P.hit_min ? 2u * k : gsel;
-                  esel = mx >= P.hit_min ? entry : esel;
-               }
-               __builtin_amdgcn_sched_barrier(0);
-               if (k == 0u) break;
             }
          }
       } else
@@ -827,7 +837,7 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 // FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
 // and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
-__global__ __launch_bounds__(256, FX_ONE_MINW) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
+__global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : 1))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr) {
    if (MARKED && gate[0] == 0u) return;   // nothing was deferred
@@ -883,7 +893,7 @@ __global__ __launch_bounds__(256, FX_ONE_MINW) void fx_search_one(const uint8_t*
    uint4 stage[CH];
    const FxTail tl = fx_tail_of(RAGGED ? Lr : 16u * CH);
    if constexpr (!MARKED) {
-      if (RAGGED) load_tile_rag<CH>(stage, rows, wave_global << 6, n, lane, tl);
+      if constexpr (RAGGED) load_tile_rag<CH>(stage, rows, wave_global << 6, n, lane, tl);
       else load_tile<CH>(stage, rows, wave_global << 6, n, lane, true);
    }
    // ---- tables -> LDS ----
@@ -1121,7 +1131,7 @@ __global__ __launch_bounds__(256, FX_ONE_MINW) void fx_search_one(const uint8_t*
             hint = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
          }
          if (process) {
-            if (RAGGED) {
+            if constexpr (RAGGED) {
                store_tile_rag<CH>(stage, tile, lane, tl);
                fx_tail_patch(tile, lane, tl);
             } else store_tile<CH>(stage, tile, lane);
@@ -1130,7 +1140,7 @@ __global__ __launch_bounds__(256, FX_ONE_MINW) void fx_search_one(const uint8_t*
          // zero valid bytes
          t += wave_stride;
          if (MARKED) live = tile_marked(t);
-         if (RAGGED) load_tile_rag<CH>(stage, rows, t << 6, n, lane, tl, live);
+         if constexpr (RAGGED) load_tile_rag<CH>(stage, rows, t << 6, n, lane, tl, live);
          else load_tile<CH>(stage, rows, t << 6, n, lane, live);
          if (!process) continue;
       } else {
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(256, FX_ONE_MINW) void fx_search_one(const uint8_t*
          const uint4* src = reinterpret_cast<const uint4*>(rows + row * (int64_t)(16 * CH));
          // (ragged rows: whole chunks as unaligned 16-byte loads, the chunk the row ends in from the row's last 16 bytes; GEN: the general
          //  procedure reads its rows from global memory)
-         if (RAGGED && !GEN) {
+         if constexpr (RAGGED && !GEN) {
             gather_row_rag<CH>(tile, lane, rows + row * (int64_t)L, row_ok, tl);
             fx_tail_patch(tile, lane, tl);
          }
@@ -1402,11 +1412,18 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
       hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, (const uint32_t*)nullptr);
       return hipGetLastError();
    };
+   constexpr bool RAG_OK = (CH & (CH - 1)) == 0;   // ragged rows run on the power-of-two instantiations (fxamd.hip: one_chunks)
+   if (ragged && !RAG_OK) return hipErrorInvalidValue;
    if (is_match) {   // `.match.`: one verdict per row, no span
       if constexpr (BSCH == 3) return hipErrorInvalidValue;   // (never dispatched: FXP_F_BYTE_A8 is a search program's table)
-      else return ragged ? go(&fx_search_one<CH, false, SCH, BSCH, true, GEN, false, true>) : go(&fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>);
+      else {
+         if constexpr (RAG_OK)
+            if (ragged) return go(&fx_search_one<CH, false, SCH, BSCH, true, GEN, false, true>);
+         return go(&fx_search_one<CH, false, SCH, BSCH, false, GEN, false, true>);
+      }
    }
-   if (ragged) return spans ? go(&fx_search_one<CH, true, SCH, BSCH, true, GEN>) : go(&fx_search_one<CH, false, SCH, BSCH, true, GEN>);
+   if constexpr (RAG_OK)
+      if (ragged) return spans ? go(&fx_search_one<CH, true, SCH, BSCH, true, GEN>) : go(&fx_search_one<CH, false, SCH, BSCH, true, GEN>);
    return spans ? go(&fx_search_one<CH, true, SCH, BSCH, false, GEN>) : go(&fx_search_one<CH, false, SCH, BSCH, false, GEN>);
 }
 

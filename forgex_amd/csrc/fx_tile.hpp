@@ -254,9 +254,9 @@ __device__ __forceinline__ void store_tile_relayout(uint4 (&v)[CH], uint4* tile,
 // symbols -- so every left-to-right walk (forward pass, windows, re-walks, the speculative pass) is the aligned kernels' code; the
 // right-to-left pass starts at the row's last byte: chunks behind the text are skipped and the chunk the row ends in is walked over its
 // valid bytes only (chain8_back_n).  No inert symbol is involved, so the byte-level tables run on ragged rows as well, and the work
-// follows the row length, not the instantiation's chunk count.  Staging: the tile is still one contiguous run of 64*Lr bytes; piece
-// p = q*64 + lane is the 16 bytes at row p / nch, chunk p % nch (nch = chunks that hold text) -- an UNALIGNED 16-byte buffer load straight
-// into the swizzled cell.  The linear LDS image + per-lane relayout of rounds 1-3 (store_tile_relayout: 4-way bank conflicts at
+// follows the row length, not the instantiation's chunk count.  Staging: the tile is still one contiguous run of 64*Lr bytes; CH lanes
+// read 16*CH bytes of one row (CH = the row's chunk count rounded up to a power of two) -- UNALIGNED 16-byte buffer loads at the row
+// stride, straight into the swizzled cells with the aligned kernels' store.  The linear LDS image + per-lane relayout of rounds 1-3 (store_tile_relayout: 4-way bank conflicts at
 // Lr = 255, unused chunk columns scanned at Lr = 100 / 132) remains only in the multi-pass kernels of this file.
 // =========================================================================================================
 struct FxTail {
@@ -264,45 +264,40 @@ struct FxTail {
    uint32_t kt;    // the chunk position Lr falls in: Lr >> 4 (chunks 0 .. kt-1 are whole text)
    uint32_t nb;    // text bytes in chunk kt: Lr & 15 (0: the row ends on a chunk boundary, chunk kt holds the NUL and KILL symbols only)
    uint32_t nch;   // chunks that hold text: (Lr + 15) >> 4
-   uint32_t inv;   // 2^16 / nch + 1: p / nch == (p * inv) >> 16 for p < 1024, nch <= 16 (the error p / 2^16 stays below 1 / nch)
-   uint32_t padb;  // 16 * nch - Lr
 };
 __device__ __forceinline__ FxTail fx_tail_of(const uint32_t Lr) {
    const uint32_t nch = (Lr + 15u) >> 4;
-   return FxTail{Lr, Lr >> 4, Lr & 15u, nch, 65536u / nch + 1u, 16u * nch - Lr};
+   return FxTail{Lr, Lr >> 4, Lr & 15u, nch};
 }
-// tile loads: piece p = q*64 + lane = row R = p / nch, chunk k = p - R*nch: the 16 bytes at tile byte R*Lr + 16k = 16p - R*padb.  The
-// extent is the tile's bytes + 3: a dword is dropped whole when it straddles the extent, and the last row's last dword does unless
-// Lr % 4 == 0 (at most 3 bytes behind the batch's last row are read, never used -- as in load_tile).
+// tile loads: CH (a power of two here: the dispatch rounds a ragged row's chunk count up to one) lanes share a row -- lane = (r0, k) =
+// (lane / CH, lane % CH) reads the 16 bytes at row byte 16k of row q * (64 / CH) + r0 in instruction q: voff = r0 * Lr + 16k per lane,
+// the rows' distance q * (64 / CH) * Lr in the scalar offset (the range check includes it).  Lanes whose chunk holds no text (k >= nch)
+// ask for an address behind the extent and fetch nothing.  The extent is the tile's bytes + 3: a dword is dropped whole when it
+// straddles the extent, and the last row's last dword does unless Lr % 4 == 0 (at most 3 bytes behind the batch's last row are read,
+// never used -- as in load_tile).
 template <int CH>
 __device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, const FxTail& T,
                                               bool enable = true) {
+   static_assert((CH & (CH - 1)) == 0, "ragged rows: the chunk count of the instantiation is a power of two");
    const int64_t rows_left = n - row0;
    const uint32_t valid = (!enable || rows_left <= 0) ? 0u : (rows_left >= 64 ? 64u : (uint32_t)rows_left) * T.Lr + 3u;
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)T.Lr;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
                                                                          __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+   constexpr uint32_t RPI = 64 / CH;
+   const uint32_t r0 = lane / CH, k = lane % CH;
+   const uint32_t voff = k < T.nch ? r0 * T.Lr + 16u * k : 0x7FFFFFF0u;
+   const uint32_t step = __builtin_amdgcn_readfirstlane(RPI * T.Lr);
 #pragma unroll
    for (int q = 0; q < CH; ++q) {
-      if ((uint32_t)q < T.nch) {   // wave-uniform
-         const uint32_t p = (uint32_t)q * 64u + lane;
-         const uint32_t R = (p * T.inv) >> 16;
-         const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 16u * p - R * T.padb, 0, FX_LOAD_AUX);
-         v[q] = make_uint4(t.x, t.y, t.z, t.w);
-      }
+      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)q * step, FX_LOAD_AUX);
+      v[q] = make_uint4(t.x, t.y, t.z, t.w);
    }
 }
 template <int CH>
 __device__ __forceinline__ void store_tile_rag(const uint4 (&v)[CH], uint4* tile, uint32_t lane, const FxTail& T) {
-#pragma unroll
-   for (int q = 0; q < CH; ++q) {
-      if ((uint32_t)q < T.nch) {
-         const uint32_t p = (uint32_t)q * 64u + lane;
-         const uint32_t R = (p * T.inv) >> 16, k = p - R * T.nch;
-         tile[tile_cell(R, k)] = v[q];
-      }
-   }
+   if (lane % CH < T.nch) store_tile<CH>(v, tile, lane);   // (the chunks behind the text keep their KILL symbols)
 }
 // what follows the text in lane r's own cells: the trailing NUL at byte Lr, KILL symbols (0xFE) behind it.  Chunks behind chunk kt are
 // written ONCE per kernel (the loader never touches them); chunk kt -- the text's last bytes, rewritten with every tile -- is patched here.

@@ -504,9 +504,20 @@ static int tile_chunks(int64_t row_len) {
       if (row_len <= 16 * c) return c;
    return 0;
 }
+// the one-launch kernel's instantiation for rows of up to 256 bytes: whole chunks as above; ragged rows (any other length) take the
+// power of two at or above their chunk count -- CH lanes share a row in the loader, and the work follows the row length, not CH
+static int one_chunks(int64_t row_len) {
+   const int c = tile_chunks(row_len);
+   if (c == 0 || row_len == 16 * c) return c;
+   int p = 1;
+   while (16 * p < row_len) p *= 2;
+   return p;
+}
 // long rows (any length): walked in 256-byte segments by the CH = 16 instantiations
 static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536; }
 static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : tile_chunks(row_len); }
+// ... and the larger of the two instantiations a row length may meet (LDS budgets of table schemes that must hold for both pipelines)
+static int chunks_max(int64_t row_len) { return long_row(row_len) ? 16 : std::max(tile_chunks(row_len), one_chunks(row_len)); }
 // what a pass needs to know beyond the tables: deferral policy of a first pass, gate word of a marked-tile pass
 struct PassOpts {
    uint32_t defer_tiles = 0, gate_word = 0;
@@ -567,7 +578,7 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    if (h.flags & FXP_F_FAST_OK) return 0;
    if ((h.flags & FXP_F_W16_OK) && !fx_env().no_w16) return 2;
    if (h.flags & FXP_F_CHAIN_OK) {
-      const size_t need = (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
+      const size_t need = (size_t)4 * 64 * 16 * (chunks_max(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
       if (need <= 150 * 1024) return 1;
    }
    return -1;
@@ -580,7 +591,7 @@ static int bytes_scheme(const FxpHeader& h) { return ((h.flags & FXP_F_BYTE_W16)
 static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, bool ragged_too = false) {
    if (fx_env().no_byte_dfa) return false;   // test hook: exercise the decode pass instead
    if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || (!long_row(row_len) && !ragged_too && row_len != 16 * tile_chunks(row_len))) return false;
-   return (size_t)4 * 64 * 16 * (chunks_of(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
+   return (size_t)4 * 64 * 16 * (chunks_max(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
 
 template <int MODE, int SCH>
@@ -673,7 +684,7 @@ static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const
    const uint32_t table_bytes = (SCH == 1 ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u) +
                                 (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
    const uint32_t Lr = (uint32_t)row_len;
-   switch (tile_chunks(row_len)) {
+   switch (one_chunks(row_len)) {
       case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
@@ -699,7 +710,7 @@ static hipError_t launch_one_any(int sch, int bsch, bool gen, const FxpHeader& h
 // fit next to it (4 tiles + class-level tables + 8 KB), else the chain format (a few hundred bytes to a few KB), 0 = none.
 static int one_bytes_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, int sch) {
    if (!bytes_ok(h, d_rows, row_len, true)) return 0;
-   const size_t tiles_b = (size_t)4 * 64 * 16 * (tile_chunks(row_len) + 1);
+   const size_t tiles_b = (size_t)4 * 64 * 16 * (one_chunks(row_len) + 1);
    const size_t cls_b = sch == 0 ? 4096 : (sch == 2 ? 4096 : 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16);
    if (bytes_scheme(h) == 2 && tiles_b + cls_b + 4096 + 2048 <= 80 * 1024)   // (3: with the forward automaton in the v_perm format, FXP_F_BYTE_A8)
       return (sch == 0 && (h.flags & FXP_F_BYTE_A8) && h.mode == FXP_MODE_SEARCH_ENGINE && !fx_env().no_a8) ? 3 : 2;

@@ -19,9 +19,22 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_*" % tag))):
         src = os.path.join(d, "summary." + ext)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(prof, "%s_summary.%s" % (name, ext)))
-    ks = glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True)
+    # the kernel-stats CSV the summary was computed from (summary.json names it); without that, the newest one.  Then the check that
+    # the tracked pair agrees: every kernel's average duration in the summary must be the CSV's.
+    sj0 = os.path.join(d, "summary.json")
+    named = json.load(open(sj0)).get("kernel_stats_csv") if os.path.exists(sj0) else None
+    ks = [os.path.join(d, named)] if named and os.path.exists(os.path.join(d, named)) else sorted(
+        glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if ks:
-        shutil.copy(ks[0], os.path.join(prof, "%s_kernel_stats.csv" % name))
+        dst = os.path.join(prof, "%s_kernel_stats.csv" % name)
+        shutil.copy(ks[-1], dst)
+        if os.path.exists(sj0):
+            import csv
+            want = {r.get("Name"): r.get("AverageNs") for r in json.load(open(sj0)).get("kernel_stats", [])}
+            have = {r.get("Name"): r.get("AverageNs") for r in csv.DictReader(open(dst))}
+            bad = [k for k in want if have.get(k) != want[k]]
+            if bad:
+                sys.exit("collect_profiles: %s: the kernel-stats CSV and the summary disagree on %r" % (name, bad[:3]))
     log = os.path.join(d, "bench_under_rocprof.log")
     if os.path.exists(log):
         lines = [ln for ln in open(log) if ln.startswith("{")]

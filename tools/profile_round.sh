@@ -7,6 +7,7 @@ TAG=${1:-r01}
 CFG=${2:-cfg3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT   # (scratch of an earlier call with the same tag: its CSVs would sit next to this run's)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --config $CFG --no-cpu-baseline --no-extras --no-parity > $OUT/bench_under_rocprof.log 2>&1

@@ -9,10 +9,15 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for sh in $SHAPES; do
   OUT=$REPO/gpurun_out/prof_${TAG}_$sh
+  rm -rf $OUT   # (scratch of an earlier call with the same tag: its CSVs would sit next to this run's)
   mkdir -p $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 30 --warmup 10 > $OUT/bench_under_rocprof.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
+  if [ "${3:-}" = "sq" ]; then   # issue / wait / LDS-conflict counters and instruction counts of the dominant kernel (two more passes)
+    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 3 --warmup 1 > $OUT/pmc_sq.log 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $OUT/pmc_inst -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 3 --warmup 1 > $OUT/pmc_inst.log 2>&1
+  fi
   (cd $REPO && python3 tools/summarize_shapes.py $OUT $TAG $sh) > $OUT/summary.txt 2>&1
   cat $OUT/summary.txt
 done

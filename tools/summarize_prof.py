@@ -12,14 +12,16 @@ out, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 
 
 def find(sub, pattern):
-    hits = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
-    return hits[0] if hits else None
+    # (the NEWEST file: gpurun merges every call's output into the same scratch directory, so older runs' files may sit next to it)
+    hits = sorted(glob.glob(os.path.join(out, sub, "**", pattern), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None
 
 
 summary = {"tag": tag, "config": cfg}
 kt = find("kt", "*kernel_stats.csv")
 if kt:
     rows = list(csv.DictReader(open(kt)))
+    summary["kernel_stats_csv"] = os.path.relpath(kt, out)   # tools/collect_profiles.py copies exactly this file
     summary["kernel_stats"] = [{k: r.get(k) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
     print("== kernel stats (%s)" % kt)
     for r in rows:
