@@ -342,10 +342,12 @@ def main():
     init_rows = synth.batch(cfg, start, 64, dev)
     init_out = (torch.empty(64, dtype=torch.uint8, device=dev), torch.empty(64, dtype=torch.int32, device=dev) if spans else None,
                 torch.empty(64, dtype=torch.int32, device=dev) if spans else None)
+    t_init = time.perf_counter()
     prog.match_device(init_rows, spans=spans, out=init_out)
     rc = forgex_amd.lib().fxamd_program_reserve(prog._h, rows_per_gpu, torch.cuda.current_stream(dev).cuda_stream)
     assert rc == 0, rc
     torch.cuda.synchronize()
+    init_ms = (time.perf_counter() - t_init) * 1e3
     # the batch is generated on the GPU LAST (seconds of generator kernels), so that the warm-up steps follow a busy GPU, not an idle gap
     rows = synth.batch(cfg, start, rows_per_gpu, dev)
 
@@ -448,7 +450,8 @@ def main():
                 "achieved": gbs(kernel_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (gbs(kernel_ms) / HBM_PEAK_GBS) if kernel_ms else None,
                 "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)" if traffic else None,
-                "kernel_ms": kernel_ms, "kernel_ms_event_pair_per_launch": kernel_1 if fast else None, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": kernel_ms, "kernel_ms_method": "HIP events on the launch stream, one pair per 10 consecutive launches, settled clocks",
+                "kernel_ms_event_pair_per_launch": kernel_1 if fast else None, "algorithmic_bytes_per_launch": alg_bytes,
                 "cold_kernel_ms": cold_ms, "cold_frac": (gbs(cold_ms) / HBM_PEAK_GBS) if cold_ms else None,
                 "cold_note": "first %d launches after a 0.5 s idle gap" % min(reps, 20)}
 
@@ -553,6 +556,9 @@ def main():
                         "note": "the same %d timed steps after %d more untimed launches (clock transient over)" % (args.steps, SETTLE)},
             "roofline": roofline, "gather_ms": gather_ms, "packed_step_ms": packed_step_ms, "flags_only": flags_only, "host_path": host_path,
             # multi-GPU runs prove themselves: ranks and devices as the collectives saw them, every rank's own step time, the gather's bytes
+            # what happened before the W warm-up steps (outside warm-up and timed region): the program's start-up, as a service does it once
+            "init": {"rows": 64, "ms": init_ms, "what": "one match call on 64 generated rows (tables uploaded, code objects loaded) + fxamd_program_reserve, "
+                     "BEFORE the batch is generated; not a step of the workload (protocol since round 3: BASELINE.md section 3)"},
             "rccl_ranks": census["ranks"] if census else None, "devices": census["devices"] if census else None,
             "devices_distinct": census["distinct"] if census else None, "per_rank_ms_per_step": per_rank_ms if use_dist else None, "gather": gather_info,
         }

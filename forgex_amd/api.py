@@ -168,8 +168,10 @@ class pinned:
             raise RuntimeError("fxamd_host_register failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
         return self.arr
 
-    def __exit__(self, *exc):
-        _lib.lib().fxamd_host_unregister(self.arr.ctypes.data_as(ctypes.c_void_p))
+    def __exit__(self, exc_type, exc, tb):
+        rc = _lib.lib().fxamd_host_unregister(self.arr.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0 and exc_type is None:   # a failed unpin leaves the memory page-locked: say so (unless an exception is already on its way)
+            raise RuntimeError("fxamd_host_unregister failed: %d (hip error %d)" % (rc, _lib.lib().fxamd_last_hip_error()))
         return False
 
 

@@ -13,6 +13,7 @@
 //   fx_general           one lane = one row through fxrow::run_row (row_engine.hpp): every mode, UTF-8 decode
 //                        on device, candidate-list driver, literal search, `.match.`; also the fix-up pass for
 //                        rows the fast kernel flags as non-ASCII.
+#include <atomic>
 #include <functional>
 
 #include "../../include/forgex_amd_bench.h"
@@ -40,8 +41,6 @@ extern template hipError_t launch_multi<3> FX_MULTI_SIG;
 extern template hipError_t launch_multi<4> FX_MULTI_SIG;
 extern template hipError_t launch_multi<6> FX_MULTI_SIG;
 extern template hipError_t launch_multi<8> FX_MULTI_SIG;
-extern template hipError_t launch_multi<12> FX_MULTI_SIG;
-extern template hipError_t launch_multi<16> FX_MULTI_SIG;
 #endif
 
 // ---- test / experiment hooks: the FXAMD_* environment variables, read once (FxEnv, fx_tile.hpp) ----
@@ -63,7 +62,6 @@ static void env_load() {
    e.multipass = on("FXAMD_MULTIPASS");
    e.no_cache = on("FXAMD_NO_CACHE");
    e.no_multi = on("FXAMD_NO_MULTI");
-   e.multi_always = on("FXAMD_MULTI_ALWAYS");
    e.multi_no_bytes = on("FXAMD_MULTI_NO_BYTES");
    e.multi_inq = on("FXAMD_MULTI_INQ");
    e.multi_serial = on("FXAMD_MULTI_SERIAL");
@@ -380,6 +378,7 @@ struct fxamd_program {
    std::vector<DevScratch> scratch;
    uint64_t use_clock = 0;
    int last_path = 0;
+   std::atomic<size_t> held{0};   // bytes of trimmable scratch this program keeps (refreshed under `mu`, read by the cache's accounting without it)
 };
 static constexpr size_t FX_MAX_SCRATCH_SETS = 16;
 
@@ -408,6 +407,10 @@ static void trim_scratch(fxamd_program* p);
 // hipFree synchronises the whole device: a Fortran loop of `pattern .in. strs(:)` does compile -> match -> free per call, so the
 // buffers stay with the cached program unless they exceed this budget (eviction from the cache frees everything anyway).
 static constexpr size_t FX_TRIM_BUDGET = size_t(512) << 20;
+// ... and what ALL cached programs may keep together: beyond it the least recently used idle ones are trimmed (64 cached programs of a
+// service that matches large batches under many patterns would otherwise sit on 64 x 512 MB next to the caller's own allocator)
+static constexpr size_t FX_TRIM_BUDGET_ALL = size_t(1) << 30;
+static size_t trim_cache(size_t keep_bytes);
 static void release_program(fxamd_program* p) {
    bool dead = false, idle = false;
    {
@@ -427,6 +430,7 @@ static void release_program(fxamd_program* p) {
       dead = --p->refs == 0;   // the cache dropped it while it was pinned
    }
    if (dead) destroy_program(p);
+   (void)trim_cache(FX_TRIM_BUDGET_ALL);   // (no-op while the cached programs together stay below the budget)
 }
 
 // (callers hold p->mu)
@@ -528,12 +532,8 @@ struct PassOpts {
 // 256-byte rows on the 8-state tables: half-row staging (8 KB of LDS per wave: three waves per SIMD instead of two)
 // (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
 //  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14)
-static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool spans = true, uint32_t out_mode = 0u) {
-   (void)h;
-   (void)spans;
-   (void)out_mode;
-   const bool off = fx_env().no_half;   // (test / experiment hook: these rows on the one-launch kernel)
-   return !off && scheme == 0 && row_len == 256;
+static bool half_rows(int scheme, int64_t row_len) {
+   return !fx_env().no_half && scheme == 0 && row_len == 256;   // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel)
 }
 
 template <int MODE, int SCH>
@@ -762,7 +762,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(h, sc0, row_len, true, out_mode)) && !fx_env().multipass;
+                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(sc0, row_len)) && !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -801,7 +801,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // The counter groups alternate between calls, and it is a call's FIRST-PASS kernel that zeroes the other group for the call
       // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
-      const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(h, scheme, row_len, d_from != nullptr, out_mode)) &&
+      const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len)) &&
                               !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
@@ -815,7 +815,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
       // 256-byte rows on the 8-state tables keep the multi-pass pipeline: its first pass stages HALF rows when spans are asked for
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
-      const bool keep_multipass = !is_match && half_rows(h, scheme, row_len, d_from != nullptr, out_mode);
+      const bool keep_multipass = !is_match && half_rows(scheme, row_len);
       first.half = keep_multipass && d_from != nullptr;
       if (one_launch) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
@@ -940,12 +940,18 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    return FXAMD_OK;
 }
 
-static void trim_scratch(fxamd_program* p) {
-   std::lock_guard<std::mutex> g(p->mu);
+// (p->mu held) what trim_scratch could free
+static size_t held_scratch(const fxamd_program* p) {
    size_t held = 0;
    for (const DevScratch& s : p->scratch)
       held += (size_t)s.worklist_rows * 4 + (size_t)s.unpacked_rows * 9 + s.nfa_scratch_rows * (size_t)2 * p->prog.hdr().nfa_words * 4;
-   if (held <= FX_TRIM_BUDGET) return;
+   return held;
+}
+static void trim_scratch(fxamd_program* p, size_t budget) {
+   std::lock_guard<std::mutex> g(p->mu);
+   const size_t held = held_scratch(p);
+   p->held.store(held);
+   if (held <= budget) return;
    for (DevScratch& s : p->scratch) {
       if (s.d_worklist && s.worklist_rows * 4 > (int64_t(1) << 20)) {
          (void)hipFree(s.d_worklist);
@@ -963,6 +969,40 @@ static void trim_scratch(fxamd_program* p) {
          s.nfa_scratch_rows = 0;
       }
    }
+   p->held.store(held_scratch(p));
+}
+static void trim_scratch(fxamd_program* p) { trim_scratch(p, FX_TRIM_BUDGET); }
+// Trim idle cached programs, least recently used first, until the cache as a whole keeps at most `keep_bytes`; returns the bytes freed.
+// Victims are pinned under the cache lock and trimmed outside it (a trim takes the program's own lock and calls hipFree).
+static size_t trim_cache(size_t keep_bytes) {
+   std::vector<fxamd_program*> victims;
+   {
+      std::lock_guard<std::mutex> g(g_cache_mu);
+      size_t total = 0;
+      for (fxamd_program* q : g_cache) total += q->held.load();
+      if (total <= keep_bytes) return 0;
+      for (fxamd_program* q : g_cache) {   // (most recently used last)
+         if (total <= keep_bytes) break;
+         const size_t h = q->held.load();
+         if (q->refs != 1 || h == 0) continue;   // in use by a caller, or nothing to free
+         ++q->refs;
+         victims.push_back(q);
+         total -= h;
+      }
+   }
+   size_t freed = 0;
+   for (fxamd_program* q : victims) {
+      const size_t before = q->held.load();
+      trim_scratch(q, 0);
+      freed += before - std::min(before, q->held.load());
+      bool dead = false;
+      {
+         std::lock_guard<std::mutex> g(g_cache_mu);
+         dead = --q->refs == 0;
+      }
+      if (dead) destroy_program(q);
+   }
+   return freed;
 }
 static void destroy_program(fxamd_program* p) {
    for (DevBlob& b : p->blobs)
@@ -979,6 +1019,10 @@ void fxamd_reload_env(void) {   // tests only: not synchronised with calls in fl
    (void)fx_env();
    env_load();
 }
+/* Free the device scratch (work lists, unpacked staging, NFA bitsets) of every idle program of the compile cache; returns the bytes
+ * freed.  The library trims by itself once the cached programs together keep more than 1 GB; a host that shares the GPU with another
+ * allocator calls this when it wants the memory back now. */
+int64_t fxamd_cache_trim(void) { return (int64_t)trim_cache(0); }
 int fxamd_device_count(void) {
    int c = 0;
    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
@@ -1191,7 +1235,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   po.half = half_rows(h, scheme, row_len, d_from != nullptr) && d_from != nullptr;
+   po.half = half_rows(scheme, row_len) && d_from != nullptr;
    if (scheme != 0 && bytes && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
@@ -1238,7 +1282,9 @@ int fxamd_match_batch_device(fxamd_program* p, const uint8_t* d_rows, int64_t n,
    DevScratch* sc = nullptr;
    rc = scratch_for(p, dev, st, &sc);
    if (rc != FXAMD_OK) return rc;
-   return enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags, d_from, d_to, st);
+   rc = enqueue_batch(p, d_blob, sc, d_rows, n, row_len, d_flags, d_from, d_to, st);
+   p->held.store(held_scratch(p));
+   return rc;
 }
 
 int fxamd_packed_layout(int64_t n, int64_t row_len, int with_spans, int64_t* off_from, int64_t* off_to, int64_t* total_bytes, int32_t* span_bytes) {
@@ -1306,6 +1352,7 @@ static int packed_slice(fxamd_program* p, const uint8_t* d_rows, int64_t n, int6
       sc->unpacked_rows = 0;
       FX_HIP(hipMalloc((void**)&sc->d_unpacked, (size_t)n * 9 + 64));
       sc->unpacked_rows = n;
+      p->held.store(held_scratch(p));
    }
    int32_t* uf = reinterpret_cast<int32_t*>(sc->d_unpacked);
    int32_t* ut = uf + n;
@@ -1399,16 +1446,20 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
             fused.push_back(i);
       }
    // The shared pass pays where a tile is small enough for full occupancy next to m patterns' tables -- rows of up to 128 bytes: 6 patterns
-   // over 100 M x 128 B 15.4 ms against 16.9 ms pattern by pattern -- and LOSES on longer rows, whose single-pattern kernels run at more
-   // waves per SIMD (half-row staging at 256 bytes: 3.67 against 3.21 ms; config 4's UTF-8 rows: 0.68 against 0.58 ms;
-   // tools/exp_multi.py, gpurun call r03_c11): those run one pipeline per pattern.  FXAMD_MULTI_ALWAYS=1: test hook.
-   if (row_len > 128 && !fx_env().multi_always) fused.clear();
+   // over 100 M x 128 B 15.4 ms against 16.9 ms pattern by pattern (tools/exp_multi.py, gpurun call r03_c11).
+   // Rows longer than 128 bytes: one pipeline per pattern.  The shared pass LOST there in every variant measured over rounds 2-3 (six
+   // patterns over config 3: 3.67 ms shared against 3.21 ms one by one; config 4: 0.75 against 0.69) -- the single-pattern
+   // kernels stage half rows / speculate, the shared one stages whole rows once per group and runs m full scans -- so round 4 removed that
+   // path instead of keeping a slower kernel behind a hook: fx_search_multi exists for rows of up to 128 bytes only.
+   if (row_len > 128) fused.clear();
    const int ch = tile_chunks(row_len);
    // byte-level tables in the shared pass (nibble format; 8 KB of LDS per pattern then): when some fused pattern has them for these rows
    std::vector<int> obs((size_t)m, 0);
    bool any_bytes = false;
    for (int32_t i : fused) {
-      const int ob = one_bytes_scheme(progs[i]->prog.hdr(), d_rows, row_len, 0);
+      // (ragged rows: fx_search_multi still pads them with the inert symbol 255, which byte-level tables do not have -- the
+      //  pad-free scheme of round 4 is the one-launch kernel's)
+      const int ob = row_len == 16 * tile_chunks(row_len) ? one_bytes_scheme(progs[i]->prog.hdr(), d_rows, row_len, 0) : 0;
       obs[(size_t)i] = (ob == 2 || ob == 3) && progs[i]->prog.hdr().mode == FXP_MODE_SEARCH_ENGINE && !fx_env().multi_no_bytes ? ob : 0;
       any_bytes = any_bytes || obs[(size_t)i] != 0;
    }
@@ -1487,8 +1538,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          case 4: e = launch_multi<4>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          case 6: e = launch_multi<6>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          case 8: e = launch_multi<8>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
-         case 12: e = launch_multi<12>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
-         default: e = launch_multi<16>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
+         default: e = hipErrorInvalidValue; break;   // (never dispatched: the shared pass takes rows of up to 128 bytes)
       }
       if (e != hipSuccess) {
          undo();
@@ -1578,7 +1628,7 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
    if (chunk_rows > n) chunk_rows = n;
    const bool reg = fx_env().host_register && row_len > 0;   // pin the caller's rows in place for the call (experiment)
    bool registered = false;
-   if (reg) registered = hipHostRegister(const_cast<uint8_t*>(h_rows), (size_t)n * rl, hipHostRegisterDefault) == hipSuccess;
+   if (reg) registered = hipHostRegister(const_cast<uint8_t*>(h_rows), (size_t)n * rl, hipHostRegisterPortable) == hipSuccess;
    int rc = FXAMD_OK;
    auto fail = [&](hipError_t e) { rc = hip_fail(e); };
    auto prepare = [&](HostSlot& s) {
@@ -1677,7 +1727,7 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
 // A caller that keeps a large batch in one array pins it once with these (the array stays usable as before).
 int fxamd_host_register(void* p, int64_t bytes) {
    if (!p || bytes <= 0) return FXAMD_E_ARG;
-   FX_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+   FX_HIP(hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable));   // (portable: pinned for every device of the process, not only the current one)
    return FXAMD_OK;
 }
 int fxamd_host_unregister(void* p) {

@@ -131,6 +131,11 @@ int fxamd_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n, i
 int fxamd_host_register(void* p, int64_t bytes);
 int fxamd_host_unregister(void* p);
 
+/* Free the device scratch (work lists, staging of packed calls, NFA bitsets) that idle programs of the compile cache keep between
+ * calls; returns the bytes freed.  The library does so by itself, least recently used first, once the cached programs together keep
+ * more than 1 GB (a single program: 512 MB); a host that shares the GPU with another allocator calls this to have the memory back now. */
+int64_t fxamd_cache_trim(void);
+
 /* ---- device-resident batches for hosts without a device runtime of their own ---------------------------------------------------
  * (the Fortran module's type(fx_batch); extends the surface of reference src/forgex.F90:24-54 instead of replacing it: the same
  * operators and `regex` accept a batch in place of a character array).  The rows are uploaded once -- or a caller's device pointer is
@@ -176,8 +181,8 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
  * one-launch kernel over the tiles that pass left.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
- * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,
- * FXAMD_MULTI_ALWAYS; grid experiments: FXAMD_ONE_GRID, FXAMD_ONE_ROUND_MB, FXAMD_ONE_BLOCKS, FXAMD_HALF_ROUNDS.  They are read once
+ * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL;
+ * grid experiments: FXAMD_ONE_GRID, FXAMD_ONE_ROUND_MB, FXAMD_ONE_BLOCKS, FXAMD_HALF_ROUNDS.  They are read once
  * per process; `fxamd_reload_env` of forgex_amd_bench.h reads them again.) */
 int fxamd_last_path(const fxamd_program* p);
 int fxamd_last_hip_error(void);

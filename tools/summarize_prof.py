@@ -63,4 +63,22 @@ if dom:
     if sqv:
         summary["sq_counters_per_launch"] = sqv
         print("== SQ counters per launch:", json.dumps(sqv))
+        wc = sqv.get("SQ_WAVE_CYCLES") or 1.0
+        print("   active %.2f  wait_any %.2f  wait_inst %.2f of the wave cycles; LDS bank conflicts %.2f of the LDS-array cycles" % (
+            sqv.get("SQ_ACTIVE_INST_ANY", 0) / wc, sqv.get("SQ_WAIT_ANY", 0) / wc, sqv.get("SQ_WAIT_INST_ANY", 0) / wc,
+            sqv.get("SQ_LDS_BANK_CONFLICT", 0) / (sqv.get("SQ_LDS_IDX_ACTIVE") or 1.0)))
+    inst = {c: sum(v) / len(v) for (n, c), v in pmc("pmc_inst").items() if n == dom}
+    if inst:
+        summary["inst_counters_per_launch"] = inst
+        # input bytes per launch from the bench line printed under the profiler
+        nbytes = None
+        try:
+            for ln in open(os.path.join(out, "bench_under_rocprof.log")):
+                if ln.startswith("{"):
+                    c = json.loads(ln)["config"]
+                    nbytes = c["rows_per_gpu"] * c["row_len"]
+        except Exception:
+            pass
+        print("== instructions per launch: " + "  ".join("%s %.3g%s" % (c, v, (" (%.2f per input byte x 64 lanes)" % (v * 64.0 / nbytes)) if nbytes else "")
+                                                          for c, v in sorted(inst.items())))
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
