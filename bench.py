@@ -25,7 +25,10 @@ One JSON line on rank 0:
                1 flag + two int32) / its average launch duration, measured live with HIP events on the launch stream,
                at settled clocks (`cold_*`: the same over the first launches after an idle gap)
   parity       GPU flags / from / to of THIS run against the product's tables walked on the host (test harness
-               tests/support/libhostwalk.so, all host cores) over the WHOLE batch of the rank
+               tests/support/libhostwalk.so, all host cores) over the WHOLE batch of the rank; `parity.oracle`: the same batch against
+               oracle/liboracle.so (the reference's algorithm restated: no matching code shared with the product) -- as many rows as
+               about 20 s of this host's cores allow, spread over the batch (the whole of config 3 on the 256-core GPU box);
+               multi-rank runs: `parity.gathered_shards` = every other rank's gathered + unpacked results against the host walker
   cpu_baseline the REAL reference (oracle/_ref/ref_driver, flang build; kind "reference") or the C++ restatement
                (oracle/liboracle.so; kind "port") on a bounded sample of the same rows, on this host's cores, and the GPU
                results compared with the reference's on that sample
@@ -110,6 +113,44 @@ def full_parity(pattern, rows_dev, flags, frm, to, threads):
         bad += k
     return {"rows": int(n), "mismatches": bad, "first_mismatch_row": first_bad, "fields": "flag, from, to" if frm is not None else "flag",
             "checker": "product tables walked on the host (tests/support/libhostwalk.so, %d threads), whole batch of rank 0" % threads,
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
+def oracle_parity(pattern, rows_dev, flags, frm, to, threads, budget_s=20.0):
+    """The timed batch against the ORACLE (oracle/liboracle.so: the C++ restatement of the reference's restart-loop algorithm, pinned
+    to the real reference by the golden vectors) -- a checker that shares no matching code with the product, unlike the host table
+    walker of full_parity.  As many rows as fit `budget_s` on this host's cores (a probe sets the rate), taken as 16 slices spread
+    evenly over the batch; on the 256-core GPU box that is the whole of config 3."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "support"))
+    import oracle_lib
+    n, L = rows_dev.shape
+    pat = pattern.encode()
+    probe = min(n, 64 * threads)
+    t0 = time.perf_counter()
+    oracle_lib.batch(2, pat, rows_dev[:probe].cpu().numpy(), threads)
+    per_row = max((time.perf_counter() - t0) / probe, 1e-9)
+    want = int(min(n, max(probe, budget_s / per_row)))
+    slices = 16 if want < n else 1
+    per = max(1, want // slices)
+    bad = checked = 0
+    first_bad = None
+    t0 = time.perf_counter()
+    for i in range(slices):
+        c0 = 0 if slices == 1 else (n - per) * i // max(1, slices - 1)
+        c1 = n if slices == 1 else min(n, c0 + per)
+        rows = np.ascontiguousarray(rows_dev[c0:c1].cpu().numpy())
+        f, a, b = oracle_lib.batch(2, pat, rows, threads)
+        d = f != flags[c0:c1].cpu().numpy()
+        if frm is not None:
+            d |= (a != frm[c0:c1].cpu().numpy()) | (b != to[c0:c1].cpu().numpy())
+        k = int(d.sum())
+        if k and first_bad is None:
+            first_bad = int(c0 + np.flatnonzero(d)[0])
+        bad += k
+        checked += c1 - c0
+    return {"rows": int(checked), "of": int(n), "mismatches": bad, "first_mismatch_row": first_bad, "slices": slices,
+            "checker": "oracle/liboracle.so (restatement of api_internal_m.F90:31-167, %d threads)" % threads,
             "seconds": round(time.perf_counter() - t0, 2)}
 
 
@@ -568,6 +609,10 @@ def main():
                 line["parity"] = full_parity(pattern, rows, flags, frm, to, threads)
             except Exception as e:
                 line["parity"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
+            try:   # ... and against the oracle, which shares no matching code with the product (as many rows as ~20 s of this host allow)
+                line["parity"]["oracle"] = oracle_parity(pattern, rows, flags, frm, to, threads)
+            except Exception as e:
+                line["parity"]["oracle"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
             # every OTHER rank's shard as it arrived on the root: the gathered + unpacked image against the host walker on that shard's
             # rows, regenerated here from (config, start, count) -- the RCCL gather and the unpack are inside what is checked
             if unpacked is not None and world > 1:

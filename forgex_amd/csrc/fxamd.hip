@@ -1463,16 +1463,24 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       obs[(size_t)i] = (ob == 2 || ob == 3) && progs[i]->prog.hdr().mode == FXP_MODE_SEARCH_ENGINE && !fx_env().multi_no_bytes ? ob : 0;
       any_bytes = any_bytes || obs[(size_t)i] != 0;
    }
-   const int gmax = ch > 0 ? multi_max_patterns(ch, any_bytes) : 0;
-   if ((int)fused.size() < 2 || gmax < 2) fused.clear();
+   // Launch groups: patterns WITH byte-level tables first (8 KB of LDS per pattern and the queue area), the others behind them, and the
+   // group size, the kernel's table stride and `any_bytes` are per GROUP -- a group of ASCII-only patterns does not pay for the
+   // others' byte-level tables with half the patterns per launch
+   std::stable_partition(fused.begin(), fused.end(), [&](int32_t i) { return obs[(size_t)i] != 0; });
+   if ((int)fused.size() < 2 || ch <= 0 || multi_max_patterns(ch, any_bytes) < 2) fused.clear();
    std::vector<char> done((size_t)m, 0);
    int dev = -1;
    if (!fused.empty()) FX_HIP(hipGetDevice(&dev));
-   for (size_t g0 = 0; g0 < fused.size(); g0 += (size_t)gmax) {
+   for (size_t g0 = 0, g1 = 0; g0 < fused.size(); g0 = g1) {
       FxMultiArgs a;
       std::memset(&a, 0, sizeof(a));
-      const size_t g1 = std::min(fused.size(), g0 + (size_t)gmax);
-      if (g1 - g0 < 2) break;   // a single leftover pattern takes its own (faster) pipeline
+      const bool group_bytes = obs[(size_t)fused[g0]] != 0;   // (sorted: a group that starts without them holds none)
+      const int gmax = multi_max_patterns(ch, group_bytes);
+      g1 = std::min(fused.size(), g0 + (size_t)std::max(gmax, 1));
+      if (g1 - g0 < 2 || gmax < 2) {   // a single leftover pattern takes its own (faster) pipeline
+         if (g1 - g0 >= 2) g1 = g0 + 1;
+         continue;
+      }
       // The group's handles stay locked from the first PREPARE to the last follow-up (in address order: two threads fusing
       // overlapping groups cannot deadlock): PREPARE flips a handle's counter group, and nobody else may enqueue on that handle
       // until the shared first pass -- which zeroes the other group for the call after this one -- is in the stream.
@@ -1523,7 +1531,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
                shs[k - g0].exc_in_shared = true;
             }
          }
-         a.any_bytes = any_bytes ? 1u : 0u;
+         a.any_bytes = group_bytes ? 1u : 0u;
          ++a.m;
       }
       if (rc != FXAMD_OK) {
@@ -1550,7 +1558,14 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       //  defers them; the scratch -- counter words, worklist -- is the one PREPARE chose on the caller's stream)
       std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
       SideStreams* ss = nullptr;
-      if (!fx_env().multi_serial) {
+      // (a caller's stream that is being CAPTURED into a hipGraph keeps its follow-ups on itself: the shared side streams would join the
+      //  capture, and another thread that uses them meanwhile would meet a capture error -- ADVICE r03)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+         (void)hipGetLastError();
+         cap = hipStreamCaptureStatusNone;
+      }
+      if (!fx_env().multi_serial && cap == hipStreamCaptureStatusNone) {
          side_lock.lock();
          ss = side_streams(dev, g1 - g0);
          if (ss && hipEventRecord(ss->fork, st) != hipSuccess) ss = nullptr;
