@@ -924,9 +924,15 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    // (used by 4b and by section 7, where the argument is written out)
    auto suffix_is_necessary_ending = [&]() -> bool {
       bool ok = lit.suffix.find('\0') == std::string::npos;
+      // (Literals with NON-ASCII characters qualify since round 4.  The argument is made on characters and carries over to the bytes
+      //  the driver's INDEX works on: a match is prefix characters + a middle of >= 0 characters + suffix characters -- the length check
+      //  below keeps the two from overlapping -- so in bytes the suffix occurrence of a match starts at least |prefix| bytes behind its
+      //  start.  On pure-ASCII rows a non-ASCII literal never occurs: a necessary one means "no match", which is what the driver
+      //  (prefix absent: brute force; suffix absent: no match) and the brute-force scan both say.  On rows the byte-level tables
+      //  answer themselves -- valid CANONICAL UTF-8: overlong forms, which decode to the same code point but are other bytes, send a
+      //  row of such a program to the general procedure -- byte occurrences are exactly the character-aligned ones.
+      //  tests/support/fuzz_prefilter.py with FX_FUZZ_UTF8=1: see DESIGN.md 3.6.)
       const std::vector<int32_t> sc = decode_chars(lit.suffix), pc = decode_chars(lit.prefix);
-      for (int32_t c : sc) ok = ok && c < 128;
-      for (int32_t c : pc) ok = ok && c < 128;
       Bits Wb = rclos[static_cast<size_t>(nfa.exit)];
       for (size_t i = sc.size(); ok && i-- > 0;) {
          if (bt(Wb, nfa.entry)) ok = false;
@@ -966,7 +972,14 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
                }
             }
          }
-         if (shortest < 0 || static_cast<size_t>(shortest) < pc.size() + sc.size()) ok = false;
+         // (round 4: "longer than the suffix" is all the driver's arithmetic needs -- a match that starts at wrapped index st and ends
+         //  with the suffix has its suffix occurrence at u = st + m - |suffix| >= st + 1, so the last occurrence in the row lies behind
+         //  st and the cut-off `suf_idx(text) < ci(wrapped)`, i.e. ci >= last occurrence (api_internal_m.F90:114-116), never drops st;
+         //  rounds 1-3 asked for m >= |prefix| + |suffix|, which sent `ab{2,}` (prefix `abb`, suffix `bb`) to the general kernel.  A match
+         //  that IS the suffix -- `A{1,2}bb` on `Abb`: prefix `A`, suffix `Abb` -- is cut off by the reference when no later occurrence
+         //  follows: such programs keep the statement-for-statement driver.)
+         (void)pc;
+         if (shortest < 0 || static_cast<size_t>(shortest) < sc.size() + 1) ok = false;
       }
       return ok;
    };
@@ -1180,7 +1193,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    if (brute_equiv && prefilter && has_suffix) {
       // With a suffix literal the driver also (a) gives up when the suffix does not occur, (b) stops at candidates behind its
       // last occurrence (api_internal_m.F90:99-116; one index is a text index, the other a wrapped one).  Neither changes a
-      // result when the suffix is a NECESSARY ending of every match and no match is shorter than prefix + suffix (then the
+      // result when the suffix is a NECESSARY ending of every match and every match is LONGER than the suffix (then the
       // suffix of the match found starts at least one byte behind the match start, which is all the off-by-one needs).
       // Necessity is checked on the NFA walked BACKWARDS from the exit: at each of the last ls positions only the suffix's own
       // symbol -- a singleton class -- leads anywhere, and the entry state (a complete, shorter match) is not met on the way.

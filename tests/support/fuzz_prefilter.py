@@ -16,7 +16,50 @@ MIDS = [".*", ".+", "[a-c]*", "\\d+", "[a-z]+", "(b|c)*", "x?", "\\s*", "[^a]*",
 ALPH = list("abcxyz012 -=") + ["ab", "aa", "foo", "id=", "aba", "zz", "12"]
 
 
+# round 4: literals with non-ASCII characters (the proofs used to be restricted to ASCII prefix / suffix literals); the texts mix the
+# literals' own characters with other multi-byte characters, overlong encodings of them (C1 A1 = 'a', E0 8E B1 = alpha: the reference
+# decodes those arithmetically to the SAME code point, but the driver's INDEX works on bytes) and structure errors
+U_LITS = ["α", "αβ", "ぁ", "é", "αa", "aα", "夢", "胡蝶", "αα", "ああ", "aé", "é ", "x", "ab", "-", "ぁa", "βα"]
+U_MIDS = [".{1,7}", ".*", ".+", "[α-ω]*", "[ぁ-ん]+", "(α|β)*", "x?", "\\s*", "[^a]*", "", ".", "\\w{1,3}", "[a-zα-ω]+"]
+U_ALPH = ["α", "β", "ぁ", "あ", "é", "夢", "胡", "蝶", "胡蝶", "a", "b", "x", " ", "-", "αβ", "αα", "ああ"]
+U_JUNK = [b"\xc1\xa1", b"\xe0\x8e\xb1", b"\xce", b"\xb1", b"\xe3\x81", b"\xff", b"\xf0\x9f\x98\x80", b"\xc0\xaf", b"\xe5\xa4"]
+
+
+def gen_case_utf8(rng):
+    r = rng.random()
+    if r < 0.5:
+        pat = rng.choice(U_LITS) + rng.choice(U_MIDS) + rng.choice(U_LITS)
+    elif r < 0.7:
+        pat = rng.choice(U_LITS) + rng.choice(U_MIDS)
+    else:
+        pat = rng.choice(U_LITS) + rng.choice(U_MIDS) + rng.choice(U_LITS) + rng.choice(U_MIDS) + rng.choice(U_LITS)
+    lits = [c for c in pat if ord(c) > 127 or c.isalnum() or c in " -"]
+    pieces = []
+    for _ in range(rng.randint(0, 12)):
+        q = rng.random()
+        if q < 0.55 and lits:
+            pieces.append(rng.choice(lits).encode())
+        elif q < 0.9:
+            pieces.append(rng.choice(U_ALPH).encode())
+        else:
+            pieces.append(rng.choice(U_JUNK))
+    return (rng.choice(["I", "R", "R"]), pat.encode(), b"".join(pieces))
+
+
+REPS = ["{2,}", "{1,2}", "+", "{2}", "{3,}", "{1,3}"]   # a repeated tail makes prefix and suffix literals overlap in the shortest match
+
+
 def gen_case(rng):
+    if os.environ.get("FX_FUZZ_UTF8"):
+        return gen_case_utf8(rng)
+    if os.environ.get("FX_FUZZ_OVERLAP") and rng.random() < 0.7:
+        body = rng.choice(LITS)
+        if rng.random() < 0.5:
+            body = "(" + body + ")"
+        pat = rng.choice(["", rng.choice(LITS)]) + body + rng.choice(REPS) + rng.choice(["", rng.choice(LITS), rng.choice(MIDS) + rng.choice(LITS)])
+        bits = [c for c in pat if c.isalnum() or c in " =-"]
+        txt = "".join(rng.choice(bits + ALPH[:4]) for _ in range(rng.randint(1, 14))) if bits else "ab"
+        return (rng.choice(["I", "R", "R"]), pat.encode(), txt.encode())
     r = rng.random()
     if r < 0.45:
         pat = rng.choice(LITS) + rng.choice(MIDS) + rng.choice(LITS)

@@ -1483,3 +1483,38 @@ def test_cache_trim_frees_idle_scratch_and_results_stay_right(fx):
         img = prog.match_device_packed(rows, spans=True)
         torch.cuda.synchronize()
         assert torch.equal(img, want), p
+
+
+def test_prefix_suffix_literals_round4_on_tile_kernel(fx):
+    """Round 4 widened the proof "candidate-list driver == brute force" (compile.cpp, suffix_is_necessary_ending): prefix / suffix
+    literals with NON-ASCII characters (`夢.{1,7}胡蝶` of the reference's own tests, `α.*β`, `ab.*é`) and literals that OVERLAP in the
+    shortest match (`ab{2,}`: prefix `abb`, suffix `bb` -- every match must only be LONGER than the suffix) now run on the tile kernels;
+    `A{1,2}bb` (a match may BE its suffix: the reference's cut-off drops it when no later occurrence follows) stays on the
+    statement-for-statement driver.  Rows: the literals' own characters, other multi-byte characters, overlong encodings of the same
+    code points (other bytes: the driver's INDEX does not see them), structure errors -- flags and spans vs the oracle."""
+    import random
+    rng = random.Random(4242)
+    pats = ["夢.{1,7}胡蝶", "α.*β", "ab.*é", "é.*ab", "α[a-z]+β", "ab{2,}", "ab{2,}c", "a\\t{2,}", "(ab)+-α", "ぁ[α-ω]*ぁあ"]
+    pieces = [x.encode() for x in ("夢", "胡蝶", "胡", "蝶", "α", "β", "é", "ぁ", "あ", "a", "b", "ab", "abb", "bb", "c", "\t", "\t\t", "-", " ", "x")] + \
+             [b"\xc1\xa1", b"\xe0\x8e\xb1", b"\xce", b"\xb1", b"\xe5\xa4", b"\xff"]
+    for L in (64, 100, 256):
+        rows = []
+        for _ in range(4096):
+            buf = b""
+            while len(buf) < L:
+                buf += rng.choice(pieces) if rng.random() < 0.9 else bytes(rng.choice(b"abcxyz ") for _ in range(rng.randint(1, 9)))
+            rows.append(np.frombuffer(buf[:L], dtype=np.uint8))
+        data = np.stack(rows)
+        for pat in pats:
+            prog, f, a, b = _device_run(fx, pat.encode(), fx.OP_SEARCH, data)
+            assert prog.last_path() != 2, (pat, L, prog.last_path())   # tile kernels (exception rows inside them go to the row procedure)
+            of, oa, ob = oracle_lib.batch(2, pat.encode(), data, NT)
+            bad = np.nonzero((f != of) | (a != oa) | (b != ob))[0]
+            assert bad.size == 0, (pat, L, int(bad[0]), int(f[bad[0]]), int(a[bad[0]]), int(b[bad[0]]), int(of[bad[0]]), int(oa[bad[0]]), int(ob[bad[0]]), data[bad[0]].tobytes())
+            _, f2, _, _ = _device_run(fx, pat.encode(), fx.OP_SEARCH, data, spans=False)
+            assert np.array_equal(f2, of), (pat, L, "flags only")
+    # the quirk that must NOT be smoothed over: a match that is its own suffix literal
+    quirk = np.frombuffer(b"Abb" + b" " * 61 + b"AbbAbb" + b" " * 58 + b"AAbb" + b" " * 60, dtype=np.uint8).reshape(3, 64)
+    prog, f, a, b = _device_run(fx, rb"A{1,2}bb", fx.OP_SEARCH, quirk)
+    of, oa, ob = oracle_lib.batch(2, rb"A{1,2}bb", quirk, NT)
+    assert f.tolist() == of.tolist() == [0, 1, 1] and a.tolist() == oa.tolist() and b.tolist() == ob.tolist()
