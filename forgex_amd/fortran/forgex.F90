@@ -424,7 +424,11 @@ contains
       character(*), intent(in), target, contiguous :: str(:)
       type(fx_batch) :: batch
       integer(c_int32_t) :: rc
-      call fxamd_f_batch_upload(c_loc(str), int(size(str), c_int64_t), int(len(str), c_int64_t), batch%h, rc)
+      if (size(str) > 0) then
+         call fxamd_f_batch_upload(c_loc(str), int(size(str), c_int64_t), int(len(str), c_int64_t), batch%h, rc)
+      else   ! (c_loc of a zero-sized array is not defined)
+         call fxamd_f_batch_upload(c_null_ptr, 0_c_int64_t, int(len(str), c_int64_t), batch%h, rc)
+      end if
       if (rc /= 0) error stop 'forgex (amd): fxamd_batch_upload failed (the match path needs a HIP device; there is no CPU fallback)'
       batch%n = size(str)
       batch%row_len = len(str)

@@ -86,12 +86,29 @@ def test_prefilter_equivalence_proof_holds_on_fuzz(built, monkeypatch):
     b = golden.run_protocol(golden.ORACLE_CLI, cases)
     diffs = [(c, x, y) for c, x, y in zip(cases, a, b) if not x.startswith("U") and x != y]
     assert not diffs, diffs[:5]
+    # round 4: literals with non-ASCII characters (texts with overlong encodings and structure errors; brute force and byte-level
+    # tables) and prefix / suffix literals that overlap in the shortest match (`ab{2,}`)
+    for mode, extra in (("FX_FUZZ_UTF8", None), ("FX_FUZZ_UTF8", "FX_HW_BYTES"), ("FX_FUZZ_OVERLAP", None)):
+        monkeypatch.setenv(mode, "1")
+        if extra:
+            monkeypatch.setenv(extra, "1")
+        rng = random.Random(72)
+        cases = [fuzz_prefilter.gen_case(rng) for _ in range(3000)]
+        a = golden.run_protocol(HW, cases)
+        b = golden.run_protocol(golden.ORACLE_CLI, cases)
+        diffs = [(c, x, y) for c, x, y in zip(cases, a, b) if not x.startswith("U") and x != y]
+        assert not diffs, (mode, extra, diffs[:5])
+        monkeypatch.delenv(mode)
+        if extra:
+            monkeypatch.delenv(extra)
     # `literal.*literal` shapes are among the programs the proof admits
     lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
     lib.hw_info.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
     # ... and so are prefixes with a border (overlap detector in R), with or without a proven suffix; a suffix literal the proof
     # does not cover keeps the pattern on the general kernel
-    for pat, want in ((b"abc.*xyz", True), (b"id=\\d+;", True), (b"aa[bc]", True), (b"aa.*bb", True), (b"foo.a b", False)):
+    # (round 4: non-ASCII literals and literals that overlap in the shortest match are admitted; a match that may BE its suffix is not)
+    for pat, want in ((b"abc.*xyz", True), (b"id=\\d+;", True), (b"aa[bc]", True), (b"aa.*bb", True), (b"foo.a b", False),
+                      ("夢.{1,7}胡蝶".encode(), True), ("α.*β".encode(), True), (b"ab{2,}", True), (b"A{1,2}bb", False)):
         info = (ctypes.c_int32 * 8)()
         lib.hw_info(pat, len(pat), 0, info)
         assert bool(info[1] & (8 | 256 | 0x2000)) == want, (pat, hex(info[1]))
