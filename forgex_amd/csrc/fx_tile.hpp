@@ -574,17 +574,19 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
    using F = typename FxF<S_>::type;
    using FA = typename FxF<S_A>::type;
    static_assert(NW % GB == 0, "window groups: a multiple of the lookup batch");
-   uint2 rw = make_uint2(0, 0);
-   uint32_t nv = 8;
-   if (on) {
-      if (g * 8u + 8u <= L) rw = *reinterpret_cast<const uint2*>(rp + g * 8u);
-      else {   // the row ends inside the group: its last 8 bytes, shifted down to the group's place (nothing behind the row is read)
-         const uint2 r = *reinterpret_cast<const uint2*>(rp + L - 8u);
-         nv = L - g * 8u;
-         const uint64_t v = (((uint64_t)r.y << 32) | r.x) >> (64u - 8u * nv);
-         rw = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-      }
+   // Round 4: the forward window's loads are issued BEFORE the re-walk.  The window starts in the hit group itself (j = 8 g + loc, so its
+   // aligned base is 8 g whatever `loc` turns out to be), which the compiler cannot know: the loads used to wait for the re-walk's result --
+   // a second round trip to L2 / HBM at the end of a wave that has nothing to overlap it with (config 2: the flush is the kernel's tail).
+   uint32_t d[2 * NW + 2];
+   {
+      const uint32_t base0 = on ? g * 8u : 0u;
+#pragma unroll
+      for (int q = 0; q < NW + 1; ++q) group_words<false, true>(d[2 * q], d[2 * q + 1], rp, lane, base0 + 8u * q, L);
    }
+   // the hit group = the window's first group; the row may end inside it: only its text bytes are walked (the loader put the NUL / KILL
+   // symbols behind them)
+   const uint2 rw = on ? make_uint2(d[0], d[1]) : make_uint2(0, 0);
+   const uint32_t nv = (on && g * 8u + 8u > L) ? L - g * 8u : 8u;
    uint32_t s;
    {
       F f[8];
@@ -606,10 +608,7 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
    if (__builtin_amdgcn_ballot_w64(cur != 0) != 0) {
       uint32_t o[2 * NW];
       {
-         const uint32_t base = j & ~7u, sh = j & 7u;
-         uint32_t d[2 * NW + 2];
-#pragma unroll
-         for (int q = 0; q < NW + 1; ++q) group_words<false, true>(d[2 * q], d[2 * q + 1], rp, lane, base + 8u * q, L);
+         const uint32_t sh = j & 7u;   // (the aligned base of j is 8 g: `d` holds the window's groups already)
          const uint32_t up = 0u - ((sh >> 2) & 1u);
          uint32_t ee[2 * NW + 1];
 #pragma unroll

@@ -28,6 +28,12 @@ for step in "$@"; do
       python bench.py --config cfg4 --flags-only --no-cpu-baseline --no-extras > $OUT/cfg4_flags.json 2> $OUT/cfg4_flags.err; line $OUT/cfg4_flags.json "cfg4 flags-only spec"
       FXAMD_NO_SPEC=1 python bench.py --config cfg4 --flags-only --no-cpu-baseline --no-extras > $OUT/cfg4_flags_nospec.json 2> $OUT/cfg4_flags_nospec.err; line $OUT/cfg4_flags_nospec.json "cfg4 flags-only nospec" ;;
     bench_*) cfg=${step#bench_}; python bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; line $OUT/bench_$cfg.json "bench $cfg" ;;
+    dist1)   # every RCCL call of the multi-rank path at world size 1 (census, per-rank times, packed gather, gathered-shard parity need world > 1)
+      FXAMD_BENCH_FORCE_DIST=1 python bench.py --config cfg5 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; line $OUT/bench_dist1.json "cfg5 rccl world 1"
+      python3 -c "
+import json
+d=json.loads(open('$OUT/bench_dist1.json').read().strip().splitlines()[-1])
+print('rccl_ranks', d['rccl_ranks'], 'devices', d['devices'], 'distinct', d['devices_distinct'], 'per_rank', d['per_rank_ms_per_step'], 'gather', d['gather'], 'oracle parity', d['parity'].get('oracle'))" ;;
     driver) python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; line $OUT/bench_driver.json "driver protocol" ;;
     k:*) expr=${step#k:}; timeout 2400 python -m pytest tests -m gpu -x -q -k "$expr" > $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; echo "pytest -k '$expr' rc $?"; tail -4 $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log ;;
     shape:*) sh=${step#shape:}; python tools/bench_shapes.py --shape $sh > $OUT/shape_$sh.json 2> $OUT/shape_$sh.err; python3 - $OUT/shape_$sh.json <<'PY'
