@@ -67,6 +67,9 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FX_HALF_WAVES
 #define FX_HALF_WAVES 3   // waves per SIMD the half-row kernel (256-byte rows, spans) is compiled for
 #endif
+#ifndef FX_MATCH_LONG_P3
+#define FX_MATCH_LONG_P3 1   // `.match.` over rows longer than 256 bytes, 8-state tables: whole segments with three lookup buffers (fx_match_row_pipe3)
+#endif
 #ifndef FX_LOAD_AUX
 #define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
 #endif
@@ -1368,6 +1371,66 @@ __device__ __forceinline__ void chain8_fwd_n(const F (&f)[8], uint32_t& state, c
       if ((uint32_t)i < nv) state = fxstep(f[i], state, T);
 }
 
+// A whole tile row (CH chunks of the wave's LDS tile) through the anchored automaton on the 8-state v_perm tables with THREE lookup buffers:
+// every group's lookups are issued two chains ahead of their use (a chain of eight v_perm_b32 is 32 cycles; one chain ahead, the lookups come
+// back late at two or three waves per SIMD).  Rolled trips of three chunks, then the CH % 3 chunks whose lookups are already in flight.
+// The formulation of fx_match_tile (fx_one.hpp; profiles/r03_pipe3_ab.txt: 10 M x 256 B 0.476-0.488 -> 0.415-0.430 ms) for the segment loop
+// of fx_match_fast (round 4: rows longer than 256 bytes).  `na` collects the OR of the row's words.
+template <int CH>
+__device__ __forceinline__ void fx_match_row_pipe3(const uint4* tile, const uint32_t lane, const uint2* __restrict__ tabA, uint32_t& st, uint32_t& na) {
+   uint2 fa[8], fb[8], fc[8];
+   auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c < (uint32_t)CH ? c : (uint32_t)CH - 1u)]; };
+   uint4 w0 = cellc(0), w1 = cellc(1), w2 = cellc(2);
+   lookup8(fa, w0.x, w0.y, tabA);
+   lookup8(fb, w0.z, w0.w, tabA);
+   constexpr uint32_t TRIPS = (uint32_t)CH / 3u, REST = (uint32_t)CH % 3u;
+#pragma unroll 1
+   for (uint32_t c = 0; c < 3u * TRIPS; c += 3u) {
+      na |= w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w | w2.x | w2.y | w2.z | w2.w;
+      lookup8(fc, w1.x, w1.y, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fa, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fa, w1.z, w1.w, tabA);
+      w0 = cellc(c + 3u);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fb, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fb, w2.x, w2.y, tabA);
+      w1 = cellc(c + 4u);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fc, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fc, w2.z, w2.w, tabA);
+      w2 = cellc(c + 5u);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fa, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fa, w0.x, w0.y, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fb, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fb, w0.z, w0.w, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fc, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+   }
+   if constexpr (REST >= 1) {   // chunk 3 TRIPS: its lookups are in fa / fb, its words in w0
+      na |= w0.x | w0.y | w0.z | w0.w;
+      if constexpr (REST == 2) {
+         na |= w1.x | w1.y | w1.z | w1.w;
+         lookup8(fc, w1.x, w1.y, tabA);
+      }
+      chain8_fwd(fa, st, nullptr);
+      if constexpr (REST == 2) lookup8(fa, w1.z, w1.w, tabA);
+      chain8_fwd(fb, st, nullptr);
+      if constexpr (REST == 2) {
+         chain8_fwd(fc, st, nullptr);
+         chain8_fwd(fa, st, nullptr);
+      }
+   }
+}
+
 // 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides (fxrow::match_gate on the row's bytes in the LDS tile)
 __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t* __restrict__ prog, const uint8_t* tb, uint32_t lane, uint32_t L) {
    auto row = [&](uint32_t j) -> uint32_t { return tb[(tile_cell(lane, j >> 4) << 4) + (j & 15u)]; };
@@ -1519,13 +1582,22 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          }
          if (ragged && (!whole || FIXUP)) na |= pad_rows<CH>(tile, lane, Lr);
          // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
+         // LONG: bytes of this segment (the row may end inside its last one, at any byte: the groups are walked over their valid bytes)
+         const uint32_t seg_len = LONG ? (Lr - seg * 256u < 256u ? Lr - seg * 256u : 256u) : 16u * CH;
+         // whole segments of long rows on the 8-state tables (round 4): three lookup buffers, as `.match.` over rows of up to 256 bytes has
+         // had since round 3 (fx_match_tile)
+         bool piped = false;
+         if constexpr (FX_MATCH_LONG_P3 != 0 && LONG && SCH == 0 && CH == 16) {
+            if (seg_len == 256u) {
+               fx_match_row_pipe3<CH>(tile, lane, tabA, st, na);
+               piped = true;
+            }
+         }
          F fa[8], fb[8];
          uint4 wk = tile[tile_cell(lane, 0)], wn = make_uint4(0, 0, 0, 0);
          if (CH >= 2) wn = tile[tile_cell(lane, 1)];
-         lookup8(fa, wk.x, wk.y, tabA);
-         // LONG: bytes of this segment (the row may end inside its last one, at any byte: the groups are walked over their valid bytes)
-         const uint32_t seg_len = LONG ? (Lr - seg * 256u < 256u ? Lr - seg * 256u : 256u) : 16u * CH;
-         const int nch = LONG ? (int)((seg_len + 15u) >> 4) : CH;   // chunks of this segment
+         if (!piped) lookup8(fa, wk.x, wk.y, tabA);
+         const int nch = piped ? 0 : (LONG ? (int)((seg_len + 15u) >> 4) : CH);   // chunks of this segment
 #pragma unroll 1   // rolled on purpose: fully unrolled, the state-independent lookups of ALL chunks get hoisted (512 VGPRs + scratch)
          for (int k = 0; k < nch; ++k) {
             const uint32_t nlo = !LONG ? 8u : (seg_len >= 16u * k + 8u ? 8u : seg_len - 16u * k);   // (>= 1: k < nch)
