@@ -708,11 +708,21 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
    if constexpr (TAIL) {
       // ragged rows (fx_tile.hpp, "Ragged rows, round 4"): whole chunks in a rolled loop, then the chunk the row ends in over its text bytes
       const FxTail& T = *c.tl;
+      // (rows of 96 bytes and more on the 8-state tables: whole trips of three chunks with three lookup buffers first, as the aligned rows)
+      uint32_t k0 = 0;
+      if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= FX_MATCH_P3_MINCH) {
+         if (T.kt >= (uint32_t)FX_MATCH_P3_MINCH) {
+            uint32_t nax = 0;
+            k0 = 3u * (T.kt / 3u);
+            fx_match_trips_pipe3<CH>(tile, lane, tabA, st, nax, T.kt / 3u);
+            if (!DECODED) na |= nax;
+         }
+      }
       F fa[8], fb[8];
-      uint4 wk = tile[tile_cell(lane, 0)];
+      uint4 wk = tile[tile_cell(lane, k0)];   // (k0 <= kt <= CH - 1)
       lookup8(fa, wk.x, wk.y, tabA);
 #pragma unroll 1
-      for (uint32_t k = 0; k < T.kt; ++k) {
+      for (uint32_t k = k0; k < T.kt; ++k) {
          if (!DECODED) na |= wk.x | wk.y | wk.z | wk.w;
          lookup8(fb, wk.z, wk.w, tabA);
          __builtin_amdgcn_sched_barrier(0);

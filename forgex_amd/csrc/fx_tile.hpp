@@ -1431,6 +1431,49 @@ __device__ __forceinline__ void fx_match_row_pipe3(const uint4* tile, const uint
    }
 }
 
+// the same for the first 3 * trips chunks of a row whose chunk count is a run-time value (ragged rows of fx_match_tile): whole trips only,
+// the caller's two-buffer loop takes the chunks behind them (the lookups issued ahead for a next trip are dropped)
+template <int CH>
+__device__ __forceinline__ void fx_match_trips_pipe3(const uint4* tile, const uint32_t lane, const uint2* __restrict__ tabA, uint32_t& st, uint32_t& na,
+                                                     const uint32_t trips) {
+   uint2 fa[8], fb[8], fc[8];
+   auto cellc = [&](const uint32_t c) { return tile[tile_cell(lane, c < (uint32_t)CH ? c : (uint32_t)CH - 1u)]; };
+   uint4 w0 = cellc(0), w1 = cellc(1), w2 = cellc(2);
+   lookup8(fa, w0.x, w0.y, tabA);
+   lookup8(fb, w0.z, w0.w, tabA);
+#pragma unroll 1
+   for (uint32_t c = 0; c < 3u * trips; c += 3u) {
+      na |= w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w | w2.x | w2.y | w2.z | w2.w;
+      lookup8(fc, w1.x, w1.y, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fa, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fa, w1.z, w1.w, tabA);
+      w0 = cellc(c + 3u);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fb, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fb, w2.x, w2.y, tabA);
+      w1 = cellc(c + 4u);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fc, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fc, w2.z, w2.w, tabA);
+      w2 = cellc(c + 5u);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fa, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fa, w0.x, w0.y, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fb, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      lookup8(fb, w0.z, w0.w, tabA);
+      __builtin_amdgcn_sched_barrier(0);
+      chain8_fwd(fc, st, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+   }
+}
+
 // 2 = verdict is TRUE, 0 = verdict is FALSE, 1 = the automaton decides (fxrow::match_gate on the row's bytes in the LDS tile)
 __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t* __restrict__ prog, const uint8_t* tb, uint32_t lane, uint32_t L) {
    auto row = [&](uint32_t j) -> uint32_t { return tb[(tile_cell(lane, j >> 4) << 4) + (j & 15u)]; };
