@@ -615,11 +615,12 @@ def main():
                 line["parity"]["oracle"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
             # every OTHER rank's shard as it arrived on the root: the gathered + unpacked image against the host walker on that shard's
             # rows, regenerated here from (config, start, count) -- the RCCL gather and the unpack are inside what is checked
-            if unpacked is not None and world > 1:
+            # (FXAMD_BENCH_FORCE_DIST=1 at world size 1 checks rank 0's own gathered image the same way: the code path on a 1-GPU box)
+            if unpacked is not None and (world > 1 or use_dist):
                 shard_checks = []
                 try:
                     del rows
-                    for r in range(1, world):
+                    for r in range(1 if world > 1 else 0, world):
                         if args.scaling == "strong" and not args.rows:
                             s_r = fxdist.shard_bounds(n_cfg, r, world)[0]
                         else:

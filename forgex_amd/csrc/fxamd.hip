@@ -18,6 +18,7 @@
 
 #include "../../include/forgex_amd_bench.h"
 #include "fx_multi.hpp"
+#include "fx_tiny.hpp"
 
 #ifndef FX_SINGLE_TU   // the launcher instantiations live in fx_tile_inst.hip (one object per chunk count)
 #define FX_X(CH, M, S)                                                  \
@@ -59,6 +60,7 @@ static void env_load() {
    e.no_byte_dfa = on("FXAMD_NO_BYTE_DFA");
    e.no_a8 = on("FXAMD_NO_A8");
    e.no_spec = on("FXAMD_NO_SPEC");
+   e.no_tiny = on("FXAMD_NO_TINY");
    e.multipass = on("FXAMD_MULTIPASS");
    e.no_cache = on("FXAMD_NO_CACHE");
    e.no_multi = on("FXAMD_NO_MULTI");
@@ -801,7 +803,16 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // The counter groups alternate between calls, and it is a call's FIRST-PASS kernel that zeroes the other group for the call
       // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
-      const bool one_launch = first_pass == FX_FP_OWN && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len)) &&
+      // `.match.` over tiny rows (4 / 8 / 16 / 32 bytes) on the class-level v_perm / nibble tables: a lane takes 64 bytes = several whole
+      // rows (fx_tiny.hpp); a first pass of the multi-pass kind: rows with bytes >= 0x80 are listed for the row-level fix-up
+      bool tiny = first_pass == FX_FP_OWN && is_match && out_mode == 0u && (row_len == 4 || row_len == 8 || row_len == 16 || row_len == 32) &&
+                  (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
+      if (tiny) {   // (a stream that is being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches)
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+         else if (cap != hipStreamCaptureStatusNone) tiny = false;
+      }
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len)) &&
                               !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
@@ -866,6 +877,21 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          else FX_HIP(fast_by<4>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, listp));
          return FXAMD_OK;
       };
+      if (tiny) {
+         const int rc = grow_worklist(sc, n);
+         if (rc != FXAMD_OK) return rc;
+         const FastParams fpt = params_of(h, scheme, false);
+#define FX_TINY(LL)                                                                                                  \
+   FX_HIP(scheme == 0 ? (launch_tiny<LL, 0>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))             \
+                      : (launch_tiny<LL, 2>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st)))
+         if (row_len == 4) FX_TINY(4);
+         else if (row_len == 8) FX_TINY(8);
+         else if (row_len == 16) FX_TINY(16);
+         else FX_TINY(32);
+#undef FX_TINY
+         p->last_path = 17;
+         return list_fixup();   // (gated on the list's count: empty on pure-ASCII batches)
+      }
       if (h.flags & FXP_F_RAW_BYTES) {   // literal search over raw bytes: nothing is deferred
          if (first_pass == FX_FP_OWN) FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          p->last_path = 1 + big;

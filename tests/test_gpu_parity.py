@@ -438,16 +438,16 @@ def test_match_operator_on_tile_kernel(fx):
         if L == 52:
             rows[::3] = np.frombuffer(b"abcdefghijkl" * 4 + b"ab42"[:4], dtype=np.uint8)
         prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
-        assert prog.last_path() in (9, 10, 11, 12, 13, 14), (pat, prog.last_path())   # `.match.` in ONE launch (fx_search_one, MATCH)
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14, 17), (pat, prog.last_path())   # `.match.` in ONE launch (fx_search_one, MATCH; 17: fx_match_tiny, rows of 4 / 8 / 16 / 32 bytes)
         of, _, _ = oracle_lib.batch(1, pat, rows, NT)
         assert np.array_equal(f, of), pat
-    # the 8-byte rows of BASELINE config 1: shorter than one chunk, still on the tile kernel (ragged instantiation)
+    # the 8-byte rows of BASELINE config 1: fx_match_tiny since round 4 (a lane takes eight whole rows)
     import torch
     from forgex_amd import synth
     rows = synth.batch("cfg1", 0, 1000, torch.device("cpu")).numpy()
     prog, f, _, _ = _device_run(fx, synth.PATTERNS["cfg1"].encode(), fx.OP_MATCH, rows, spans=False)
     of, _, _ = oracle_lib.batch(1, synth.PATTERNS["cfg1"].encode(), rows, NT)
-    assert np.array_equal(f, of) and prog.last_path() in (9, 10, 11, 12, 13, 14), prog.last_path()
+    assert np.array_equal(f, of) and prog.last_path() == 17, prog.last_path()
 
 
 def test_match_one_launch_vs_multipass_pipeline(fx, monkeypatch):
@@ -1234,7 +1234,8 @@ def test_one_launch_calls_replay_from_a_hip_graph(fx):
         prog = fx.Program(synth.PATTERNS[cfg], op)
         out = prog.match_device(rows, spans=spans)   # (first call: tables uploaded, scratch allocated, code objects loaded)
         torch.cuda.synchronize()
-        assert prog.last_path() in (9, 10, 11, 12, 13, 14), (cfg, prog.last_path())
+        # (config 1's 8-byte rows run fx_match_tiny -- a first pass with counter words -- outside a capture and the one-launch kernel inside one)
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14) or (cfg == "cfg1" and prog.last_path() == 17), (cfg, prog.last_path())
         assert fx.lib().fxamd_program_reserve(prog._h, n, torch.cuda.current_stream().cuda_stream) == 0
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):   # the capture stream needs its own scratch set: reserve it before capturing
@@ -1518,3 +1519,40 @@ def test_prefix_suffix_literals_round4_on_tile_kernel(fx):
     prog, f, a, b = _device_run(fx, rb"A{1,2}bb", fx.OP_SEARCH, quirk)
     of, oa, ob = oracle_lib.batch(2, rb"A{1,2}bb", quirk, NT)
     assert f.tolist() == of.tolist() == [0, 1, 1] and a.tolist() == oa.tolist() and b.tolist() == ob.tolist()
+
+
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+def test_match_over_tiny_rows(fx, L, monkeypatch):
+    """Round 4: `.match.` over rows of 4 / 8 / 16 / 32 bytes on fx_match_tiny (`last_path` 17: a lane takes a 64-byte span = several whole
+    rows; BASELINE config 1's shape is `\\d{3}-\\d{4}` over 8-byte rows) -- v_perm and nibble tables, programs with a literal / prefix /
+    suffix gate (the `prefix == text => true` quirk of api_internal_m.F90:200-205 included), rows with bytes >= 0x80 (listed for the
+    row-level fix-up), batches whose last lane span is partial -- against the oracle and against the one-launch kernel (FXAMD_NO_TINY)."""
+    import random
+    import torch
+    rng = random.Random(1700 + L)
+    nrng = np.random.default_rng(1700 + L)
+    alpha = np.frombuffer(b"0123456789-ab cd", dtype=np.uint8)
+    n = 64 * 64 * 3 + 37                      # three full trips and a partial lane span
+    rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+    seeds = [b"100-1002", b"ab", b"abc", b"abd", b"aaaa", b"12345678", "é".encode() * 2, "あ".encode(), b"\xff", b"ab-0", b"abcd" * 8, b"-" * 32]
+    for i in range(0, n, 3):
+        sd = seeds[(i // 3) % len(seeds)][:L]
+        buf = (sd + bytes(rng.choice(b"0123456789") for _ in range(L)))[:L] if i % 2 else (sd + b" " * L)[:L]
+        rows[i] = np.frombuffer(buf, dtype=np.uint8)
+    if L == 8:   # config 1's generator
+        from forgex_amd import synth
+        rows[:1000] = synth.batch("cfg1", 0, 1000, torch.device("cpu")).numpy()
+    pats = [rb"\d{3}-\d{4}", rb"\d+", rb"[0-9a-d -]+", rb"ab[cd]", rb"ab(c|d)e?", rb"a{2}[ab]*", rb"\d*-?\d*", rb"abcd", "[é0-9]+".encode(), rb".+", rb"(ab|cd)+\d*"]
+    n17 = 0
+    for pat in pats:
+        monkeypatch.delenv("FXAMD_NO_TINY", raising=False)
+        prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+        n17 += 1 if prog.last_path() == 17 else 0
+        of, _, _ = oracle_lib.batch(1, pat, rows, NT)
+        bad = np.nonzero(f != of)[0]
+        assert bad.size == 0, (pat, L, prog.last_path(), int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
+        monkeypatch.setenv("FXAMD_NO_TINY", "1")
+        prog2, f2, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+        assert prog2.last_path() != 17 and np.array_equal(f2, f), (pat, L, prog2.last_path())
+    monkeypatch.delenv("FXAMD_NO_TINY", raising=False)
+    assert n17 >= 8, n17   # (programs whose automaton fits neither the v_perm nor the nibble tables keep the other kernels)

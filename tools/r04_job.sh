@@ -33,7 +33,7 @@ for step in "$@"; do
       python3 -c "
 import json
 d=json.loads(open('$OUT/bench_dist1.json').read().strip().splitlines()[-1])
-print('rccl_ranks', d['rccl_ranks'], 'devices', d['devices'], 'distinct', d['devices_distinct'], 'per_rank', d['per_rank_ms_per_step'], 'gather', d['gather'], 'oracle parity', d['parity'].get('oracle'))" ;;
+print('gathered_shards', d['parity'].get('gathered_shards'), 'rccl_ranks', d['rccl_ranks'], 'devices', d['devices'], 'distinct', d['devices_distinct'], 'per_rank', d['per_rank_ms_per_step'], 'gather', d['gather'], 'oracle parity', d['parity'].get('oracle'))" ;;
     driver) python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; line $OUT/bench_driver.json "driver protocol" ;;
     k:*) expr=${step#k:}; timeout 2400 python -m pytest tests -m gpu -x -q -k "$expr" > $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; echo "pytest -k '$expr' rc $?"; tail -4 $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log ;;
     shape:*) sh=${step#shape:}; python tools/bench_shapes.py --shape $sh > $OUT/shape_$sh.json 2> $OUT/shape_$sh.err; python3 - $OUT/shape_$sh.json <<'PY'
