@@ -152,6 +152,164 @@ __global__ __launch_bounds__(256) void fx_match_tiny(const uint8_t* __restrict__
    }
 }
 
+// fx_search_tiny: the `.in.` VERDICT (flags only: what the reference's operator returns, forgex.F90:74-160) over the same tiny rows.  Per row
+// the reverse automaton walks the L bytes from the row's last byte (start state: after the trailing NUL) -- a hit anywhere is a start
+// inside the text, which always yields a span (api_internal_m.F90:140-148), so the verdict is TRUE -- then the leading NUL: a start THERE is
+// the leftmost one, and the verdict is the forward walk's (max_match > 2: an accept after at least one more symbol than the NUL), walked
+// here with the anchored tables whenever a lane of the wave has such a start.  Rows with a byte >= 0x80 and rows that end in the overlap
+// state of a bordered prefix literal (FXP_F_OVERLAP_SINK) go to the row-level fix-up.
+template <int L, int SCH>
+__global__ __launch_bounds__(256) void fx_search_tiny(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
+                                                       uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred, uint32_t* __restrict__ clear_next,
+                                                       uint32_t* __restrict__ worklist) {
+   static_assert(L == 4 || L == 8 || L == 16 || L == 32, "tiny rows: a divisor of the 64-byte lane span");
+   static_assert(SCH == 0 || SCH == 2, "class-level v_perm or nibble tables");
+   constexpr int RPL = 64 / L;
+   constexpr bool WIDE = SCH == 2;
+   using F = typename FxF<SCH>::type;
+   if (blockIdx.x == 0 && threadIdx.x == 0) {
+      clear_next[0] = 0u;
+      clear_next[1] = 0u;
+      clear_next[2] = 0u;
+      clear_next[3] = 0u;
+   }
+   __shared__ F tabR_s[256];
+   __shared__ F tabA_s[256];
+   __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 64 * 4];
+   const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
+   {
+      const uint2 e = reinterpret_cast<const uint2*>(prog + (WIDE ? h->off_w16R : h->off_fastR))[threadIdx.x];
+      reinterpret_cast<uint2*>(tabR_s)[threadIdx.x] = e;
+      const uint2 ea = reinterpret_cast<const uint2*>(prog + (WIDE ? h->off_w16A : h->off_fastA))[threadIdx.x];
+      reinterpret_cast<uint2*>(tabA_s)[threadIdx.x] = ea;
+   }
+   __syncthreads();
+   const F* tabR = tabR_s;
+   const F* tabA = tabA_s;
+   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   uint4* tile = tiles + wave * 256;
+   const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+   const int64_t total = n * (int64_t)L;
+   const int64_t n_tiles = (total + 4095) >> 12;
+   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   uint4 stage[4];
+   auto load = [&](const int64_t t) {
+      const int64_t left = total - (t << 12);
+      const uint32_t valid = left <= 0 ? 0u : (left >= 4096 ? 4096u : (uint32_t)left);
+      const uint64_t base = reinterpret_cast<uint64_t>(rows) + ((uint64_t)t << 12);
+      const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                            __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+         const fx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + (uint32_t)q * 1024u, 0, FX_LOAD_AUX);
+         stage[q] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+   };
+   load(wave_global);
+   const F fz = tabR[0];   // the leading NUL
+   for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
+      store_tile<4>(stage, tile, lane);
+      load(t + wave_stride);
+      const int64_t row_first = ((t << 6) + lane) * RPL;
+      uint32_t out[RPL <= 4 ? 1 : RPL / 4] = {0};
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) {
+         const uint32_t off = (uint32_t)(j * L);
+         uint32_t w[L / 4];
+         if constexpr (L == 4) {
+            w[0] = *reinterpret_cast<const uint32_t*>(tb + (tile_cell(lane, off >> 4) << 4) + (off & 15u));
+         } else if constexpr (L == 8) {
+            const uint2 v = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, off >> 4) << 4) + (off & 15u));
+            w[0] = v.x;
+            w[1] = v.y;
+         } else {
+#pragma unroll
+            for (int c = 0; c < L / 16; ++c) {
+               const uint4 v = tile[tile_cell(lane, (off >> 4) + (uint32_t)c)];
+               w[4 * c] = v.x;
+               w[4 * c + 1] = v.y;
+               w[4 * c + 2] = v.z;
+               w[4 * c + 3] = v.w;
+            }
+         }
+         uint32_t na = 0;
+#pragma unroll
+         for (int i = 0; i < L / 4; ++i) na |= w[i];
+         uint32_t st = fp.R_start, mx = 0;
+         if constexpr (L == 4) {
+            F f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = tabR[(w[0] >> (8 * i)) & 0xFFu];
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+               st = fxstep(f[i], st, nullptr);
+               mx = max(mx, st);
+            }
+         } else {
+#pragma unroll
+            for (int g = L / 8 - 1; g >= 0; --g) {
+               F f[8];
+               lookup8(f, w[2 * g], w[2 * g + 1], tabR);
+               mx = max(mx, chain8_back(f, st, nullptr));
+            }
+         }
+         const bool hit = mx >= fp.hit_min;                 // a start inside the text
+         const uint32_t sn = fxstep(fz, st, nullptr);
+         const bool s_nul = sn >= fp.hit_min;               // a start at the leading NUL
+         const int64_t row = row_first + j;
+         const bool row_ok = row < n;
+         bool verdict = hit;
+         if (__builtin_amdgcn_ballot_w64(s_nul) != 0) {   // (wave-uniform; `^`-anchored patterns) forward from the leading NUL
+            uint32_t cur = s_nul ? fp.A_init : 0u;
+            const F fza = tabA[0];
+            cur = fxstep(fza, cur, nullptr);
+            bool acc = false;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+               const F f = tabA[(w[i / 4] >> (8 * (i & 3))) & 0xFFu];
+               cur = fxstep(f, cur, nullptr);
+               acc = acc || cur >= fp.acc_min;
+            }
+            cur = fxstep(fza, cur, nullptr);   // the trailing NUL
+            acc = acc || cur >= fp.acc_min;
+            verdict = s_nul ? acc : hit;
+         }
+         const bool listed = row_ok && ((na & 0x80808080u) != 0u || (fp.inv_on != 0u && sn == fp.inv));
+         const uint64_t em = __builtin_amdgcn_ballot_w64(listed);
+         if (em != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&n_deferred[1], (uint32_t)__builtin_popcountll(em));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (listed) worklist[base + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = (uint32_t)row;
+         }
+         const uint32_t flag = listed ? (uint32_t)FX_NEEDS_GENERAL : (verdict ? 1u : 0u);
+         out[j / 4] |= flag << (8 * (j & 3));
+      }
+      if (row_first + RPL <= n) {
+         uint8_t* dst = flags + row_first;
+         if constexpr (RPL == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)out[0];
+         else if constexpr (RPL == 4) *reinterpret_cast<uint32_t*>(dst) = out[0];
+         else if constexpr (RPL == 8) *reinterpret_cast<uint2*>(dst) = make_uint2(out[0], out[1]);
+         else *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+      } else {
+#pragma unroll
+         for (int j = 0; j < RPL; ++j)
+            if (row_first + j < n) flags[row_first + j] = (uint8_t)(out[j / 4] >> (8 * (j & 3)));
+      }
+   }
+}
+
+template <int L, int SCH>
+hipError_t launch_tiny_search(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* ctr, uint32_t* worklist, hipStream_t st) {
+   uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(ctr) ^ 16u);
+   const int64_t n_tiles = (n * (int64_t)L + 4095) >> 12;
+   int64_t blocks = (n_tiles + 3) / 4;
+   if (blocks > 256 * 8) blocks = 256 * 8;
+   hipLaunchKernelGGL((fx_search_tiny<L, SCH>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, ctr, clear_next, worklist);
+   return hipGetLastError();
+}
+
 template <int L, int SCH>
 hipError_t launch_tiny(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, uint32_t* ctr, uint32_t* worklist, hipStream_t st) {
    uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(ctr) ^ 16u);   // the other parity's group of four words

@@ -805,8 +805,9 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
       // `.match.` over tiny rows (4 / 8 / 16 / 32 bytes) on the class-level v_perm / nibble tables: a lane takes 64 bytes = several whole
       // rows (fx_tiny.hpp); a first pass of the multi-pass kind: rows with bytes >= 0x80 are listed for the row-level fix-up
-      bool tiny = first_pass == FX_FP_OWN && is_match && out_mode == 0u && (row_len == 4 || row_len == 8 || row_len == 16 || row_len == 32) &&
-                  (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
+      // ... and the `.in.` VERDICT (no spans asked for) over the same rows: fx_search_tiny
+      bool tiny = first_pass == FX_FP_OWN && (is_match || (h.mode == FXP_MODE_SEARCH_ENGINE && d_from == nullptr && !(h.flags & FXP_F_RAW_BYTES))) && out_mode == 0u &&
+                  (row_len == 4 || row_len == 8 || row_len == 16 || row_len == 32) && (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
       if (tiny) {   // (a stream that is being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches)
          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
@@ -881,9 +882,11 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          const int rc = grow_worklist(sc, n);
          if (rc != FXAMD_OK) return rc;
          const FastParams fpt = params_of(h, scheme, false);
-#define FX_TINY(LL)                                                                                                  \
-   FX_HIP(scheme == 0 ? (launch_tiny<LL, 0>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))             \
-                      : (launch_tiny<LL, 2>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st)))
+#define FX_TINY(LL)                                                                                                                    \
+   FX_HIP(is_match ? (scheme == 0 ? (launch_tiny<LL, 0>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))                     \
+                                  : (launch_tiny<LL, 2>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st)))                    \
+                   : (scheme == 0 ? (launch_tiny_search<LL, 0>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))              \
+                                  : (launch_tiny_search<LL, 2>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))))
          if (row_len == 4) FX_TINY(4);
          else if (row_len == 8) FX_TINY(8);
          else if (row_len == 16) FX_TINY(16);

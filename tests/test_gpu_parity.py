@@ -1556,3 +1556,40 @@ def test_match_over_tiny_rows(fx, L, monkeypatch):
         assert prog2.last_path() != 17 and np.array_equal(f2, f), (pat, L, prog2.last_path())
     monkeypatch.delenv("FXAMD_NO_TINY", raising=False)
     assert n17 >= 8, n17   # (programs whose automaton fits neither the v_perm nor the nibble tables keep the other kernels)
+
+
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+def test_in_verdict_over_tiny_rows(fx, L, monkeypatch):
+    """Round 4: the `.in.` VERDICT (flags only -- what the reference's operator returns, forgex.F90:74-160) over rows of 4 / 8 / 16 / 32 bytes
+    on fx_search_tiny (`last_path` 17): per row the reverse automaton from the row's last byte, a hit inside the text = TRUE; a start at the
+    leading NUL is the leftmost one and takes the forward walk's answer (`^`-anchored patterns: max_match > 2, api_internal_m.F90:140-148);
+    rows with bytes >= 0x80 and overlap rows of bordered prefix literals go to the row-level fix-up.  Against the oracle and the one-launch
+    kernel (FXAMD_NO_TINY); the span entry keeps the other kernels."""
+    import random
+    rng = random.Random(1800 + L)
+    nrng = np.random.default_rng(1800 + L)
+    alpha = np.frombuffer(b"0123456789-ab cd\nxa", dtype=np.uint8)
+    n = 64 * 64 * 2 + 53
+    rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+    seeds = [b"100-1002", b"ab", b"aab", b"aaab", b"--a", b"---a", b"12", "é".encode() * 2, "あ1".encode(), b"\xffa", b"ab\n", b"\nab", b"x" * 32]
+    for i in range(0, n, 3):
+        sd = seeds[(i // 3) % len(seeds)][:L]
+        off = rng.randint(0, L - len(sd))
+        rows[i, off:off + len(sd)] = np.frombuffer(sd, dtype=np.uint8)
+    pats = [rb"\d{3}-\d{4}", rb"[a-d]+\d+", rb"^\d+", rb"\d+$", rb"^ab", rb"^", rb"$", rb"^$", rb"aa[bc]", rb"--[a-z]+", rb"a b|cd", rb"x*", rb"[^0-9]+x", "é+".encode(), rb"ab$"]
+    n17 = 0
+    for pat in pats:
+        monkeypatch.delenv("FXAMD_NO_TINY", raising=False)
+        prog, f, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+        n17 += 1 if prog.last_path() == 17 else 0
+        of, _, _ = oracle_lib.batch(0, pat, rows, NT)
+        bad = np.nonzero(f != of)[0]
+        assert bad.size == 0, (pat, L, prog.last_path(), int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
+        # the span entry (regex) on the same rows: other kernels, same verdicts
+        prog_s, fs, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=True)
+        assert prog_s.last_path() != 17 and np.array_equal(fs, of), (pat, L, prog_s.last_path())
+        monkeypatch.setenv("FXAMD_NO_TINY", "1")
+        prog2, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+        assert prog2.last_path() != 17 and np.array_equal(f2, f), (pat, L, prog2.last_path())
+    monkeypatch.delenv("FXAMD_NO_TINY", raising=False)
+    assert n17 >= 10, n17

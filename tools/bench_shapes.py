@@ -24,6 +24,7 @@ SHAPES = {
     "match_cfg1x":  ("`.match.` `\\d{3}-\\d{4}` (config 1's pattern, nibble tables) over 64M x 8 B rows of config 1's generator", "match", [r"\d{3}-\d{4}"], "cfg1", None, 64_000_000, False, False),
     "match_cfg5":   ("`.match.` `[a-z ]+\\d*[a-z ]*` over config 5's shard (12.5 M x 128 B, 8-state tables)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg5", None, 12_500_000, False, False),
     "match_utf8":   ("`.match.` `[α-ωぁ-ん ]+` over config-4 rows (byte-level tables)", "match", ["[α-ωぁ-ん ]+"], "cfg4", None, 1 << 20, False, False),
+    "in_flags_cfg1x": ("`.in.` verdict (flags only) `\\d{3}-\\d{4}` over 64M x 8 B rows of config 1's generator (fx_search_tiny)", "search", [r"\d{3}-\d{4}"], "cfg1", None, 64_000_000, False, False),
     "match_ragged_200": ("`.match.` over config-3 bytes viewed as rows of 200 B (ragged rows of the one-launch kernel)", "match", [r"[a-z ]+\d*[a-z ]*[a-z 0-9]*"], "cfg3", 200, 12_800_000, False, False),
     "match_long_1024": ("`.match.` `[a-z ]+\\d*[a-z ]*[a-z 0-9]*` over config-3 bytes viewed as 2.5M x 1024 B rows (segment loop of fx_match_fast)", "match", [r"[a-z ]+\d*[a-z ]*[a-z 0-9]*"], "cfg3", 1024, 2_500_000, False, False),
     "long_1024":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as 2.5M x 1024 B rows", "search", [r"[a-z]+\d+"], "cfg3", 1024, 2_500_000, False, True),
