@@ -807,7 +807,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // rows (fx_tiny.hpp); a first pass of the multi-pass kind: rows with bytes >= 0x80 are listed for the row-level fix-up
       // ... and the `.in.` VERDICT (no spans asked for) over the same rows: fx_search_tiny
       bool tiny = first_pass == FX_FP_OWN && (is_match || (h.mode == FXP_MODE_SEARCH_ENGINE && d_from == nullptr && !(h.flags & FXP_F_RAW_BYTES))) && out_mode == 0u &&
-                  (row_len == 4 || row_len == 8 || row_len == 16 || row_len == 32) && (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
+                  row_len >= 2 && row_len <= 32 && (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
       if (tiny) {   // (a stream that is being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches)
          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
@@ -887,10 +887,16 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
                                   : (launch_tiny<LL, 2>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st)))                    \
                    : (scheme == 0 ? (launch_tiny_search<LL, 0>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))              \
                                   : (launch_tiny_search<LL, 2>(d_rows, n, d_blob, fpt, d_flags, ctr, sc->d_worklist, st))))
-         if (row_len == 4) FX_TINY(4);
-         else if (row_len == 8) FX_TINY(8);
-         else if (row_len == 16) FX_TINY(16);
-         else FX_TINY(32);
+         switch (row_len) {
+#define FX_TINY_CASE(LL) \
+   case LL: FX_TINY(LL); break;
+            FX_TINY_CASE(2) FX_TINY_CASE(3) FX_TINY_CASE(4) FX_TINY_CASE(5) FX_TINY_CASE(6) FX_TINY_CASE(7) FX_TINY_CASE(8) FX_TINY_CASE(9) FX_TINY_CASE(10)
+            FX_TINY_CASE(11) FX_TINY_CASE(12) FX_TINY_CASE(13) FX_TINY_CASE(14) FX_TINY_CASE(15) FX_TINY_CASE(16) FX_TINY_CASE(17) FX_TINY_CASE(18)
+            FX_TINY_CASE(19) FX_TINY_CASE(20) FX_TINY_CASE(21) FX_TINY_CASE(22) FX_TINY_CASE(23) FX_TINY_CASE(24) FX_TINY_CASE(25) FX_TINY_CASE(26)
+            FX_TINY_CASE(27) FX_TINY_CASE(28) FX_TINY_CASE(29) FX_TINY_CASE(30) FX_TINY_CASE(31) FX_TINY_CASE(32)
+#undef FX_TINY_CASE
+            default: return FXAMD_E_ARG;
+         }
 #undef FX_TINY
          p->last_path = 17;
          return list_fixup();   // (gated on the list's count: empty on pure-ASCII batches)

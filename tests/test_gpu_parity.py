@@ -1521,10 +1521,13 @@ def test_prefix_suffix_literals_round4_on_tile_kernel(fx):
     assert f.tolist() == of.tolist() == [0, 1, 1] and a.tolist() == oa.tolist() and b.tolist() == ob.tolist()
 
 
-@pytest.mark.parametrize("L", [4, 8, 16, 32])
+TINY_LENGTHS = [2, 3, 4, 5, 7, 8, 10, 12, 13, 16, 20, 21, 24, 27, 31, 32]
+
+
+@pytest.mark.parametrize("L", TINY_LENGTHS)
 def test_match_over_tiny_rows(fx, L, monkeypatch):
-    """Round 4: `.match.` over rows of 4 / 8 / 16 / 32 bytes on fx_match_tiny (`last_path` 17: a lane takes a 64-byte span = several whole
-    rows; BASELINE config 1's shape is `\\d{3}-\\d{4}` over 8-byte rows) -- v_perm and nibble tables, programs with a literal / prefix /
+    """Round 4: `.match.` over rows of 2 to 32 bytes on fx_match_tiny (`last_path` 17: a lane takes a span of 64 / L whole rows -- 64 bytes
+    for the divisors of 64, ragged spans for the other lengths; BASELINE config 1's shape is `\\d{3}-\\d{4}` over 8-byte rows) -- v_perm and nibble tables, programs with a literal / prefix /
     suffix gate (the `prefix == text => true` quirk of api_internal_m.F90:200-205 included), rows with bytes >= 0x80 (listed for the
     row-level fix-up), batches whose last lane span is partial -- against the oracle and against the one-launch kernel (FXAMD_NO_TINY)."""
     import random
@@ -1558,9 +1561,9 @@ def test_match_over_tiny_rows(fx, L, monkeypatch):
     assert n17 >= 8, n17   # (programs whose automaton fits neither the v_perm nor the nibble tables keep the other kernels)
 
 
-@pytest.mark.parametrize("L", [4, 8, 16, 32])
+@pytest.mark.parametrize("L", TINY_LENGTHS)
 def test_in_verdict_over_tiny_rows(fx, L, monkeypatch):
-    """Round 4: the `.in.` VERDICT (flags only -- what the reference's operator returns, forgex.F90:74-160) over rows of 4 / 8 / 16 / 32 bytes
+    """Round 4: the `.in.` VERDICT (flags only -- what the reference's operator returns, forgex.F90:74-160) over rows of 2 to 32 bytes
     on fx_search_tiny (`last_path` 17): per row the reverse automaton from the row's last byte, a hit inside the text = TRUE; a start at the
     leading NUL is the leftmost one and takes the forward walk's answer (`^`-anchored patterns: max_match > 2, api_internal_m.F90:140-148);
     rows with bytes >= 0x80 and overlap rows of bordered prefix literals go to the row-level fix-up.  Against the oracle and the one-launch
@@ -1593,3 +1596,21 @@ def test_in_verdict_over_tiny_rows(fx, L, monkeypatch):
         assert prog2.last_path() != 17 and np.array_equal(f2, f), (pat, L, prog2.last_path())
     monkeypatch.delenv("FXAMD_NO_TINY", raising=False)
     assert n17 >= 10, n17
+
+
+def test_tiny_rows_every_length_and_batch_end(fx):
+    """Every row length 2..32 on the tiny-row kernels with batch sizes that end inside a lane's span, inside a tile, on a tile boundary and
+    one row behind it (the ragged span loader's byte extent), `.match.` and the `.in.` verdict against the oracle."""
+    nrng = np.random.default_rng(1900)
+    alpha = np.frombuffer(b"0123456789-ab", dtype=np.uint8)
+    for L in range(2, 33):
+        rpl = 64 // L
+        for n in (1, rpl - 1 if rpl > 1 else 2, rpl + 1, 64 * rpl - 1, 64 * rpl, 64 * rpl + 1, 64 * rpl * 9 + rpl // 2 + 1):
+            rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+            rows[::5, :2] = np.frombuffer(b"ab", dtype=np.uint8)
+            for op, kind, pat in ((fx.OP_MATCH, 1, rb"ab[0-9-]*"), (fx.OP_SEARCH, 0, rb"^ab\d|\d-\d"), (fx.OP_SEARCH, 0, rb"b\d+$")):
+                prog, f, _, _ = _device_run(fx, pat, op, rows, spans=False)
+                assert prog.last_path() == 17, (L, n, pat, prog.last_path())
+                of, _, _ = oracle_lib.batch(kind, pat, rows, NT)
+                bad = np.nonzero(f != of)[0]
+                assert bad.size == 0, (pat, L, n, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())

@@ -54,6 +54,10 @@ SHAPES = {
     "ragged_132":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 132 B", "search", [r"[a-z]+\d+"], "cfg3", 132, 19_393_939, False, True),
     "ragged_200":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 200 B", "search", [r"[a-z]+\d+"], "cfg3", 200, 12_800_000, False, True),
     "ragged_20":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 20 B", "search", [r"[a-z]+\d+"], "cfg3", 20, 64_000_000, False, True),
+    # short rows of a length that does not divide 64 (character(10), (12), (20), (24)): the tiny-row kernels' ragged spans
+    "match_rows_12": ("`.match.` `[a-z ]+\\d*[a-z ]*` over config-3 bytes viewed as 100M rows of 12 B (fx_match_tiny, ragged spans)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg3", 12, 100_000_000, False, False),
+    "in_flags_rows_20": ("`.in.` verdict `[a-z]+\\d+` over config-3 bytes viewed as 64M rows of 20 B (fx_search_tiny, ragged spans)", "search", [r"[a-z]+\d+"], "cfg3", 20, 64_000_000, False, False),
+    "in_flags_rows_10": ("`.in.` verdict `[a-z]+\\d+` over config-3 bytes viewed as 128M rows of 10 B", "search", [r"[a-z]+\d+"], "cfg3", 10, 128_000_000, False, False),
     "ragged_255_flags": ("the same at 255 B, flags only", "search", [r"[a-z]+\d+"], "cfg3", 255, 10_000_000, False, False),
     # config 4's pattern and text at ragged row lengths (byte-level tables on ragged rows: round 4)
     "utf8_100":     ("config 4's pattern and text in rows of 100 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 100), 2 << 20, False, True),
