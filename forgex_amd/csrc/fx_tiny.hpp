@@ -33,9 +33,9 @@ __device__ __forceinline__ void fx_tiny_load(uint4 (&stage)[4], const uint8_t* _
    using T = FxTiny<L>;
    const int64_t off0 = t * (int64_t)(64 * T::LS);
    const int64_t left = total - off0;
-   // (+3: a dword is dropped whole when it straddles the extent, and with spans that are not a multiple of 4 bytes the batch's last
-   //  dword does -- at most 3 bytes behind the batch's last row are read, never used: as in load_tile)
-   const uint32_t valid = left <= 0 ? 0u : (uint32_t)(left >= 64 * T::LS ? 64 * T::LS : left) + (T::LS == 64 ? 0u : 3u);
+   // (+3: a dword is dropped whole when it straddles the extent, and with rows that are not a multiple of 4 bytes the batch's last
+   //  dword may -- at most 3 bytes behind the batch's last row are read, never used: as in load_tile)
+   const uint32_t valid = left <= 0 ? 0u : (uint32_t)(left >= 64 * T::LS ? 64 * T::LS : left) + (L % 4 == 0 ? 0u : 3u);
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)off0;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
@@ -121,7 +121,7 @@ __device__ __forceinline__ void fx_tiny_list(const bool listed, const int64_t ro
 template <int L, int SCH, int J>
 struct FxTinyMatchRows {
    template <class F, class Gate>
-   static __device__ __forceinline__ void run(const uint32_t (&d)[17], const F* __restrict__ tabA, const FastParams& fp, const uint32_t (&fm)[4], const bool gated,
+   static __device__ __forceinline__ void run(const uint32_t (&d)[17], const F* __restrict__ tabA, const FastParams& fp, const uint32_t fm0, const uint32_t fm1, const uint32_t fm2, const uint32_t fm3, const bool gated,
                                               const Gate& gate_of, const int64_t row_first, const int64_t n, const uint32_t lane, uint32_t* n_deferred,
                                               uint32_t* worklist, uint32_t (&out)[(FxTiny<L>::RPL + 3) / 4]) {
       if constexpr (J < FxTiny<L>::RPL) {
@@ -136,9 +136,9 @@ struct FxTinyMatchRows {
          for (int i = 0; i < L; ++i) st = fxstep(f[i], st, nullptr);
          uint32_t fin;
          if (SCH == 2) {
-            const uint32_t fw = (st & 8u) ? ((st & 4u) ? fm[3] : fm[2]) : ((st & 4u) ? fm[1] : fm[0]);
+            const uint32_t fw = (st & 8u) ? ((st & 4u) ? fm3 : fm2) : ((st & 4u) ? fm1 : fm0);
             fin = (fw >> ((st & 3u) * 8u)) & 3u;
-         } else fin = __builtin_amdgcn_perm(fm[1], fm[0], st) & 1u;
+         } else fin = __builtin_amdgcn_perm(fm1, fm0, st) & 1u;
          uint32_t flag = (st != 0u && fin == 1u) ? 1u : 0u;
          if (gated) {   // (wave-uniform: the program has a literal / prefix / suffix gate)
             const uint32_t gate = gate_of(J * L);
@@ -149,7 +149,7 @@ struct FxTinyMatchRows {
          fx_tiny_list(listed, row, lane, n_deferred, worklist);
          if (listed) flag = FX_NEEDS_GENERAL;
          out[J / 4] |= flag << (8 * (J & 3));
-         FxTinyMatchRows<L, SCH, J + 1>::run(d, tabA, fp, fm, gated, gate_of, row_first, n, lane, n_deferred, worklist, out);
+         FxTinyMatchRows<L, SCH, J + 1>::run(d, tabA, fp, fm0, fm1, fm2, fm3, gated, gate_of, row_first, n, lane, n_deferred, worklist, out);
       }
    }
 };
@@ -183,15 +183,15 @@ __global__ __launch_bounds__(256) void fx_match_tiny(const uint8_t* __restrict__
    const int64_t n_tiles = (total + 64 * T::LS - 1) / (64 * T::LS);
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    const bool gated = (h->len_prefix | h->len_suffix | h->len_all) != 0u;
-   uint32_t fm[4] = {0, 0, 0, 0};   // FINAL verdict of a state: byte q of {fm[1], fm[0]} (v_perm) / of fm[0..3] (nibble tables)
+   uint32_t fm0 = 0, fm1 = 0, fm2 = 0, fm3 = 0;   // FINAL verdict of a state: byte q of {fm1, fm0} (v_perm) / of fm0..fm3 (nibble tables)
    if (SCH == 2) {
-      fm[0] = h->w16_finalM[0];
-      fm[1] = h->w16_finalM[1];
-      fm[2] = h->w16_finalM[2];
-      fm[3] = h->w16_finalM[3];
+      fm0 = h->w16_finalM[0];
+      fm1 = h->w16_finalM[1];
+      fm2 = h->w16_finalM[2];
+      fm3 = h->w16_finalM[3];
    } else {
-      fm[0] = h->fast_finalM[0];
-      fm[1] = h->fast_finalM[1];
+      fm0 = h->fast_finalM[0];
+      fm1 = h->fast_finalM[1];
    }
    uint4 stage[4];
    fx_tiny_load<L>(stage, rows, total, wave_global, lane);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void fx_match_tiny(const uint8_t* __restrict__
          auto rowb = [&](uint32_t k) -> uint32_t { return tb[(tile_cell(lane, ((uint32_t)off + k) >> 4) << 4) + (((uint32_t)off + k) & 15u)]; };
          return fxrow::match_gate(h, prog, rowb, (uint32_t)L);
       };
-      FxTinyMatchRows<L, SCH, 0>::run(d, tabA, fp, fm, gated, gate_of, row_first, n, lane, n_deferred, worklist, out);
+      FxTinyMatchRows<L, SCH, 0>::run(d, tabA, fp, fm0, fm1, fm2, fm3, gated, gate_of, row_first, n, lane, n_deferred, worklist, out);
       fx_tiny_emit<L>(flags, row_first, n, out);
    }
 }

@@ -803,7 +803,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // The counter groups alternate between calls, and it is a call's FIRST-PASS kernel that zeroes the other group for the call
       // after it: so the group flips only when such a kernel runs -- not for the one-launch kernel, which uses no counters (a
       // handle that alternates between the two pipelines would otherwise meet the stale counts of its last multi-pass call).
-      // `.match.` over tiny rows (4 / 8 / 16 / 32 bytes) on the class-level v_perm / nibble tables: a lane takes 64 bytes = several whole
+      // `.match.` over tiny rows (2 to 32 bytes) on the class-level v_perm / nibble tables: a lane takes a span of 64 / L whole
       // rows (fx_tiny.hpp); a first pass of the multi-pass kind: rows with bytes >= 0x80 are listed for the row-level fix-up
       // ... and the `.in.` VERDICT (no spans asked for) over the same rows: fx_search_tiny
       bool tiny = first_pass == FX_FP_OWN && (is_match || (h.mode == FXP_MODE_SEARCH_ENGINE && d_from == nullptr && !(h.flags & FXP_F_RAW_BYTES))) && out_mode == 0u &&

@@ -179,8 +179,8 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * One-launch kernel fx_search_one: 9 = class-level tables + in-LDS decode, 10 = per-tile selection of class-level / byte-level tables,
  * 11 = byte-level tables on every tile (12 / 13 / 14: the same with the general row procedure for queued rows).
  * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
- * one-launch kernel over the tiles that pass left.  17 = `.match.` and the `.in.` verdict (no spans) over rows of 4 / 8 / 16 / 32 bytes:
- * fx_match_tiny / fx_search_tiny (a lane takes a 64-byte span = several whole rows) + the gated row-level fix-up of rows with bytes >= 0x80
+ * one-launch kernel over the tiles that pass left.  17 = `.match.` and the `.in.` verdict (no spans) over rows of 2 to 32 bytes:
+ * fx_match_tiny / fx_search_tiny (a lane takes a span of 64 / L whole rows) + the gated row-level fix-up of rows with bytes >= 0x80
  * (a stream under hipGraph capture keeps path 9-14).
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
  * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_NO_TINY, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL;
