@@ -1614,3 +1614,40 @@ def test_tiny_rows_every_length_and_batch_end(fx):
                 of, _, _ = oracle_lib.batch(kind, pat, rows, NT)
                 bad = np.nonzero(f != of)[0]
                 assert bad.size == 0, (pat, L, n, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
+
+
+def test_tiny_rows_fuzz_patterns(fx):
+    """Random patterns (the generator that pinned the oracle to the real reference) over rows of every length 2..32, ASCII rows and rows mixed
+    with valid and broken UTF-8 (listed for the row-level fix-up), `.match.` and the `.in.` verdict against the oracle; batch sizes around
+    the lane-span and tile boundaries.  (FX_FUZZ_SEED / FX_FUZZ_PATTERNS: longer soak runs.)"""
+    import random
+    import fuzz_diff
+    seed = int(os.environ.get("FX_FUZZ_SEED", "0"))
+    want = int(os.environ.get("FX_FUZZ_PATTERNS", "60"))
+    rng = random.Random(2100 + 1000 * seed)
+    nrng = np.random.default_rng(2100 + seed)
+    ascii_alpha = np.frombuffer(b"abcxyz019 .-\n\tAZ_@", dtype=np.uint8)
+    pieces = [b"a", b"b", b"c", b"x", b"0", b"9", b" ", b".", "あ".encode(), "α".encode(), "é".encode(), b"\x80", b"\xe3\x81", b"\xff", b"-", b"\n"]
+    n17 = done = tried = 0
+    while done < want and tried < 20 * want:
+        tried += 1
+        pat = fuzz_diff.gen_pattern(rng).encode()
+        if fx.Program(pat, fx.OP_SEARCH).status != 0:
+            continue
+        done += 1
+        L = rng.randint(2, 32)
+        rpl = 64 // L
+        n = rng.choice([1, rpl, 64 * rpl - 1, 64 * rpl + 1, 64 * rpl * 4 + rng.randint(0, 64 * rpl), 64 * rpl * 5])
+        rows = ascii_alpha[nrng.integers(0, len(ascii_alpha), size=(n, L))].copy()
+        for i in range(0, n, 7):   # every seventh row: UTF-8 pieces, whole and broken
+            buf = b""
+            while len(buf) < L:
+                buf += rng.choice(pieces)
+            rows[i] = np.frombuffer(buf[:L], dtype=np.uint8)
+        for op, kind in ((fx.OP_MATCH, 1), (fx.OP_SEARCH, 0)):
+            prog, f, _, _ = _device_run(fx, pat, op, rows, spans=False)
+            n17 += 1 if prog.last_path() == 17 else 0
+            of, _, _ = oracle_lib.batch(kind, pat, rows, NT)
+            bad = np.nonzero(f != of)[0]
+            assert bad.size == 0, (pat, L, n, op, prog.last_path(), int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
+    assert done >= want and n17 >= want, (done, n17)   # (programs without class-level v_perm / nibble tables keep the other kernels)
