@@ -1416,28 +1416,56 @@ int fxamd_unpack_results(const uint8_t* d_packed, int64_t n, int64_t row_len, in
 // Side streams for the per-pattern follow-up passes of a shared first pass: each is a small, latency-bound launch (a gated pass over
 // a pattern's exception rows), so the patterns' follow-ups run side by side -- forked from the caller's stream by an event, joined back
 // by one event per pattern -- instead of one after the other (6 UTF-8 patterns on config 4's rows: 6 x ~40 us in a row otherwise).
+// One set per (device, caller stream) -- ADVICE r03: with one set per device, callers on different streams were serialised on the host
+// (one mutex around every fork / join) and coupled on the device (B's follow-ups queued behind A's on the same side stream).  A set's
+// mutex is held while its fork / join is enqueued, so only callers that share a caller stream meet on it; the pool keeps at most
+// FX_SIDE_SETS sets per process and re-keys the least recently used free one after that (its side streams may still hold the old
+// caller's work: the new one's follow-ups queue behind it -- an ordering that is only stricter).
 struct SideStreams {
    int device = -1;
+   hipStream_t caller = nullptr;
+   uint64_t stamp = 0;
+   std::mutex mu;   // held while a fork / join is enqueued (the events are the set's)
    hipEvent_t fork = nullptr;
    std::vector<hipStream_t> streams;
    std::vector<hipEvent_t> joined;
 };
-static std::mutex g_side_mu;   // held while a fork / join is enqueued (the events are shared)
+constexpr size_t FX_SIDE_SETS = 16;
+static std::mutex g_side_mu;   // the pool's list only
 static std::vector<SideStreams*> g_side;
-static SideStreams* side_streams(int dev, size_t k) {   // (g_side_mu held)
+static uint64_t g_side_clock = 0;
+// the set of (dev, caller), locked (`lock` owns its mutex on success), with at least k side streams
+static SideStreams* side_streams(int dev, hipStream_t caller, size_t k, std::unique_lock<std::mutex>& lock) {
    SideStreams* ss = nullptr;
-   for (SideStreams* x : g_side)
-      if (x->device == dev) ss = x;
-   if (!ss) {
-      ss = new (std::nothrow) SideStreams();
-      if (!ss) return nullptr;
-      ss->device = dev;
-      if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) {
-         delete ss;
-         return nullptr;
+   {
+      std::lock_guard<std::mutex> g(g_side_mu);
+      for (SideStreams* x : g_side)
+         if (x->device == dev && x->caller == caller) ss = x;
+      if (!ss && g_side.size() >= FX_SIDE_SETS) {   // re-key the least recently used set of this device that nobody is using
+         for (SideStreams* x : g_side)
+            if (x->device == dev && (!ss || x->stamp < ss->stamp)) ss = x;
+         if (ss) {
+            std::unique_lock<std::mutex> l(ss->mu, std::try_to_lock);
+            if (!l.owns_lock()) return nullptr;   // (in use right now: this call keeps its follow-ups on the caller's stream)
+            ss->caller = caller;
+            ss->stamp = ++g_side_clock;
+            lock = std::move(l);
+         }
       }
-      g_side.push_back(ss);
+      if (!ss) {
+         ss = new (std::nothrow) SideStreams();
+         if (!ss) return nullptr;
+         ss->device = dev;
+         ss->caller = caller;
+         if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) {
+            delete ss;
+            return nullptr;
+         }
+         g_side.push_back(ss);
+      }
+      ss->stamp = ++g_side_clock;
    }
+   if (!lock.owns_lock()) lock = std::unique_lock<std::mutex>(ss->mu);
    while (ss->streams.size() < k) {
       hipStream_t s = nullptr;
       hipEvent_t e = nullptr;
@@ -1591,7 +1619,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       // use the counter words and the worklist PREPARE chose (carried in `shs`, not recomputed).
       // (side by side on side streams when the batch may hold rows for them -- some pattern scans UTF-8 tiles in the shared pass or
       //  defers them; the scratch -- counter words, worklist -- is the one PREPARE chose on the caller's stream)
-      std::unique_lock<std::mutex> side_lock(g_side_mu, std::defer_lock);
+      std::unique_lock<std::mutex> side_lock;
       SideStreams* ss = nullptr;
       // (a caller's stream that is being CAPTURED into a hipGraph keeps its follow-ups on itself: the shared side streams would join the
       //  capture, and another thread that uses them meanwhile would meet a capture error -- ADVICE r03)
@@ -1601,12 +1629,11 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          cap = hipStreamCaptureStatusNone;
       }
       if (!fx_env().multi_serial && cap == hipStreamCaptureStatusNone) {
-         side_lock.lock();
-         ss = side_streams(dev, g1 - g0);
+         ss = side_streams(dev, st, g1 - g0, side_lock);
          if (ss && hipEventRecord(ss->fork, st) != hipSuccess) ss = nullptr;
          if (!ss) {
             (void)hipGetLastError();
-            side_lock.unlock();
+            if (side_lock.owns_lock()) side_lock.unlock();
          }
       }
       for (size_t k = g0; k < g1; ++k) {

@@ -1651,3 +1651,51 @@ def test_tiny_rows_fuzz_patterns(fx):
             bad = np.nonzero(f != of)[0]
             assert bad.size == 0, (pat, L, n, op, prog.last_path(), int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
     assert done >= want and n17 >= want, (done, n17)   # (programs without class-level v_perm / nibble tables keep the other kernels)
+
+
+def test_many_patterns_from_several_streams_and_threads(fx):
+    """the side streams of the per-pattern follow-ups are kept per (device, caller stream).  Four host threads, each on its own
+    stream, run the same group of UTF-8 patterns (the same cached handles) over their own batches with broken rows -- every pattern has
+    follow-up work -- at the same time and repeatedly; results equal the single-threaded ones."""
+    import threading
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    pats = [synth.PATTERNS["cfg4"], "[ぁ-ん]+", "[α-ω][ぁ-ん]", "ん[α-ω]+", "[a-z]+"]
+    progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+    g = torch.Generator().manual_seed(78)
+    batches = []
+    for i in range(4):
+        n = 20000 - 64 * i
+        rows = synth.batch("cfg4", 50000 * i, n, dev)[:, :128].contiguous()
+        rows[:, 125:] = 32
+        sel = (torch.rand(n, generator=g) < 0.05).to(dev)
+        pos = torch.randint(0, 128, (n,), generator=g).to(dev)
+        idx = torch.arange(n, device=dev)[sel]
+        rows[idx, pos[sel]] = 0xFF
+        batches.append(rows)
+    want = []
+    for rows in batches:
+        f, a, b = fx.match_many(progs, rows)
+        torch.cuda.synchronize()
+        want.append((f.clone(), a.clone(), b.clone()))
+    assert sum(1 for p in progs if p.last_path() == 15) >= 4
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    f, a, b = fx.match_many(progs, batches[i])
+                    st.synchronize()
+                    if not (torch.equal(f, want[i][0]) and torch.equal(a, want[i][1]) and torch.equal(b, want[i][2])):
+                        errs.append(i)
+        except Exception as e:   # noqa
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
