@@ -26,7 +26,7 @@ struct FxEnv {
    bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
       host_register;
    int64_t slice_rows;                                      // rows per enqueue (a multiple of 64)
-   int one_grid, one_round_mb, one_blocks, half_rounds;     // launch-grid experiments (0 = the built-in rule)
+   int one_grid, one_round_mb, one_blocks, half_rounds, half_sch;     // launch-grid experiments (0 = the built-in rule)
 };
 const FxEnv& fx_env();   // (fxamd.hip)
 
@@ -821,7 +821,8 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
    constexpr int COLS = fx_tile_cols<CH, SPANS, LONG>();   // chunk columns per row in LDS: the row's chunks [+ the end-of-row column]
-   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * COLS);
+   // (HALF4: the four shared end-of-row cells come first behind the tiles, see below)
+   uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * COLS + (HALF4 ? 4 : 0));
    const uint32_t tr_bytes = BYTES ? h->byte_TR_bytes : h->chain_TR_bytes, ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
    const uint32_t chain_bytes = CHAIN ? ((512u + tr_bytes + ta_bytes + 15u) & ~15u) : 0u;
    const uint8_t* TRp = reinterpret_cast<const uint8_t*>(cmap) + 512;
@@ -1737,7 +1738,7 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    const bool spans = from && to;
    if (Lr > 16u * CH) {   // long rows: segment-walking instantiation (CH = 16: any length; CH = 8, first pass with the 8-state tables:
                           // half-row staging of 256-byte rows), first-pass / byte-level modes only
-      if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 0)) {
+      if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0)) {
          constexpr int CHN = SCH;
          const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds +
                             ((FX_HALF4 != 0 && CH <= 8 && spans) ? 64 : 0);   // (+ the four shared end-of-row cells)

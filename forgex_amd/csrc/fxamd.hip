@@ -77,6 +77,10 @@ static void env_load() {
    e.one_round_mb = num("FXAMD_ONE_ROUND_MB");
    e.one_blocks = num("FXAMD_ONE_BLOCKS");
    e.half_rounds = num("FXAMD_HALF_ROUNDS");
+   {
+      const char* v = std::getenv("FXAMD_HALF_SCH");
+      e.half_sch = v && *v ? std::atoi(v) : 7;   // bit s: table scheme s (0 v_perm, 1 chain, 2 nibble) stages half rows; test / experiment hook
+   }
    g_env = e;
 }
 const FxEnv& fx_env() {
@@ -531,12 +535,19 @@ struct PassOpts {
    int64_t grid_tiles = 0;         // MODE 4: upper bound of the worklist's tiles (the count itself lives on the device)
    bool half = false;              // first pass over 256-byte rows with the 8-state tables: stage HALF rows (CH = 8 segment walker)
 };
-// 256-byte rows on the 8-state tables: half-row staging (8 KB of LDS per wave: three waves per SIMD instead of two)
+// 256-byte rows: the multi-pass pipeline whose first pass stages HALF rows (8 KB of LDS per wave: four waves per SIMD instead of two).
+// Round 2: the 8-state v_perm tables.  Round 4: the chain tables (one dependent LDS read per byte: latency-bound, so twice the waves is
+// twice the rate -- 17-state pattern with spans 1.19 -> 0.72 ms, an e-mail pattern 0.97 -> 0.49 ms on config-3 rows) and, with spans, the
+// nibble tables (0.52 -> 0.48 ms); profiles/r04_half_chain_ab.txt.
 // (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
 //  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14)
-static bool half_rows(int scheme, int64_t row_len) {
-   return !fx_env().no_half && scheme == 0 && row_len == 256;   // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel)
+static bool half_rows(int scheme, int64_t row_len, bool spans) {
+   // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel; FXAMD_HALF_SCH: bit s = table scheme s takes half rows)
+   if (fx_env().no_half || row_len != 256 || scheme < 0 || scheme > 2 || ((fx_env().half_sch >> scheme) & 1) == 0) return false;
+   return scheme != 2 || spans;   // (flags only, nibble tables: the one-launch kernel's whole rows sit near the memory path already)
 }
+// ... and whether that first pass stages half rows or whole ones (flags only, v_perm tables: whole rows, on the memory path)
+static bool half_staging(int scheme, bool spans) { return spans || scheme == 1; }
 
 template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
@@ -764,7 +775,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(sc0, row_len)) && !fx_env().multipass;
+                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(sc0, row_len, d_from != nullptr)) && !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -813,7 +824,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
          else if (cap != hipStreamCaptureStatusNone) tiny = false;
       }
-      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len)) &&
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len, d_from != nullptr)) &&
                               !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
@@ -827,8 +838,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
       // 256-byte rows on the 8-state tables keep the multi-pass pipeline: its first pass stages HALF rows when spans are asked for
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
-      const bool keep_multipass = !is_match && half_rows(scheme, row_len);
-      first.half = keep_multipass && d_from != nullptr;
+      const bool keep_multipass = !is_match && half_rows(scheme, row_len, d_from != nullptr);
+      // (flags only: whole rows sit on the memory path with the v_perm and nibble tables; the chain tables' dependent LDS read per byte is
+      //  latency-bound and gains from the four waves per SIMD of the half-row tile there too)
+      first.half = keep_multipass && half_staging(scheme, d_from != nullptr);
       if (one_launch) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
          // the in-LDS decode on the others, exception rows through per-wave queues -- decoded in LDS, or, for programs whose tables
@@ -841,7 +854,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
-      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && utf8_tables && !fx_env().multipass;
+      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && scheme == 0 && utf8_tables && !fx_env().multipass;
       if ((bytes || !utf8_tables || first_pass != FX_FP_OWN) && !marked_followup) {
          const int rc = grow_worklist(sc, n);
          if (rc != FXAMD_OK) return rc;
@@ -906,7 +919,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          p->last_path = 1 + big;
          return FXAMD_OK;
       }
-      if (bytes && scheme != 0 && first_pass == FX_FP_OWN) {
+      if (bytes && scheme != 0 && first_pass == FX_FP_OWN && !first.half) {
          // no 8-state class-level tables to be faster with on ASCII: the byte-level tables take every tile, UTF-8 or not, in one pass
          if (is_match) FX_HIP(match_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
          else FX_HIP(fast_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
@@ -1270,8 +1283,8 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   po.half = half_rows(scheme, row_len) && d_from != nullptr;
-   if (scheme != 0 && bytes && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
+   po.half = half_rows(scheme, row_len, d_from != nullptr) && half_staging(scheme, d_from != nullptr);
+   if (scheme != 0 && bytes && !po.half && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
    } else {
