@@ -70,6 +70,14 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FX_MATCH_LONG_P3
 #define FX_MATCH_LONG_P3 1   // `.match.` over rows longer than 256 bytes, 8-state tables: whole segments with three lookup buffers (fx_match_row_pipe3)
 #endif
+#ifndef FX_LONG_NT_MIN
+// Rows longer than 256 bytes, search kernels: the segment loads take the nt policy only from this row length on.  Below it the lines stay
+// in L2 for the re-walk and the forward pass (which read the row from global memory once its segments have left the tile) and for the
+// neighbouring segment's load when a row length is not a multiple of the 128-byte line: measured in one allocation, nt against the
+// default policy (profiles/r04_long_nt_ab.txt): 400-byte rows 1.085 -> 0.890 ms, 1024-byte rows 0.567 -> 0.535 ms, 4096-byte rows
+// 0.492 -> 0.522 ms (worse), `.match.` over 1024-byte rows 0.408 -> 0.444 ms (worse: it reads every byte once -- it keeps nt).
+#define FX_LONG_NT_MIN 2048u
+#endif
 #ifndef FX_LOAD_AUX
 #define FX_LOAD_AUX 2   // cache policy bits of the tile loads: 2 = nt (rows are read once; measured 2-3 % over the default policy)
 #endif
@@ -105,7 +113,7 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
 // configuration: 8 KB of LDS per wave instead of 16, so that three waves per SIMD fit.
 template <int CH>
 __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
-                                              uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable, bool short_seg = false) {
+                                              uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable, bool short_seg = false, bool nt = true) {
    // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
    // (k_lo, k_hi) = (0, CH-1); the short last one has k_hi = its last (possibly partial) chunk and the chunks behind it repeat that
    // one (never walked).  Rows start at any byte: the pieces are unaligned buffer loads.
@@ -121,10 +129,19 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __r
    kc = kc < k_lo ? k_lo : (kc > k_hi ? k_hi : kc);
    const uint32_t voff = (lane / CH) * Lr + (kc - k_lo) * 16u;
    const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_byte);
+   // (`nt` is wave-uniform -- a function of the row length: the cache policy is an immediate of the instruction, hence the two loops)
+   if (CH != 16 || nt) {
 #pragma unroll
-   for (int q = 0; q < CH; ++q) {
-      const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)((64 / CH) * q) * Lr, FX_LOAD_AUX);
-      v[q] = make_uint4(t.x, t.y, t.z, t.w);
+      for (int q = 0; q < CH; ++q) {
+         const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)((64 / CH) * q) * Lr, FX_LOAD_AUX);
+         v[q] = make_uint4(t.x, t.y, t.z, t.w);
+      }
+   } else {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+         const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)((64 / CH) * q) * Lr, 0);
+         v[q] = make_uint4(t.x, t.y, t.z, t.w);
+      }
    }
    // The short last segment of the tile's LAST row: its final piece may reach past the tile, and the range check works dword by
    // dword on UNALIGNED dwords (rows start at any byte) -- the dword that holds the row's last bytes is dropped whole when it
@@ -730,7 +747,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 // segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
+   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), Lr >= FX_LONG_NT_MIN)
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
    load_tile_seg<16>(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en), (((sg) + 1u) * 256u > Lr))
 
