@@ -749,7 +749,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 #define PREFETCH_SEG(st, tn, sg, en) \
    load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), Lr >= FX_LONG_NT_MIN)
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
-   load_tile_seg<16>(st, rows, (tn) << 6, n, lane, Lr, (sg) * 256u, 0u, (((sg) + 1u) * 256u > Lr) ? (((Lr & 255u) + 15u) >> 4) - 1u : 15u, (en), (((sg) + 1u) * 256u > Lr))
+   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
@@ -1500,15 +1500,18 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
 
 // MODE as in fx_search_fast (BYTES modes: a row whose walk ends inside a character or in the INVALID state -- FINAL column 2 -- is
 // left to the row-level fix-up)
+// (round 4: LONG with CH = 8 is the HALF-row staging of 256-byte rows for the chain tables -- 8 KB of tile per wave, four waves per SIMD:
+//  their one dependent LDS read per byte is latency-bound, `.match.` of a 23-state pattern over config-3 rows 0.94 -> 0.66 ms, profiles/r04_half_chain_ab.txt)
 template <int CH, int MODE, int SCH, bool RAGGED, bool LONG = false>
-__global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+__global__ __launch_bounds__(256, (LONG && CH == 8) ? 4 : 1) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
                                                        uint32_t* __restrict__ worklist) {
    const uint32_t L = (RAGGED || LONG) ? Lr : 16u * CH;   // true row length; pads (symbol 255) behind it are the identity for A
-   const uint32_t S = LONG ? ((Lr + 255u) >> 8) : 1u;       // LONG: 256-byte segments per row (the last one shorter when Lr % 256 != 0, at any byte), left to right
+   constexpr uint32_t SEGB = 16u * CH;                       // bytes of one LDS tile row = one segment of a long row
+   const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // LONG: segments per row (the last one shorter when Lr % SEGB != 0, at any byte), left to right
    constexpr bool ragged = RAGGED;
-   static_assert(!LONG || (CH == 16 && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, first-pass / byte-level modes");
+   static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 (8: half rows), first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
@@ -1644,7 +1647,7 @@ __global__ __launch_bounds__(256) void fx_match_fast(const uint8_t* __restrict__
          if (ragged && (!whole || FIXUP)) na |= pad_rows<CH>(tile, lane, Lr);
          // ---- left-to-right pass over the whole row, lookups of the next 8-byte group in flight during the chain ----
          // LONG: bytes of this segment (the row may end inside its last one, at any byte: the groups are walked over their valid bytes)
-         const uint32_t seg_len = LONG ? (Lr - seg * 256u < 256u ? Lr - seg * 256u : 256u) : 16u * CH;
+         const uint32_t seg_len = LONG ? (Lr - seg * SEGB < SEGB ? Lr - seg * SEGB : SEGB) : 16u * CH;
          // whole segments of long rows on the 8-state tables (round 4): three lookup buffers, as `.match.` over rows of up to 256 bytes has
          // had since round 3 (fx_match_tile)
          bool piped = false;
@@ -1814,15 +1817,21 @@ hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, F
    const uint32_t map_lds = ((MODE == 1 || MODE == 4) && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
-   if (Lr > 256u) {   // long rows
-      if constexpr (CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) {
+   if (Lr > 16u * CH) {   // long rows (CH = 16), or 256-byte rows staged as half rows (CH = 8: first pass on the chain tables)
+      if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 1)) {
          constexpr int CHN = SCH;
-         const void* fn = reinterpret_cast<const void*>(&fx_match_fast<16, MODE, CHN, false, true>);
+         const void* fn = reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
-         hipLaunchKernelGGL((fx_match_fast<16, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+         if (CH == 8) {   // whole rounds of the four resident blocks per CU, as the half-row search kernel's grid
+            int64_t rounds = (n * (int64_t)Lr) / ((int64_t)225 << 20);
+            rounds = rounds < 3 ? 3 : (rounds > 64 ? 64 : rounds);
+            blocks = (n_tiles + 3) / 4;
+            if (blocks > 256 * 4 * rounds) blocks = 256 * 4 * rounds;
+         }
+         hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
          return hipGetLastError();
       } else {
          return hipErrorInvalidValue;

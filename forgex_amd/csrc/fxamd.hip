@@ -548,6 +548,8 @@ static bool half_rows(int scheme, int64_t row_len, bool spans) {
 }
 // ... and whether that first pass stages half rows or whole ones (flags only, v_perm tables: whole rows, on the memory path)
 static bool half_staging(int scheme, bool spans) { return spans || scheme == 1; }
+// `.match.` over 256-byte rows on the chain tables: the multi-pass pipeline with a half-row first pass too (fx_match_fast<8,...,LONG>)
+static bool match_half_rows(int scheme, int64_t row_len) { return scheme == 1 && half_rows(scheme, row_len, false); }
 
 template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
@@ -561,7 +563,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
       fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
       fp.inv = BYTES ? h.bw16_inv_A : 0u;
    }
-   switch (chunks_of(row_len)) {
+   switch ((po.half && SCH == 1 && MODE == 0) ? 8 : chunks_of(row_len)) {
       case 1: return launch_match<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_match<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_match<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -775,7 +777,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE || !half_rows(sc0, row_len, d_from != nullptr)) && !fx_env().multipass;
+                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(sc0, row_len) : !half_rows(sc0, row_len, d_from != nullptr)) && !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -824,7 +826,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
          else if (cap != hipStreamCaptureStatusNone) tiny = false;
       }
-      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match || !half_rows(scheme, row_len, d_from != nullptr)) &&
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match ? !match_half_rows(scheme, row_len) : !half_rows(scheme, row_len, d_from != nullptr)) &&
                               !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
@@ -841,7 +843,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       const bool keep_multipass = !is_match && half_rows(scheme, row_len, d_from != nullptr);
       // (flags only: whole rows sit on the memory path with the v_perm and nibble tables; the chain tables' dependent LDS read per byte is
       //  latency-bound and gains from the four waves per SIMD of the half-row tile there too)
-      first.half = keep_multipass && half_staging(scheme, d_from != nullptr);
+      first.half = (keep_multipass && half_staging(scheme, d_from != nullptr)) || (is_match && match_half_rows(scheme, row_len));
       if (one_launch) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
          // the in-LDS decode on the others, exception rows through per-wave queues -- decoded in LDS, or, for programs whose tables
