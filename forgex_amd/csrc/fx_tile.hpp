@@ -130,7 +130,7 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __r
    const uint32_t voff = (lane / CH) * Lr + (kc - k_lo) * 16u;
    const uint32_t s0 = __builtin_amdgcn_readfirstlane(seg_byte);
    // (`nt` is wave-uniform -- a function of the row length: the cache policy is an immediate of the instruction, hence the two loops)
-   if (CH != 16 || nt) {
+   if (nt) {
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
          const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 + (uint32_t)((64 / CH) * q) * Lr, FX_LOAD_AUX);
@@ -747,7 +747,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 // segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), Lr >= FX_LONG_NT_MIN)
+   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 16 || Lr >= FX_LONG_NT_MIN)
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
    load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
 

@@ -540,7 +540,8 @@ struct PassOpts {
 // twice the rate -- 17-state pattern with spans 1.19 -> 0.72 ms, an e-mail pattern 0.97 -> 0.49 ms on config-3 rows) and, with spans, the
 // nibble tables (0.52 -> 0.48 ms); profiles/r04_half_chain_ab.txt.
 // (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
-//  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14)
+//  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14; round 4, with the
+//  default cache policy on the loads so that the second half meets its line in L2: 0.45 ms against 0.366 ms, gpurun call r04_c26)
 static bool half_rows(int scheme, int64_t row_len, bool spans) {
    // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel; FXAMD_HALF_SCH: bit s = table scheme s takes half rows)
    if (fx_env().no_half || row_len != 256 || scheme < 0 || scheme > 2 || ((fx_env().half_sch >> scheme) & 1) == 0) return false;
@@ -856,7 +857,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
       // every row with a byte >= 0x80, and overlap rows, when there are no decode tables at all
-      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && scheme == 0 && utf8_tables && !fx_env().multipass;
+      const bool marked_followup = first_pass == FX_FP_OWN && keep_multipass && scheme == 0 && row_len == 256 && utf8_tables && !fx_env().multipass;
       if ((bytes || !utf8_tables || first_pass != FX_FP_OWN) && !marked_followup) {
          const int rc = grow_worklist(sc, n);
          if (rc != FXAMD_OK) return rc;
