@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_tile(uint4 (&v)[CH], const uint8_t* __restr
 // contiguous bytes of one row.  Same buffer resource trick: extent = the tile's valid bytes, the row / segment distance rides in
 // the scalar offset (which the range check includes).  CH = 8 with 256-byte rows is the HALF-ROW staging of the headline
 // configuration: 8 KB of LDS per wave instead of 16, so that three waves per SIMD fit.
-template <int CH>
+template <int CH, bool TAILFIX = (CH == 16)>
 __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, uint32_t Lr,
                                               uint32_t seg_byte, uint32_t k_lo, uint32_t k_hi, bool enable, bool short_seg = false, bool nt = true) {
    // the segment starts at row byte `seg_byte`; tile chunk k holds segment chunk clamp(k, k_lo, k_hi) - k_lo.  A whole segment has
@@ -149,7 +149,7 @@ __device__ __forceinline__ void load_tile_seg(uint4 (&v)[CH], const uint8_t* __r
    // re-read one by one; nothing behind the tile's own bytes is touched.
    // (CH = 8 is the half-row staging of 256-byte rows: whole segments only -- the code is left out of that kernel, where its mere
    //  presence cost 2-3 %)
-   if (CH == 16 && short_seg && enable) {
+   if (TAILFIX && short_seg && enable) {
       const uint32_t tile_bytes = rows_left >= 64 ? 64u * Lr : (uint32_t)rows_left * Lr;
       const uint32_t last_row = (rows_left >= 64 ? 64u : (uint32_t)rows_left) - 1u;
       const uint32_t q_last = last_row / (64u / CH);
@@ -747,7 +747,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 // segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 16 || Lr >= FX_LONG_NT_MIN)
+   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 16 || Lr >= FX_LONG_NT_MIN)
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
    load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
 
@@ -769,7 +769,12 @@ template <int CH, bool SPANS, bool LONG>
 constexpr int fx_tile_cols() {
    return (!LONG || (CH <= 8 && SPANS && FX_DEFER_LONG == 0 && FX_HALF4 == 0)) ? CH + 1 : CH;
 }
-template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false>
+// NOHALF (round 4; LONG with CH = 8 only): rows longer than 256 bytes walked in 128-byte segments -- the half-row kernel's lean loop and
+// 8 KB of tile per wave (four waves per SIMD) WITHOUT its in-LDS finish: exact start and forward pass from global memory, as with the
+// 256-byte segments.  For the chain tables only, whose one dependent LDS read per byte is latency-bound (17-state pattern over 1024-byte
+// rows: profiles/r04_half_chain_ab.txt); with the v_perm tables the backward pass is not what long rows wait for (0.562 -> 0.524 ms at
+// 1024 bytes, but 1.07 -> 1.17 ms at 400 and 0.493 -> 0.506 ms at 4096: not dispatched).
+template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false, bool NOHALF = false>
 __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : ((LONG && CH <= 8 && SPANS && FX_HALF4 != 0) ? 4 : 1)) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
@@ -780,14 +785,15 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    constexpr uint32_t SEGB = 16u * CH;                   // bytes of one LDS tile row = one segment of a long row
    const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // segments per row, the last one shorter when Lr % SEGB != 0
    constexpr bool ragged = RAGGED;
-   constexpr bool HALFROW = LONG && (CH == 8 || CH == 4);   // 256-byte (128-byte) rows staged as two halves of CH chunks (the launcher guarantees Lr == 32 * CH)
+   static_assert(!NOHALF || (LONG && CH == 8), "NOHALF: the 128-byte segment walker of long rows");
+   constexpr bool HALFROW = LONG && (CH == 8 || CH == 4) && !NOHALF;   // 256-byte (128-byte) rows staged as two halves of CH chunks (the launcher guarantees Lr == 32 * CH)
    // Match compaction (segment-walking kernels with spans): the exact start and the forward pass are per-ROW work that only rows with a
    // hit need, but a wave pays for them per TILE -- at full price when one lane in 64 has a hit.  Such rows are queued (row, hit group,
    // state entering it) in a per-wave LDS queue instead, and when 64 have gathered -- and once more at the end -- every lane takes one
    // queued row: re-walks its hit group and walks forward, reading the row's bytes from global memory (L2: the tile was just read).
    // The tile pass itself stores their flag (a hit inside the text always yields a span: flag 1); from / to follow at the flush.
    constexpr bool DEFER = FX_DEFER_LONG != 0 && LONG && SPANS;
-   constexpr bool HALF4 = FX_HALF4 != 0 && HALFROW && SPANS && !DEFER;   // the four-waves-per-SIMD tuning of the half-row kernel (see FX_HALF4)
+   constexpr bool HALF4 = FX_HALF4 != 0 && LONG && (CH == 8 || CH == 4) && SPANS && !DEFER;   // the four-waves-per-SIMD tuning of the half-row kernel (see FX_HALF4)
    static_assert(!LONG || ((CH == 16 || CH == 8 || CH == 4) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, 8 or 4, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
@@ -1758,8 +1764,23 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    const bool spans = from && to;
    if (Lr > 16u * CH) {   // long rows: segment-walking instantiation (CH = 16: any length; CH = 8, first pass with the 8-state tables:
                           // half-row staging of 256-byte rows), first-pass / byte-level modes only
+      if constexpr (CH == 8 && SCH == 1 && (MODE == 0 || MODE == 2)) {
+         if (Lr != 256u) {   // rows longer than 256 bytes on the chain tables: 128-byte segments, finished from global memory (NOHALF)
+            const size_t lds8 = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds + 64;
+            if (lds8 > 64 * 1024) {
+               const hipError_t e = hipFuncSetAttribute(spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, false, true, true>)
+                                                              : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, false, true, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+               if (e != hipSuccess) return e;
+            }
+            if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, false, true, true>), dim3((unsigned)blocks), dim3(256), lds8, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+            else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, false, true, true>), dim3((unsigned)blocks), dim3(256), lds8, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+            return hipGetLastError();
+         }
+      }
       if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0)) {
          constexpr int CHN = SCH;
+         if (CH == 8 && Lr != 256u) return hipErrorInvalidValue;   // (half rows: 256-byte rows only)
          const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds +
                             ((FX_HALF4 != 0 && CH <= 8 && spans) ? 64 : 0);   // (+ the four shared end-of-row cells)
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false, true>)

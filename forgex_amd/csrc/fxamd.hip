@@ -79,7 +79,8 @@ static void env_load() {
    e.half_rounds = num("FXAMD_HALF_ROUNDS");
    {
       const char* v = std::getenv("FXAMD_HALF_SCH");
-      e.half_sch = v && *v ? std::atoi(v) : 7;   // bit s: table scheme s (0 v_perm, 1 chain, 2 nibble) stages half rows; test / experiment hook
+      // bit s: table scheme s (0 v_perm, 1 chain, 2 nibble) stages half rows; bit 3: long rows on the chain tables in 128-byte segments
+      e.half_sch = v && *v ? std::atoi(v) : 15;   // (test / experiment hook)
    }
    g_env = e;
 }
@@ -641,7 +642,9 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.inv_on = 1u;
       fp.inv = WIDE ? h.R_inv : (CHAIN ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
-   switch (po.half ? 8 : chunks_of(row_len)) {
+   // (rows longer than 256 bytes on the chain tables: 128-byte segments at four waves per SIMD -- fx_search_fast NOHALF; bit 3 of the hook)
+   const bool long8 = CHAIN && (MODE == 0 || MODE == 2) && long_row(row_len) && (fx_env().half_sch & 8) != 0;
+   switch ((po.half || long8) ? 8 : chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_fast<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_fast<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);

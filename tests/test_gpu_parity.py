@@ -1787,3 +1787,48 @@ def test_match_half_rows_for_chain_tables(fx, monkeypatch):
             prog2, f2, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
             assert prog2.last_path() not in (5, 8) and np.array_equal(f2, of), (pat, kind, prog2.last_path())
     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+
+
+def test_long_rows_chain_tables_in_128_byte_segments(fx, monkeypatch):
+    """Round 4: rows longer than 256 bytes of programs on the chain tables are walked in 128-byte segments (fx_search_fast NOHALF: the
+    half-row kernel's loop at four waves per SIMD, finished from global memory) -- class-level first pass and byte-level pass over all
+    tiles, lengths of every residue (a shorter last segment that ends at any byte, the tile's last bytes), matches across segment
+    borders, UTF-8 and broken rows, spans and flags only -- against the oracle and the 256-byte segments (FXAMD_HALF_SCH=7)."""
+    import random
+    rng = random.Random(2500)
+    nrng = np.random.default_rng(2500)
+    alpha = np.frombuffer(b"abcdefghij klmnop0123456789-@._", dtype=np.uint8)
+    pats = [rb"[a-z]{6}\d{1,3}[a-z ]{6}", rb"(19|20)\d\d-(0[1-9]|1[012])-(0[1-9]|[12][0-9]|3[01])", rb"[a-z]{3,5}\d{2,4}[a-z ]{3}$", "[ぁ-ん]{3}[ァ-ヶ]{3}[0-9]{3}".encode()]
+    seeds = [b"abcdef123abc de", b"2024-02-29", b"abcd1234efg", "あいうアイウ123".encode(), b"1999-12-31", b"ghijkl7mnop  "]
+    for pat in pats[:3]:   # (the fourth runs on the nibble tables: the 256-byte segments, for comparison)
+        fl = fx.Program(pat, fx.OP_SEARCH).info()["flags"]
+        assert (fl & 256) and not (fl & ((1 << 13) | 8)), (pat, fl)   # chain tables only
+    for L in (257, 259, 300, 383, 384, 385, 400, 512, 515, 1000, 1024, 2049):
+        n = 64 * 5 + 17
+        rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+        for i in range(0, n, 2):
+            sd = np.frombuffer(seeds[(i // 2) % len(seeds)], dtype=np.uint8)
+            border = 128 * rng.randint(1, L // 128)
+            off = [0, L - len(sd), max(0, min(L - len(sd), border - rng.randint(0, len(sd)))), rng.randint(0, L - len(sd))][(i // 2) % 4]
+            rows[i, off:off + len(sd)] = sd
+        for i in range(3, n, 13):
+            c = np.frombuffer("んω€".encode(), dtype=np.uint8)
+            off = rng.randint(0, L - len(c))
+            rows[i, off:off + len(c)] = c
+        for i in range(9, n, 31):
+            rows[i, rng.randint(0, L - 1)] = rng.choice([0x80, 0xC0, 0xFF, 0xE3])
+        rows[1::64, L - 11:] = np.frombuffer(b"abcd1234efg", dtype=np.uint8)   # (a match of the `$` pattern at the row's last byte)
+        for pat in pats:
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            for hook in (None, "7"):
+                if hook:
+                    monkeypatch.setenv("FXAMD_HALF_SCH", hook)
+                else:
+                    monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+                prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+                bad = np.nonzero((f != of) | (a != oa) | (b != ob))[0]
+                assert bad.size == 0, (pat, L, hook, prog.last_path(), int(bad[0]), int(f[bad[0]]), int(a[bad[0]]), int(b[bad[0]]), int(of[bad[0]]), int(oa[bad[0]]), int(ob[bad[0]]))
+                _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+                assert np.array_equal(f2, of), (pat, L, hook, "flags only")
+            assert int(of.sum()) > 0, (pat, L)
+    monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
