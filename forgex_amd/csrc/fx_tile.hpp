@@ -749,7 +749,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 #define PREFETCH_SEG(st, tn, sg, en) \
    load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 16 || Lr >= FX_LONG_NT_MIN)
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
-   load_tile_seg<CH>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
+   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
@@ -1508,7 +1508,8 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
 // left to the row-level fix-up)
 // (round 4: LONG with CH = 8 is the HALF-row staging of 256-byte rows for the chain tables -- 8 KB of tile per wave, four waves per SIMD:
 //  their one dependent LDS read per byte is latency-bound, `.match.` of a 23-state pattern over config-3 rows 0.94 -> 0.66 ms, profiles/r04_half_chain_ab.txt)
-template <int CH, int MODE, int SCH, bool RAGGED, bool LONG = false>
+//  NOHALF: rows longer than 256 bytes in 128-byte segments, chain tables -- as fx_search_fast's)
+template <int CH, int MODE, int SCH, bool RAGGED, bool LONG = false, bool NOHALF = false>
 __global__ __launch_bounds__(256, (LONG && CH == 8) ? 4 : 1) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
@@ -1839,8 +1840,23 @@ hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, F
    const size_t lds = (size_t)4 * 64 * CH * 16 + chain_bytes + map_lds;
    const bool ragged = Lr != 16u * CH;
    if (Lr > 16u * CH) {   // long rows (CH = 16), or 256-byte rows staged as half rows (CH = 8: first pass on the chain tables)
+      if constexpr (CH == 8 && SCH == 1 && (MODE == 0 || MODE == 2)) {
+         if (Lr != 256u) {   // rows longer than 256 bytes on the chain tables: 128-byte segments (NOHALF: the loader's tail fix for short last segments)
+            if (lds > 64 * 1024) {
+               const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+               if (e != hipSuccess) return e;
+            }
+            int64_t rounds = (n * (int64_t)Lr) / ((int64_t)225 << 20);
+            rounds = rounds < 3 ? 3 : (rounds > 64 ? 64 : rounds);
+            blocks = (n_tiles + 3) / 4;
+            if (blocks > 256 * 4 * rounds) blocks = 256 * 4 * rounds;
+            hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, false, true, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+            return hipGetLastError();
+         }
+      }
       if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 1)) {
          constexpr int CHN = SCH;
+         if (CH == 8 && Lr != 256u) return hipErrorInvalidValue;   // (half rows: 256-byte rows only)
          const void* fn = reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

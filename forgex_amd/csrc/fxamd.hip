@@ -565,7 +565,8 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
       fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
       fp.inv = BYTES ? h.bw16_inv_A : 0u;
    }
-   switch ((po.half && SCH == 1 && MODE == 0) ? 8 : chunks_of(row_len)) {
+   const bool long8 = CHAIN && (MODE == 0 || MODE == 2) && long_row(row_len) && (fx_env().half_sch & 8) != 0;   // (as launch_fast_any's)
+   switch (((po.half && SCH == 1 && MODE == 0) || long8) ? 8 : chunks_of(row_len)) {
       case 1: return launch_match<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_match<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_match<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);

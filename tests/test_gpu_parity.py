@@ -1831,4 +1831,27 @@ def test_long_rows_chain_tables_in_128_byte_segments(fx, monkeypatch):
                 _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
                 assert np.array_equal(f2, of), (pat, L, hook, "flags only")
             assert int(of.sum()) > 0, (pat, L)
+        # `.match.` (fx_match_fast NOHALF): letters and blanks with one run of 1..4 digits (up to 3: a match), some rows with UTF-8 / broken bytes
+        mrows = np.frombuffer(b"abcdefghij klmnop", dtype=np.uint8)[nrng.integers(0, 17, size=(n, L))].copy()
+        for i in range(n):
+            k = 1 + i % 4
+            off = min([7, L - 9, 128 * rng.randint(1, L // 128) - 2, rng.randint(6, L - 12)][i % 4], L - 8)
+            mrows[i, off:off + k] = np.frombuffer(b"0123"[:k], dtype=np.uint8)
+        for i in range(5, n, 17):
+            c = np.frombuffer("んω".encode(), dtype=np.uint8)
+            off = rng.randint(0, L - len(c))
+            mrows[i, off:off + len(c)] = c
+        for i in range(11, n, 37):
+            mrows[i, rng.randint(0, L - 1)] = 0xFF
+        for pat in (rb"[a-z ]{6}[a-z ]*\d{0,3}[a-z ]{6}[a-z ]*", "[a-zぁ-ん ]{9}[a-zぁ-ん ]*\\d{0,3}[a-z ω]{8}[a-z ω]*".encode()):
+            om, _, _ = oracle_lib.batch(1, pat, mrows, NT)
+            for hook in (None, "7"):
+                if hook:
+                    monkeypatch.setenv("FXAMD_HALF_SCH", hook)
+                else:
+                    monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+                pm, fm, _, _ = _device_run(fx, pat, fx.OP_MATCH, mrows, spans=False)
+                bad = np.nonzero(fm != om)[0]
+                assert bad.size == 0, (pat, L, hook, "match", pm.last_path(), int(bad[0]), int(fm[bad[0]]), int(om[bad[0]]))
+            assert 0 < int(om.sum()) < n, (pat, L)
     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)

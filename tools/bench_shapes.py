@@ -28,6 +28,7 @@ SHAPES = {
     "in_flags_cfg1x": ("`.in.` verdict (flags only) `\\d{3}-\\d{4}` over 64M x 8 B rows of config 1's generator (fx_search_tiny)", "search", [r"\d{3}-\d{4}"], "cfg1", None, 64_000_000, False, False),
     "match_ragged_200": ("`.match.` over config-3 bytes viewed as rows of 200 B (ragged rows of the one-launch kernel)", "match", [r"[a-z ]+\d*[a-z ]*[a-z 0-9]*"], "cfg3", 200, 12_800_000, False, False),
     "match_long_1024": ("`.match.` `[a-z ]+\\d*[a-z ]*[a-z 0-9]*` over config-3 bytes viewed as 2.5M x 1024 B rows (segment loop of fx_match_fast)", "match", [r"[a-z ]+\d*[a-z ]*[a-z 0-9]*"], "cfg3", 1024, 2_500_000, False, False),
+    "match_long_chain_1024": ("`.match.` of a 23-state pattern (chain tables) over config-3 bytes viewed as 2.5M x 1024 B rows", "match", [r"[a-z ]{6}[a-z ]*\d{0,3}[a-z ]{6}[a-z ]*"], "cfg3", 1024, 2_500_000, False, False),
     "long_1024":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as 2.5M x 1024 B rows", "search", [r"[a-z]+\d+"], "cfg3", 1024, 2_500_000, False, True),
     "long_chain_1024": ("`[a-z]{6}\\d{1,3}[a-z ]{6}` (17 states: chain tables) `.in.` + spans, config-3 bytes viewed as 2.5M x 1024 B rows", "search", [r"[a-z]{6}\d{1,3}[a-z ]{6}"], "cfg3", 1024, 2_500_000, False, True),
     "long_4096":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as 625k x 4096 B rows", "search", [r"[a-z]+\d+"], "cfg3", 4096, 625_000, False, True),
