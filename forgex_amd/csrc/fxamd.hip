@@ -831,13 +831,24 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
          else if (cap != hipStreamCaptureStatusNone) tiny = false;
       }
-      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) && (is_match ? !match_half_rows(scheme, row_len) : !half_rows(scheme, row_len, d_from != nullptr)) &&
-                              !fx_env().multipass;
+      // Where round 4 moved rows off the one-launch kernel -- 256-byte rows on the chain / nibble tables (half rows) -- a stream that is
+      // being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches (the counter groups of
+      // the multi-pass pipelines alternate on the host).
+      // (Rows of 129..255 bytes on the chain tables walked like long rows, in 128-byte segments, were tried too: the 17-state pattern over
+      //  200-byte rows 1.283 -> 1.349 ms -- a 128-byte and a 72-byte segment pay two segments' fixed work; gpurun call r04_c34.)
+      bool half = is_match ? match_half_rows(scheme, row_len) : half_rows(scheme, row_len, d_from != nullptr);
+      if (half && (scheme != 0 || is_match)) {
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+         else if (cap != hipStreamCaptureStatusNone) half = false;
+      }
+      const bool as_long = long_row(row_len);
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
-      const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !long_row(row_len);
+      const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !as_long;
       const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
       const int bsch = bytes_scheme(h);
       const int big = scheme == 0 ? 0 : 4;   // last_path: 1 / 3 with the 8-state tables, 5 / 6 with the wide v_perm or chain tables
@@ -845,10 +856,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       first.defer_tiles = (utf8_tables || bytes) ? 1u : 0u;
       // 256-byte rows on the 8-state tables keep the multi-pass pipeline: its first pass stages HALF rows when spans are asked for
       // (8 KB of LDS per wave: three waves per SIMD), which the one-launch kernel -- a full row per lane in LDS -- cannot
-      const bool keep_multipass = !is_match && half_rows(scheme, row_len, d_from != nullptr);
+      const bool keep_multipass = !is_match && half;
       // (flags only: whole rows sit on the memory path with the v_perm and nibble tables; the chain tables' dependent LDS read per byte is
       //  latency-bound and gains from the four waves per SIMD of the half-row tile there too)
-      first.half = (keep_multipass && half_staging(scheme, d_from != nullptr)) || (is_match && match_half_rows(scheme, row_len));
+      first.half = (keep_multipass && half_staging(scheme, d_from != nullptr)) || (is_match && half);
       if (one_launch) {
          // ONE launch: every tile finished by the wave that staged it (class-level tables on pure-ASCII tiles, byte-level tables or
          // the in-LDS decode on the others, exception rows through per-wave queues -- decoded in LDS, or, for programs whose tables

@@ -1855,3 +1855,43 @@ def test_long_rows_chain_tables_in_128_byte_segments(fx, monkeypatch):
                 assert bad.size == 0, (pat, L, hook, "match", pm.last_path(), int(bad[0]), int(fm[bad[0]]), int(om[bad[0]]))
             assert 0 < int(om.sum()) < n, (pat, L)
     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+
+
+def test_chain_table_rows_under_graph_capture_keep_the_one_launch_kernel(fx):
+    """Round 4 moved 256-byte rows of chain-table programs to the half-row multi-pass pipeline, whose counter groups alternate on the host; a call on a stream that is being captured into a hipGraph keeps the one-launch kernel
+    (`last_path` 9-14) and the graph replays on new row contents."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    pat = r"[a-z]{6}\d{1,3}[a-z ]{6}"
+    for L, op, spans in ((256, fx.OP_SEARCH, True), (256, fx.OP_SEARCH, False), (256, fx.OP_MATCH, False)):
+        n = 4096
+        p = r"[a-z ]{6}[a-z ]*\d{0,3}[a-z ]{6}[a-z ]*" if op == fx.OP_MATCH else pat
+        def batch(start):
+            flat = synth.batch("cfg3", start, n, dev).reshape(-1)
+            return flat[: (flat.numel() // L) * L].reshape(-1, L)[:n * 256 // L].contiguous()
+        rows = batch(0)
+        m = rows.shape[0]
+        prog = fx.Program(p, op)
+        out = prog.match_device(rows, spans=spans)
+        torch.cuda.synchronize()
+        assert prog.last_path() in (5, 7, 8), (L, op, prog.last_path())
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            assert fx.lib().fxamd_program_reserve(prog._h, m, side.cuda_stream) == 0
+            prog.match_device(rows, spans=spans, out=out)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            prog.match_device(rows, spans=spans, out=out)
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14), (L, op, prog.last_path())
+        for start in (10000, 77777):
+            rows.copy_(batch(start))
+            g.replay()
+            torch.cuda.synchronize()
+            got = [t.clone() if t is not None else None for t in out]
+            want = prog.match_device(rows, spans=spans)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]), (L, op, start)
+            if spans:
+                assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (L, op, start)
