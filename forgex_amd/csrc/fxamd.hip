@@ -543,15 +543,19 @@ struct PassOpts {
 // (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
 //  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14; round 4, with the
 //  default cache policy on the loads so that the second half meets its line in L2: 0.45 ms against 0.366 ms, gpurun call r04_c26)
-static bool half_rows(int scheme, int64_t row_len, bool spans) {
+static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
    // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel; FXAMD_HALF_SCH: bit s = table scheme s takes half rows)
    if (fx_env().no_half || row_len != 256 || scheme < 0 || scheme > 2 || ((fx_env().half_sch >> scheme) & 1) == 0) return false;
+   // A program whose every match needs a byte >= 0x80 is given text that holds such bytes: the half-row first pass would load every tile
+   // only to defer it to the follow-up (config 4's pattern and text in 256-byte rows: 0.1135 ms against 0.0838 ms on the one-launch
+   // kernel, which answers the pure-ASCII tiles of such programs with an OR of their words anyway; gpurun call r04_c38)
+   if (h.flags & FXP_F_NEEDS_NONASCII) return false;
    return scheme != 2 || spans;   // (flags only, nibble tables: the one-launch kernel's whole rows sit near the memory path already)
 }
 // ... and whether that first pass stages half rows or whole ones (flags only, v_perm tables: whole rows, on the memory path)
 static bool half_staging(int scheme, bool spans) { return spans || scheme == 1; }
 // `.match.` over 256-byte rows on the chain tables: the multi-pass pipeline with a half-row first pass too (fx_match_fast<8,...,LONG>)
-static bool match_half_rows(int scheme, int64_t row_len) { return scheme == 1 && half_rows(scheme, row_len, false); }
+static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && half_rows(h, scheme, row_len, false); }
 
 template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
@@ -782,7 +786,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
    if (out_mode != 0u) {
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(sc0, row_len) : !half_rows(sc0, row_len, d_from != nullptr)) && !fx_env().multipass;
+                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(h, sc0, row_len) : !half_rows(h, sc0, row_len, d_from != nullptr)) && !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
@@ -836,7 +840,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // the multi-pass pipelines alternate on the host).
       // (Rows of 129..255 bytes on the chain tables walked like long rows, in 128-byte segments, were tried too: the 17-state pattern over
       //  200-byte rows 1.283 -> 1.349 ms -- a 128-byte and a 72-byte segment pay two segments' fixed work; gpurun call r04_c34.)
-      bool half = is_match ? match_half_rows(scheme, row_len) : half_rows(scheme, row_len, d_from != nullptr);
+      bool half = is_match ? match_half_rows(h, scheme, row_len) : half_rows(h, scheme, row_len, d_from != nullptr);
       if (half && (scheme != 0 || is_match)) {
          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
@@ -1301,7 +1305,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   po.half = half_rows(scheme, row_len, d_from != nullptr) && half_staging(scheme, d_from != nullptr);
+   po.half = half_rows(h, scheme, row_len, d_from != nullptr) && half_staging(scheme, d_from != nullptr);
    if (scheme != 0 && bytes && !po.half && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));
