@@ -850,6 +850,15 @@ template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MAR
 __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : 1))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr) {
+   if (MARKED && blockIdx.x == 0 && threadIdx.x == 0) {
+      // (FX_ADAPT_CALLS, fx_tile.hpp) the persistent word behind the two counter groups: count down while it is set, else look at what the
+      // first pass sampled -- more than half of its tiles deferred sets it.  No other block of this kernel reads it; the next call's first
+      // pass does, after this kernel.
+      uint32_t* hintw = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(gate) & ~uintptr_t(31)) + 32u);
+      const uint32_t hv = hintw[0];
+      if (hv != 0u) hintw[0] = hv - 1u;
+      else if (gate[3] >= 8u && gate[2] * 2u > gate[3]) hintw[0] = FX_ADAPT_CALLS;
+   }
    if (MARKED && gate[0] == 0u) return;   // nothing was deferred
    // out_mode 0: flags u8[n], from / to int32[n].  out_mode 1 / 2 / 4: PACKED results (what a multi-GPU host gathers):
    // `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit word i >> 6: the ballot of the tile's wave, one store per tile),

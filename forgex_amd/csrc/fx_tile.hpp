@@ -23,7 +23,7 @@
 // Test / experiment hooks (environment variables FXAMD_*), read ONCE per process -- the library's scalar callers make match calls in
 // loops, and a dozen getenv per enqueue is host time on their path.  fxamd_reload_env() (C ABI, tests only) reads them again.
 struct FxEnv {
-   bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
+   bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, no_adapt, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
       host_register;
    int64_t slice_rows;                                      // rows per enqueue (a multiple of 64)
    int one_grid, one_round_mb, one_blocks, half_rounds, half_sch;     // launch-grid experiments (0 = the built-in rule)
@@ -69,6 +69,15 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef FX_MATCH_LONG_P3
 #define FX_MATCH_LONG_P3 1   // `.match.` over rows longer than 256 bytes, 8-state tables: whole segments with three lookup buffers (fx_match_row_pipe3)
+#endif
+#ifndef FX_ADAPT_CALLS
+// The half-row pipeline of 256-byte rows on batches that are mostly UTF-8 (round 4): its first pass loads every tile only to defer it to
+// the follow-up -- the rows are read twice.  A first pass that finds more than half of its tiles deferred (sampled: every 256th wave reports
+// its tiles and how many of them it deferred, words [3] and [2] of the call's counter group) makes the follow-up set a persistent word
+// behind the counter groups; while that word is not zero (it counts down: the next FX_ADAPT_CALLS calls on this scratch set) the first pass
+// marks every tile for the follow-up WITHOUT loading it.  Results never depend on the word: the follow-up finishes whatever is marked,
+// pure-ASCII tiles included (with the class-level tables); only the cost does, until the count-down ends and a first pass looks again.
+#define FX_ADAPT_CALLS 8u
 #endif
 #ifndef FX_LONG_NT_MIN
 // Rows longer than 256 bytes, search kernels: the segment loads take the nt policy only from this row length on.  Below it the lines stay
@@ -817,6 +826,20 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id in an SGPR: tile indices stay scalar
    const int64_t n_tiles = (n + 63) >> 6;
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
+   // (see FX_ADAPT_CALLS) bit 1 of defer_tiles: this first pass takes part; the persistent word sits behind the two counter groups
+   const bool adapt = MODE == 0 && (fp.defer_tiles & 2u) != 0u;
+   if (adapt) {
+      const uint32_t* hintw = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(n_deferred) & ~uintptr_t(31)) + 32u);
+      if (__builtin_amdgcn_readfirstlane(hintw[0]) != 0u) {   // mostly UTF-8 lately: every tile to the follow-up, unread
+         for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
+            const int64_t row = (t << 6) + lane;
+            if (row < n) flags[row] = FX_NEEDS_GENERAL;
+         }
+         if (lane == 0) n_deferred[0] = 1u;
+         return;
+      }
+   }
+   uint32_t n_def = 0, n_seen = 0;   // (wave-uniform) tiles this wave deferred / was given
    // Start-up: this thread's entries of the 256-entry tables are READ first, then the first tiles' global loads go out, and only then are the
    // entries written to LDS: the block's two start-up latencies -- tables from L2, rows from HBM -- overlap instead of adding up, and the wait
    // for the table entries (the older loads: vmcnt counts in order) does not wait for the rows.  (The marked-tile passes read the flags first;
@@ -1036,6 +1059,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    // `live`: the tile in `stage` is to be scanned (always, except in the marked-tile passes); on return it says so for t_next
    auto do_tile = [&](uint4 (&stage)[CH], bool& live, const int64_t t, const int64_t t_next) {
       const int64_t row0 = t << 6;
+      n_seen += 1u;
       STAMP(7);
       int64_t row = row0 + lane;   // the row this lane owns and whether it exists
       bool row_ok = row < n;
@@ -1078,6 +1102,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          if (defer_early) {
             if (row_ok) flags[row] = FX_NEEDS_GENERAL;
             any_deferred = true;
+            n_def += 1u;
             return;
          }
          if (FIXUP) {
@@ -1319,6 +1344,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       if (queued) flag = 1;
       if (nonascii) flag = FX_NEEDS_GENERAL;
       any_deferred = any_deferred || defer_tile;
+      n_def += defer_tile ? 1u : 0u;
       if (row_ok) {
          flags[row] = (uint8_t)flag;
          if (SPANS && !queued) {
@@ -1373,6 +1399,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    STAMP_FLUSH;
    // one plain store per wave (not an atomic per tile: 16k same-address atomics cost ~0.2 ms); the value only gates the second pass
    if (MODE == 0 && any_deferred && lane == 0) n_deferred[0] = 1u;
+   if (adapt && (wave_global & 255) == 0 && lane == 0) {   // the sample FX_ADAPT_CALLS describes: two atomics from every 256th wave (same-address atomics cost ~12 ns each)
+      atomicAdd(&n_deferred[3], n_seen);
+      if (n_def != 0u) atomicAdd(&n_deferred[2], n_def);
+   }
 }
 
 // =========================================================================================================

@@ -61,6 +61,7 @@ static void env_load() {
    e.no_a8 = on("FXAMD_NO_A8");
    e.no_spec = on("FXAMD_NO_SPEC");
    e.no_tiny = on("FXAMD_NO_TINY");
+   e.no_adapt = on("FXAMD_NO_ADAPT");
    e.multipass = on("FXAMD_MULTIPASS");
    e.no_cache = on("FXAMD_NO_CACHE");
    e.no_multi = on("FXAMD_NO_MULTI");
@@ -489,9 +490,9 @@ static int scratch_for(fxamd_program* p, int dev, hipStream_t st, DevScratch** o
       }
    }
    if (!found->d_counter) {
-      FX_HIP(hipMalloc((void**)&found->d_counter, 32));
+      FX_HIP(hipMalloc((void**)&found->d_counter, 64));   // two groups of four words + the persistent word of FX_ADAPT_CALLS (+ spare)
       // zeroed IN STREAM ORDER: a memset on the null stream is not ordered against kernels on a non-blocking stream
-      FX_HIP(hipMemsetAsync(found->d_counter, 0, 32, st));
+      FX_HIP(hipMemsetAsync(found->d_counter, 0, 64, st));
    }
    found->last_use = ++p->use_clock;
    *out = found;
@@ -952,6 +953,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // ONE gated follow-up -- the one-launch kernel over the tiles that pass marked (byte-level tables or in-LDS decode, exception
       // queues inside) -- instead of a pass over marked tiles plus a pass over a worklist
       if (marked_followup) {
+         if (!fx_env().no_adapt) first.defer_tiles |= 2u;   // (FX_ADAPT_CALLS: batches that are mostly UTF-8 skip the first pass's loads)
          FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
          const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

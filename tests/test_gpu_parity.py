@@ -1895,3 +1895,46 @@ def test_chain_table_rows_under_graph_capture_keep_the_one_launch_kernel(fx):
             assert torch.equal(got[0], want[0]), (L, op, start)
             if spans:
                 assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (L, op, start)
+
+
+def test_adaptive_first_pass_on_mostly_utf8_batches(fx, monkeypatch):
+    """Round 4 (FX_ADAPT_CALLS): on 256-byte rows the half-row pipeline's first pass, having found most tiles holding bytes >= 0x80, marks
+    every tile for the follow-up WITHOUT loading it for the next calls on the same scratch set (a persistent count-down on the device).
+    Results must never depend on that word: a UTF-8 batch called many times in a row, then a pure-ASCII batch (the stale word sends its
+    tiles through the follow-up), then a mixed one -- every call equal to the oracle; the same with FXAMD_NO_ADAPT=1."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    n = 64 * 400
+    u = torch.full((n, 256), 32, dtype=torch.uint8, device=dev)
+    u[:, :190] = synth.batch("cfg4", 500, n, dev)[:, :190]
+    a = synth.batch("cfg3", 900, n, dev)
+    mixed = a.clone()
+    mixed[64 * 100:64 * 300] = u[64 * 100:64 * 300]
+    for hook in (None, "1"):
+        if hook:
+            monkeypatch.setenv("FXAMD_NO_ADAPT", hook)
+        else:
+            monkeypatch.delenv("FXAMD_NO_ADAPT", raising=False)
+        for pat in (r"[a-z ]+\d*", r"\d+[a-z]"):
+            prog = fx.Program(pat, fx.OP_SEARCH)
+            for spans in (True, False):
+                for rows, calls in ((u, 12), (a, 11), (mixed, 4), (u, 3), (a, 2)):
+                    k = 3000
+                    of, oa, ob = oracle_lib.batch(2, pat.encode(), rows[:k].cpu().numpy(), NT)
+                    first = None
+                    for c in range(calls):
+                        f, fa, fb = prog.match_device(rows, spans=spans)
+                        torch.cuda.synchronize()
+                        assert prog.last_path() == 16, (pat, prog.last_path())
+                        got = (f.clone(), fa.clone() if spans else None, fb.clone() if spans else None)
+                        if first is None:
+                            first = got
+                            assert np.array_equal(got[0][:k].cpu().numpy(), of), (pat, spans, hook, c)
+                            if spans:
+                                assert np.array_equal(got[1][:k].cpu().numpy(), oa) and np.array_equal(got[2][:k].cpu().numpy(), ob), (pat, hook, c)
+                        else:
+                            assert torch.equal(got[0], first[0]), (pat, spans, hook, c)
+                            if spans:
+                                assert torch.equal(got[1], first[1]) and torch.equal(got[2], first[2]), (pat, hook, c)
+    monkeypatch.delenv("FXAMD_NO_ADAPT", raising=False)

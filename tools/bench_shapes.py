@@ -69,6 +69,7 @@ SHAPES = {
     "utf8_100":     ("config 4's pattern and text in rows of 100 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 100), 2 << 20, False, True),
     "utf8_132":     ("config 4's pattern and text in rows of 132 B", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 132), 3 << 19, False, True),
     "utf8_256":     ("config 4's pattern and text in rows of 256 B (255 B of text + a blank): the half-row first pass defers every tile to the gated follow-up", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 256), 1 << 20, False, True),
+    "utf8_256_any": ("`[a-z ]+` (a pattern that matches ASCII text too) over config 4's text in rows of 256 B: the half-row pipeline on a batch that is mostly UTF-8 (FX_ADAPT_CALLS)", "search", ["[a-z ]+"], "cfg4", ("cut", 256), 1 << 20, False, True),
     "utf8_255":     ("config 4's pattern and text in rows of 255 B (190 B of text, blank-padded)", "search", ["[α-ωぁ-ん]+"], "cfg4", ("cut", 255), 1 << 20, False, True),
 }
 
