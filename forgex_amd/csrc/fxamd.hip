@@ -540,7 +540,7 @@ struct PassOpts {
 // 256-byte rows: the multi-pass pipeline whose first pass stages HALF rows (8 KB of LDS per wave: four waves per SIMD instead of two).
 // Round 2: the 8-state v_perm tables.  Round 4: the chain tables (one dependent LDS read per byte: latency-bound, so twice the waves is
 // twice the rate -- 17-state pattern with spans 1.19 -> 0.72 ms, an e-mail pattern 0.97 -> 0.49 ms on config-3 rows) and, with spans, the
-// nibble tables (0.52 -> 0.48 ms); profiles/r04_half_chain_ab.txt.
+// nibble tables (0.52 -> 0.48 ms; flags only 0.49 -> 0.465 ms); profiles/r04_half_chain_ab.txt.
 // (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
 //  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14; round 4, with the
 //  default cache policy on the loads so that the second half meets its line in L2: 0.45 ms against 0.366 ms, gpurun call r04_c26)
@@ -551,10 +551,11 @@ static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool span
    // only to defer it to the follow-up (config 4's pattern and text in 256-byte rows: 0.1135 ms against 0.0838 ms on the one-launch
    // kernel, which answers the pure-ASCII tiles of such programs with an OR of their words anyway; gpurun call r04_c38)
    if (h.flags & FXP_F_NEEDS_NONASCII) return false;
-   return scheme != 2 || spans;   // (flags only, nibble tables: the one-launch kernel's whole rows sit near the memory path already)
+   return true;
 }
-// ... and whether that first pass stages half rows or whole ones (flags only, v_perm tables: whole rows, on the memory path)
-static bool half_staging(int scheme, bool spans) { return spans || scheme == 1; }
+// ... and whether that first pass stages half rows or whole ones (flags only, v_perm tables: whole rows, on the memory path; flags only,
+// nibble tables: half rows at three waves per SIMD, 0.487-0.493 -> 0.464-0.466 ms on config-3 rows, gpurun call r04_c44)
+static bool half_staging(int scheme, bool spans) { return spans || scheme != 0; }
 // `.match.` over 256-byte rows on the chain tables: the multi-pass pipeline with a half-row first pass too (fx_match_fast<8,...,LONG>)
 static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && half_rows(h, scheme, row_len, false); }
 

@@ -181,8 +181,7 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
  * one-launch kernel over the tiles that pass left.  17 = `.match.` and the `.in.` verdict (no spans) over rows of 2 to 32 bytes:
  * fx_match_tiny / fx_search_tiny (a lane takes a span of 64 / L whole rows) + the gated row-level fix-up of rows with bytes >= 0x80
- * (a stream under hipGraph capture keeps path 9-14).  256-byte rows of programs with more than 8 states (chain tables; nibble tables
- * when spans are asked for) report 5 / 6 / 8 as well: the same pipeline with a half-row first pass at four waves per SIMD (one-launch
+ * (a stream under hipGraph capture keeps path 9-14).  256-byte rows of programs with more than 8 states (chain and nibble tables) report 5 / 6 / 8 as well: the same pipeline with a half-row first pass at four waves per SIMD (one-launch
  * kernel on a stream under hipGraph capture); rows longer than 256 bytes on the chain tables: 7 or 5 / 6, walked in 128-byte segments.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
  * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_NO_TINY, FXAMD_NO_ADAPT, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,

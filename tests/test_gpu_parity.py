@@ -1702,7 +1702,7 @@ def test_many_patterns_from_several_streams_and_threads(fx):
 
 
 def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
-    """Round 4: 256-byte rows of programs on the chain tables (spans and flags only) and the nibble tables (spans) take the multi-pass pipeline
+    """Round 4: 256-byte rows of programs on the chain tables and the nibble tables (spans and flags only) take the multi-pass pipeline
     whose first pass stages HALF rows (four waves per SIMD; `last_path` 8 / 5 / 6) -- pure-ASCII batches, batches with UTF-8 tiles (the
     byte-level pass over the tiles the first pass deferred) and with structurally broken rows (worklist), matches in either half, across the
     half boundary, at the row's first and last byte -- against the oracle and against the one-launch kernel (FXAMD_HALF_SCH=1)."""
@@ -1735,7 +1735,7 @@ def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
                 prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
                 fl = prog.info()["flags"]
                 if not (fl & 8) and (fl & ((1 << 13) | 256)):   # no 8-state tables; nibble tables (taken when present) or chain tables
-                    want_half = (spans or not (fl & (1 << 13))) and not (fl & (1 << 20))   # (FXP_F_NEEDS_NONASCII programs keep the one-launch kernel)
+                    want_half = not (fl & (1 << 20))   # (FXP_F_NEEDS_NONASCII programs keep the one-launch kernel)
                     assert (prog.last_path() in (5, 6, 8)) == want_half, (pat, kind, spans, prog.last_path())
                 bad = np.nonzero(f != of)[0]
                 assert bad.size == 0, (pat, kind, spans, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]))
