@@ -756,7 +756,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 // segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 16 || Lr >= FX_LONG_NT_MIN)
+   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH == 8 || (CH == 16 && Lr >= FX_LONG_NT_MIN))
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
    load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
 
@@ -1809,9 +1809,9 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
             return hipGetLastError();
          }
       }
-      if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0)) {
+      if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0) || (CH == 4 && MODE == 0 && SCH == 1)) {
          constexpr int CHN = SCH;
-         if (CH == 8 && Lr != 256u) return hipErrorInvalidValue;   // (half rows: 256-byte rows only)
+         if (CH <= 8 && Lr != 32u * CH) return hipErrorInvalidValue;   // (half rows: rows of twice the tile's bytes only)
          const size_t lds = (size_t)4 * 64 * (spans ? fx_tile_cols<CH, true, true>() : fx_tile_cols<CH, false, true>()) * 16 + chain_bytes + map_lds +
                             ((FX_HALF4 != 0 && CH <= 8 && spans) ? 64 : 0);   // (+ the four shared end-of-row cells)
          const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, CHN, false, true>)

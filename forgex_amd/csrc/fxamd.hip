@@ -81,7 +81,8 @@ static void env_load() {
    {
       const char* v = std::getenv("FXAMD_HALF_SCH");
       // bit s: table scheme s (0 v_perm, 1 chain, 2 nibble) stages half rows; bit 3: long rows on the chain tables in 128-byte segments
-      e.half_sch = v && *v ? std::atoi(v) : 15;   // (test / experiment hook)
+      // bit 4: 128-byte rows on the chain tables in 64-byte halves
+      e.half_sch = v && *v ? std::atoi(v) : 31;   // (test / experiment hook)
    }
    g_env = e;
 }
@@ -546,7 +547,14 @@ struct PassOpts {
 //  default cache policy on the loads so that the second half meets its line in L2: 0.45 ms against 0.366 ms, gpurun call r04_c26)
 static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
    // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel; FXAMD_HALF_SCH: bit s = table scheme s takes half rows)
-   if (fx_env().no_half || row_len != 256 || scheme < 0 || scheme > 2 || ((fx_env().half_sch >> scheme) & 1) == 0) return false;
+   if (fx_env().no_half) return false;
+   // 128-byte rows on the chain tables: 64-byte halves (bit 4 of the hook).  The chain scheme's dependent LDS read per byte is latency-bound:
+   // four waves per SIMD on a 4 KB tile against the one-launch kernel's three (and class-level tables on pure-ASCII tiles instead of
+   // byte-level ones everywhere): the 17-state pattern over config 5's shard 0.743 -> 0.496 ms (gpurun call r04_c47).  With the v_perm
+   // tables the split lines cost more than the waves gain (config 5: 0.45 against 0.366 ms, see below).
+   if (row_len == 128 && scheme == 1 && (fx_env().half_sch & 16) != 0 && !(h.flags & FXP_F_NEEDS_NONASCII)) return true;
+   // (the nibble tables on 64-byte halves lose: `\d{3}-\d{4}` over config 5's shard 0.327 -> 0.366 ms, gpurun call r04_c48)
+   if (row_len != 256 || scheme < 0 || scheme > 2 || ((fx_env().half_sch >> scheme) & 1) == 0) return false;
    // A program whose every match needs a byte >= 0x80 is given text that holds such bytes: the half-row first pass would load every tile
    // only to defer it to the follow-up (config 4's pattern and text in 256-byte rows: 0.1135 ms against 0.0838 ms on the one-launch
    // kernel, which answers the pure-ASCII tiles of such programs with an OR of their words anyway; gpurun call r04_c38)
@@ -557,7 +565,7 @@ static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool span
 // nibble tables: half rows at three waves per SIMD, 0.487-0.493 -> 0.464-0.466 ms on config-3 rows, gpurun call r04_c44)
 static bool half_staging(int scheme, bool spans) { return spans || scheme != 0; }
 // `.match.` over 256-byte rows on the chain tables: the multi-pass pipeline with a half-row first pass too (fx_match_fast<8,...,LONG>)
-static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && half_rows(h, scheme, row_len, false); }
+static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && row_len == 256 && half_rows(h, scheme, row_len, false); }
 
 template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
@@ -651,7 +659,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    }
    // (rows longer than 256 bytes on the chain tables: 128-byte segments at four waves per SIMD -- fx_search_fast NOHALF; bit 3 of the hook)
    const bool long8 = CHAIN && (MODE == 0 || MODE == 2) && long_row(row_len) && (fx_env().half_sch & 8) != 0;
-   switch ((po.half || long8) ? 8 : chunks_of(row_len)) {
+   switch ((po.half || long8) ? (row_len == 128 ? 4 : 8) : chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_fast<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 3: return launch_fast<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);

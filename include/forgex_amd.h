@@ -185,7 +185,8 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * kernel on a stream under hipGraph capture); rows longer than 256 bytes on the chain tables: 7 or 5 / 6, walked in 128-byte segments.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
  * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_NO_TINY, FXAMD_NO_ADAPT, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,
- * FXAMD_HALF_SCH (bit s: table scheme s -- 0 v_perm, 1 chain, 2 nibble -- takes half rows; bit 3: 128-byte segments of long chain rows);
+ * FXAMD_HALF_SCH (bit s: table scheme s -- 0 v_perm, 1 chain, 2 nibble -- takes half rows; bit 3: 128-byte segments of long chain rows;
+ * bit 4: 128-byte rows on the chain tables in 64-byte halves);
  * grid experiments: FXAMD_ONE_GRID, FXAMD_ONE_ROUND_MB, FXAMD_ONE_BLOCKS, FXAMD_HALF_ROUNDS.  They are read once
  * per process; `fxamd_reload_env` of forgex_amd_bench.h reads them again.) */
 int fxamd_last_path(const fxamd_program* p);

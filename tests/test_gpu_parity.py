@@ -1702,49 +1702,57 @@ def test_many_patterns_from_several_streams_and_threads(fx):
 
 
 def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
-    """Round 4: 256-byte rows of programs on the chain tables and the nibble tables (spans and flags only) take the multi-pass pipeline
-    whose first pass stages HALF rows (four waves per SIMD; `last_path` 8 / 5 / 6) -- pure-ASCII batches, batches with UTF-8 tiles (the
-    byte-level pass over the tiles the first pass deferred) and with structurally broken rows (worklist), matches in either half, across the
-    half boundary, at the row's first and last byte -- against the oracle and against the one-launch kernel (FXAMD_HALF_SCH=1)."""
+    """Round 4: 256-byte rows of programs on the chain tables and the nibble tables (spans and flags only), and 128-byte rows of programs on
+    the chain tables, take the multi-pass pipeline whose first pass stages HALF rows (four waves per SIMD; `last_path` 8 / 5 / 6) --
+    pure-ASCII batches, batches with UTF-8 tiles (the byte-level pass over the tiles the first pass deferred) and with structurally broken
+    rows (worklist), matches in either half, across the half boundary, at the row's first and last byte -- against the oracle and against
+    the one-launch kernel (FXAMD_HALF_SCH=1)."""
     import random
     rng = random.Random(2300)
     nrng = np.random.default_rng(2300)
     alpha = np.frombuffer(b"abcdefghijkx0123456789-@._ comrgnt", dtype=np.uint8)
-    n, L = 64 * 37 + 11, 256
     seeds = [b"555-1234", b"bob@mail.org", b"2024-02-29", b"abcdef123abc de", b"abcdefk", "あいうアイウ123".encode(), b"carol@example.com"]
-    pats = [rb"\d{3}-\d{4}", rb"[a-z0-9]+@[a-z0-9]+\.[a-z]{2,4}", rb"[a-z]{6}\d{1,3}[a-z ]{6}", rb"\d{4}-\d{2}-\d{2}", "[ぁ-ん]{3}[ァ-ヶ]{3}\\d+".encode(), rb"^[a-k]{5}.*\d{2}$"]
-    for kind in ("ascii", "utf8", "broken"):
-        rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
-        for i in range(0, n, 3):
-            sd = np.frombuffer(seeds[(i // 3) % len(seeds)], dtype=np.uint8)
-            where = (i // 3) % 5
-            off = [0, L - len(sd), 128 - len(sd) // 2, rng.randint(0, 120 - len(sd)), rng.randint(130, L - len(sd))][where]
-            rows[i, off:off + len(sd)] = sd
-        if kind != "ascii":
-            for i in range(5, n, 11):   # a UTF-8 character somewhere (the tile is deferred to the byte-level pass)
-                c = np.frombuffer("んω€".encode(), dtype=np.uint8)
-                off = rng.randint(0, L - len(c))
-                rows[i, off:off + len(c)] = c
-        if kind == "broken":
-            for i in range(7, n, 29):
-                rows[i, rng.randint(0, L - 1)] = rng.choice([0x80, 0xC0, 0xFF, 0xE3])
-        for pat in pats:
-            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
-            for spans in (True, False):
-                monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
-                prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
-                fl = prog.info()["flags"]
-                if not (fl & 8) and (fl & ((1 << 13) | 256)):   # no 8-state tables; nibble tables (taken when present) or chain tables
-                    want_half = not (fl & (1 << 20))   # (FXP_F_NEEDS_NONASCII programs keep the one-launch kernel)
-                    assert (prog.last_path() in (5, 6, 8)) == want_half, (pat, kind, spans, prog.last_path())
-                bad = np.nonzero(f != of)[0]
-                assert bad.size == 0, (pat, kind, spans, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]))
-                if spans:
-                    assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, kind)
-                monkeypatch.setenv("FXAMD_HALF_SCH", "1")
-                prog2, f2, a2, b2 = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
-                assert prog2.last_path() not in (5, 6, 8) and np.array_equal(f2, of), (pat, kind, spans, prog2.last_path())
+    pats = [rb"\d{3}-\d{4}", rb"[a-z0-9]+@[a-z0-9]+\.[a-z]{2,4}", rb"[a-z]{6}\d{1,3}[a-z ]{6}", rb"\d{4}-\d{2}-\d{2}", "[ぁ-ん]{3}[ァ-ヶ]{3}\\d+".encode(), rb"^[a-k]{5}.*\d{2}$",
+            rb"(19|20)\d\d-(0[1-9]|1[012])-(0[1-9]|[12][0-9]|3[01])"]
+    n_half = {256: 0, 128: 0}
+    for L in (256, 128):
+        n = 64 * 37 + 11
+        H = L // 2
+        for kind in ("ascii", "utf8", "broken"):
+            rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+            for i in range(0, n, 3):
+                sd = np.frombuffer(seeds[(i // 3) % len(seeds)], dtype=np.uint8)
+                where = (i // 3) % 5
+                off = [0, L - len(sd), H - len(sd) // 2, rng.randint(0, H - 8 - len(sd)), rng.randint(H + 2, L - len(sd))][where]
+                rows[i, off:off + len(sd)] = sd
+            if kind != "ascii":
+                for i in range(5, n, 11):   # a UTF-8 character somewhere (the tile is deferred to the byte-level pass)
+                    c = np.frombuffer("んω€".encode(), dtype=np.uint8)
+                    off = rng.randint(0, L - len(c))
+                    rows[i, off:off + len(c)] = c
+            if kind == "broken":
+                for i in range(7, n, 29):
+                    rows[i, rng.randint(0, L - 1)] = rng.choice([0x80, 0xC0, 0xFF, 0xE3])
+            for pat in pats:
+                of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+                for spans in (True, False):
+                    monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+                    prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
+                    fl = prog.info()["flags"]
+                    if not (fl & 8) and (fl & ((1 << 13) | 256)):   # no 8-state tables; nibble tables (taken when present) or chain tables
+                        # (FXP_F_NEEDS_NONASCII programs keep the one-launch kernel; 128-byte rows: the chain tables only)
+                        want_half = not (fl & (1 << 20)) and (L == 256 or not (fl & (1 << 13)))
+                        assert (prog.last_path() in (5, 6, 8)) == want_half, (pat, L, kind, spans, prog.last_path())
+                        n_half[L] += 1 if want_half else 0
+                    bad = np.nonzero(f != of)[0]
+                    assert bad.size == 0, (pat, L, kind, spans, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]))
+                    if spans:
+                        assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L, kind)
+                    monkeypatch.setenv("FXAMD_HALF_SCH", "1")
+                    prog2, f2, a2, b2 = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
+                    assert prog2.last_path() not in (5, 6, 8) and np.array_equal(f2, of), (pat, L, kind, spans, prog2.last_path())
     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+    assert n_half[256] >= 24 and n_half[128] >= 12, n_half
 
 
 def test_match_half_rows_for_chain_tables(fx, monkeypatch):
