@@ -41,6 +41,8 @@ SHAPES = {
     "nibble_cfg3_flags": ("`\\d{3}-\\d{4}` `.in.` verdict (flags only) over config-3 rows (nibble tables)", "search", [r"\d{3}-\d{4}"], "cfg3", None, 10_000_000, False, False),
     "chain17_cfg3_flags": ("the 17-state pattern, `.in.` verdict (flags only) over config-3 rows (chain tables, half rows)", "search", [r"[a-z]{6}\d{1,3}[a-z ]{6}"], "cfg3", None, 10_000_000, False, False),
     "nibble_128":   ("`\\d{3}-\\d{4}` (nibble tables) `.in.` + spans over config 5's shard (12.5 M x 128 B)", "search", [r"\d{3}-\d{4}"], "cfg5", None, 12_500_000, False, True),
+    "chain17_64":   ("the 17-state pattern over config-3 bytes viewed as 40 M rows of 64 B", "search", [r"[a-z]{6}\d{1,3}[a-z ]{6}"], "cfg3", 64, 40_000_000, False, True),
+    "chain17_192":  ("the 17-state pattern over config-3 bytes viewed as rows of 192 B", "search", [r"[a-z]{6}\d{1,3}[a-z ]{6}"], "cfg3", 192, 13_333_333, False, True),
     "literal_cfg2": ("literal `foobar` `.in.` + spans over 16M x 64 B rows of config 2's generator (raw-byte INDEX on the tile kernel)", "search", ["foobar"], "cfg2", None, 16 << 20, False, True),
     "multi6_cfg3":  ("six 8-state patterns over config-3 rows in ONE pass (fx_search_multi)", "search",
                      [r"[a-z]+\d+", r"\d+[a-z]", r"[a-z]+ \d", r"q[a-z]*\d", r"\d\d+", r"[a-z]\d[a-z]"], "cfg3", None, 10_000_000, False, True),
