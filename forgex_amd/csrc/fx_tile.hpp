@@ -758,7 +758,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 #define PREFETCH_SEG(st, tn, sg, en) \
    load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH == 8 || (CH == 16 && Lr >= FX_LONG_NT_MIN))
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
-   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr))
+   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 4)
 
 // FIXUP = false: first pass over the caller's rows.  Tiles holding a byte >= 0x80 are not scanned here: with
 //                 FXP_F_FAST_UTF8 the whole tile is marked FX_NEEDS_GENERAL (flags) and left to the second pass, otherwise
@@ -1540,7 +1540,7 @@ __device__ __forceinline__ uint32_t match_gate(const FxpHeader* h, const uint8_t
 //  their one dependent LDS read per byte is latency-bound, `.match.` of a 23-state pattern over config-3 rows 0.94 -> 0.66 ms, profiles/r04_half_chain_ab.txt)
 //  NOHALF: rows longer than 256 bytes in 128-byte segments, chain tables -- as fx_search_fast's)
 template <int CH, int MODE, int SCH, bool RAGGED, bool LONG = false, bool NOHALF = false>
-__global__ __launch_bounds__(256, (LONG && CH == 8) ? 4 : 1) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
+__global__ __launch_bounds__(256, (LONG && CH <= 8) ? 4 : 1) void fx_match_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                        FastParams fp, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_deferred,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t* __restrict__ clear_next,
                                                        uint32_t* __restrict__ worklist) {
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8) ? 4 : 1) void fx_match_fast(
    constexpr uint32_t SEGB = 16u * CH;                       // bytes of one LDS tile row = one segment of a long row
    const uint32_t S = LONG ? ((Lr + SEGB - 1u) / SEGB) : 1u;   // LONG: segments per row (the last one shorter when Lr % SEGB != 0, at any byte), left to right
    constexpr bool ragged = RAGGED;
-   static_assert(!LONG || ((CH == 16 || CH == 8) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 (8: half rows), first-pass / byte-level modes");
+   static_assert(!LONG || ((CH == 16 || CH == 8 || CH == 4) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16 (8 / 4: half rows), first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
@@ -1886,13 +1886,13 @@ hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, F
       }
       if constexpr ((CH == 16 && (MODE == 0 || MODE == 2 || MODE == 3)) || (CH == 8 && MODE == 0 && SCH == 1)) {
          constexpr int CHN = SCH;
-         if (CH == 8 && Lr != 256u) return hipErrorInvalidValue;   // (half rows: 256-byte rows only)
+         if (CH == 8 && Lr != 256u) return hipErrorInvalidValue;   // (half rows: 256-byte rows only -- 128-byte rows in 64-byte halves gained 1.6 %: not dispatched)
          const void* fn = reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, CHN, false, true>);
          if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
-         if (CH == 8) {   // whole rounds of the four resident blocks per CU, as the half-row search kernel's grid
+         if (CH <= 8) {   // whole rounds of the four resident blocks per CU, as the half-row search kernel's grid
             int64_t rounds = (n * (int64_t)Lr) / ((int64_t)225 << 20);
             rounds = rounds < 3 ? 3 : (rounds > 64 ? 64 : rounds);
             blocks = (n_tiles + 3) / 4;

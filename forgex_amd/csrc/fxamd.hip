@@ -565,6 +565,7 @@ static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool span
 // nibble tables: half rows at three waves per SIMD, 0.487-0.493 -> 0.464-0.466 ms on config-3 rows, gpurun call r04_c44)
 static bool half_staging(int scheme, bool spans) { return spans || scheme != 0; }
 // `.match.` over 256-byte rows on the chain tables: the multi-pass pipeline with a half-row first pass too (fx_match_fast<8,...,LONG>)
+// (128-byte rows: `.match.` of a 23-state pattern over config 5's shard 0.4518 -> 0.4443 ms on 64-byte halves -- within a box's drift: not dispatched)
 static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && row_len == 256 && half_rows(h, scheme, row_len, false); }
 
 template <int MODE, int SCH>

@@ -1756,44 +1756,45 @@ def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
 
 
 def test_match_half_rows_for_chain_tables(fx, monkeypatch):
-    """Round 4: `.match.` over 256-byte rows of programs on the chain tables takes the multi-pass pipeline with a half-row first pass
-    (fx_match_fast<8,...,LONG>: four waves per SIMD; `last_path` 5 / 8) -- pure-ASCII batches, UTF-8 tiles (byte-level pass over the deferred
-    tiles), broken rows (worklist), rows that fail in the first / second half and at the last byte -- against the oracle and the one-launch
-    kernel (FXAMD_HALF_SCH=1)."""
+    """Round 4: `.match.` over 256-byte rows of programs on the chain tables takes the multi-pass pipeline with a half-row first
+    pass (fx_match_fast<8,...,LONG>: four waves per SIMD; `last_path` 5 / 8) -- pure-ASCII batches, UTF-8 tiles (byte-level pass over the
+    deferred tiles), broken rows (worklist), rows that fail in the first / second half and at the last byte -- against the oracle and the
+    one-launch kernel (FXAMD_HALF_SCH=1)."""
     import random
     rng = random.Random(2400)
     nrng = np.random.default_rng(2400)
-    n, L = 64 * 29 + 5, 256
     pats = [rb"[a-z ]{6}[a-z ]*\d{0,3}[a-z ]{6}[a-z ]*", rb"[a-z ]{12}[a-z ]*\d*[a-z ]{6}", "[a-zぁ-ん ]{9}[a-zぁ-ん ]*\\d{0,3}[a-z ω€]{8}[a-z ω€]*".encode()]
     alpha = np.frombuffer(b"abcdefghij klmnopqrstuvwxyz", dtype=np.uint8)
-    for kind in ("ascii", "utf8", "broken"):
-        rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
-        for i in range(0, n, 2):   # digits somewhere: a run of 1..3 (match), 4 (no match), two runs (no match)
-            off = [rng.randint(6, 120), rng.randint(130, 240), 126, L - 3][(i // 2) % 4]
-            k = [1, 3, 4, 2][(i // 2) % 4]
-            rows[i, off:off + k] = np.frombuffer(b"0123"[:k], dtype=np.uint8)
-            if (i // 2) % 7 == 0:
-                rows[i, 3:4] = ord("7")
-        if kind != "ascii":
-            for i in range(5, n, 9):
-                c = np.frombuffer("んω€".encode(), dtype=np.uint8)
-                off = rng.randint(0, L - len(c))
-                rows[i, off:off + len(c)] = c
-        if kind == "broken":
-            for i in range(7, n, 23):
-                rows[i, rng.randint(0, L - 1)] = rng.choice([0x80, 0xC0, 0xFF, 0xE3])
-        for pat in pats:
-            of, _, _ = oracle_lib.batch(1, pat, rows, NT)
-            monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
-            prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
-            assert prog.info()["flags"] & 256 and not prog.info()["flags"] & ((1 << 13) | 8), pat
-            assert prog.last_path() in (5, 8), (pat, kind, prog.last_path())
-            bad = np.nonzero(f != of)[0]
-            assert bad.size == 0, (pat, kind, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
-            assert 0 < int(of.sum()) < n, (pat, kind)
-            monkeypatch.setenv("FXAMD_HALF_SCH", "1")
-            prog2, f2, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
-            assert prog2.last_path() not in (5, 8) and np.array_equal(f2, of), (pat, kind, prog2.last_path())
+    for L in (256,):   # (128-byte rows keep the one-launch kernel: 64-byte halves gained 1.6 % for `.match.`)
+        n, H = 64 * 29 + 5, L // 2
+        for kind in ("ascii", "utf8", "broken"):
+            rows = alpha[nrng.integers(0, len(alpha), size=(n, L))].copy()
+            for i in range(0, n, 2):   # digits somewhere: a run of 1..3 (match), 4 (no match), two runs (no match)
+                off = [rng.randint(6, H - 8), rng.randint(H + 2, L - 16), H - 2, L - 3][(i // 2) % 4]
+                k = [1, 3, 4, 2][(i // 2) % 4]
+                rows[i, off:off + k] = np.frombuffer(b"0123"[:k], dtype=np.uint8)
+                if (i // 2) % 7 == 0:
+                    rows[i, 3:4] = ord("7")
+            if kind != "ascii":
+                for i in range(5, n, 9):
+                    c = np.frombuffer("んω€".encode(), dtype=np.uint8)
+                    off = rng.randint(0, L - len(c))
+                    rows[i, off:off + len(c)] = c
+            if kind == "broken":
+                for i in range(7, n, 23):
+                    rows[i, rng.randint(0, L - 1)] = rng.choice([0x80, 0xC0, 0xFF, 0xE3])
+            for pat in pats:
+                of, _, _ = oracle_lib.batch(1, pat, rows, NT)
+                monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
+                prog, f, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+                assert prog.info()["flags"] & 256 and not prog.info()["flags"] & ((1 << 13) | 8), pat
+                assert prog.last_path() in (5, 8), (pat, L, kind, prog.last_path())
+                bad = np.nonzero(f != of)[0]
+                assert bad.size == 0, (pat, L, kind, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]), rows[bad[0]].tobytes())
+                assert 0 < int(of.sum()) < n, (pat, L, kind)
+                monkeypatch.setenv("FXAMD_HALF_SCH", "1")
+                prog2, f2, _, _ = _device_run(fx, pat, fx.OP_MATCH, rows, spans=False)
+                assert prog2.last_path() not in (5, 8) and np.array_equal(f2, of), (pat, L, kind, prog2.last_path())
     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
 
 

@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 SHAPES = {
     "match_cfg3":   ("`.match.` `[a-z ]+\\d*[a-z ]*` over config-3 rows (8-state tables, one verdict byte per row)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg3", None, 10_000_000, False, False),
     "match_chain_cfg3": ("`.match.` `[a-z ]{6}[a-z ]*\\d{0,3}[a-z ]{6}[a-z ]*` (23 states: chain tables) over config-3 rows", "match", [r"[a-z ]{6}[a-z ]*\d{0,3}[a-z ]{6}[a-z ]*"], "cfg3", None, 10_000_000, False, False),
+    "match_chain_128": ("`.match.` of the 23-state pattern (chain tables) over config 5's shard (12.5 M x 128 B)", "match", [r"[a-z ]{6}[a-z ]*\d{0,3}[a-z ]{6}[a-z ]*"], "cfg5", None, 12_500_000, False, False),
     "match_cfg1x":  ("`.match.` `\\d{3}-\\d{4}` (config 1's pattern, nibble tables) over 64M x 8 B rows of config 1's generator", "match", [r"\d{3}-\d{4}"], "cfg1", None, 64_000_000, False, False),
     "match_cfg5":   ("`.match.` `[a-z ]+\\d*[a-z ]*` over config 5's shard (12.5 M x 128 B, 8-state tables)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg5", None, 12_500_000, False, False),
     "match_utf8":   ("`.match.` `[α-ωぁ-ん ]+` over config-4 rows (byte-level tables)", "match", ["[α-ωぁ-ん ]+"], "cfg4", None, 1 << 20, False, False),
