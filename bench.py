@@ -437,8 +437,8 @@ def main():
     L = forgex_amd.lib()
     stream = torch.cuda.current_stream(dev)
     reps = max(5, min(args.steps, 200))
-    one_launch = prog.last_path() in (9, 10, 11, 12, 13, 14)   # fx_search_one: the step IS one kernel launch
-    fast = one_launch or prog.last_path() in (1, 3, 5, 6, 7, 8, 16)
+    one_launch = prog.last_path() in (9, 10, 11, 12, 13, 14, 19)   # fx_search_one / fx_search_span with the general procedure inside: the step IS one kernel launch
+    fast = one_launch or prog.last_path() in (1, 3, 5, 6, 7, 8, 16, 18)
     whole_step = one_launch or cfg == "cfg4"   # multi-pass pipeline on non-ASCII rows: several passes share the work -> time the whole step
 
     def kernel_events(k, group=1):
@@ -480,6 +480,8 @@ def main():
             traffic = None
     if prog.last_path() == 16:   # 256- / 128-byte rows: first pass (the timed kernel; half-row staging when spans are asked for) + one gated follow-up
         kname = ("fx_search_fast<%d, true, 0, 0, false, true> (half-row staging)" % (row_len // 32)) if spans else "fx_search_fast<16, false, 0, 0, false, false>"
+    elif prog.last_path() in (18, 19):   # the span kernel (rows of 128 / 64 bytes: a lane owns 256 bytes of whole rows); 18: + one gated follow-up
+        kname = "fx_search_span<%d, %s, 0, %s>" % (row_len, "true" if spans else "false", "true" if prog.last_path() == 19 else "false")
     else:
         kname = ("fx_search_one<%d>" if one_launch else "fx_search_fast<%d>") % (row_len // 16)
     if whole_step and not one_launch:

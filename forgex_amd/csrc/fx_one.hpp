@@ -1450,7 +1450,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
 template <int CH, int BSCH>
 hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
                              uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate) {
-   static_assert(CH == 16 || CH == 8, "follow-up of the half-row first pass: 256- or 128-byte rows");
+   static_assert(CH == 16 || CH == 8 || CH == 4, "follow-up of the half-row first pass (256-byte rows) and of the span kernel (128- / 64-byte rows)");
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    const size_t static_b = 4096 + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64;
    const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;

@@ -22,7 +22,7 @@ FX_ONE_COMBOS_G(FX_Y, FX_INST_CH, true)
 #if FX_INST_CH <= 8   // (the many-pattern pass takes rows of up to 128 bytes: beyond, one pipeline per pattern is faster -- fxamd.hip)
 template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;
 #endif
-#if FX_INST_CH == 16
+#if FX_INST_CH == 16 || FX_INST_CH == 8 || FX_INST_CH == 4
 template hipError_t launch_one_marked<FX_INST_CH, 0> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<FX_INST_CH, 1> FX_ONE_MARKED_SIG;
 template hipError_t launch_one_marked<FX_INST_CH, 2> FX_ONE_MARKED_SIG;

@@ -19,6 +19,7 @@
 #include "../../include/forgex_amd_bench.h"
 #include "fx_multi.hpp"
 #include "fx_tiny.hpp"
+#include "fx_span.hpp"
 
 #ifndef FX_SINGLE_TU   // the launcher instantiations live in fx_tile_inst.hip (one object per chunk count)
 #define FX_X(CH, M, S)                                                  \
@@ -35,7 +36,15 @@ FX_ONE_ALL(FX_X)
    extern template hipError_t launch_one_marked<CH, 2> FX_ONE_MARKED_SIG;   \
    extern template hipError_t launch_one_marked<CH, 3> FX_ONE_MARKED_SIG;
 FX_Z(16)
+FX_Z(8)
+FX_Z(4)
 #undef FX_Z
+#define FX_S(RL, SCH)                                                  \
+   extern template hipError_t launch_span<RL, SCH, false> FX_SPAN_SIG;  \
+   extern template hipError_t launch_span<RL, SCH, true> FX_SPAN_SIG;
+FX_S(128, 0)
+FX_S(64, 0)
+#undef FX_S
 extern template hipError_t launch_multi<1> FX_MULTI_SIG;
 extern template hipError_t launch_multi<2> FX_MULTI_SIG;
 extern template hipError_t launch_multi<3> FX_MULTI_SIG;
@@ -61,6 +70,8 @@ static void env_load() {
    e.no_a8 = on("FXAMD_NO_A8");
    e.no_spec = on("FXAMD_NO_SPEC");
    e.no_tiny = on("FXAMD_NO_TINY");
+   e.no_span = on("FXAMD_NO_SPAN");
+   e.span_bytes = on("FXAMD_SPAN_BYTES");
    e.no_adapt = on("FXAMD_NO_ADAPT");
    e.multipass = on("FXAMD_MULTIPASS");
    e.no_cache = on("FXAMD_NO_CACHE");
@@ -774,6 +785,20 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
    return (h.flags & (sch == 0 ? FXP_F_FAST_UTF8 : (sch == 2 ? FXP_F_W16_UTF8 : FXP_F_CHAIN_UTF8))) != 0;
 }
 
+// The span kernel (fx_span.hpp; round 5): searches with spans over rows of 128 / 64 bytes on the 8-state tables.  0 = not its case,
+// 1 = first pass + ONE gated follow-up (programs whose class-level tables decode UTF-8: tiles with bytes >= 0x80 are marked for the
+// one-launch kernel's MARKED instantiation), 2 = GEN: one launch, rows the tables cannot answer walked by the general row procedure
+// inside it (candidate-list driver programs; FXAMD_SPAN_BYTES=1, experiment hook: also when the program has byte-level tables, which the
+// one-launch kernel would use on such tiles).  FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook).
+static int span_kind(const FxpHeader& h, int scheme, const uint8_t* d_rows, int64_t row_len, bool spans) {
+   if (!spans || scheme != 0 || (row_len != 128 && row_len != 64) || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) ||
+       fx_env().multipass || fx_env().no_span)
+      return 0;
+   if (scheme_decodes_utf8(h, scheme)) return 1;
+   if (one_bytes_scheme(h, d_rows, row_len, scheme) != 0 && !fx_env().span_bytes) return 0;   // (byte-level tables answer UTF-8 tiles: the one-launch kernel)
+   return 2;
+}
+
 // ---- the pipeline of one batch call, enqueued on `st` with the scratch set `sc` (p->mu held) ----------------------------------
 // out_mode != 0: PACKED results (d_flags = bit words, d_from / d_to = narrow arrays of out_mode bytes per row).  Only the one-launch
 // kernel writes them itself; for every other path the function returns FX_NOT_PACKED before anything is enqueued and the caller
@@ -858,8 +883,20 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          else if (cap != hipStreamCaptureStatusNone) half = false;
       }
       const bool as_long = long_row(row_len);
-      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !fx_env().multipass;
-      if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
+      // Rows of 128 / 64 bytes with spans on the 8-state tables (round 5, fx_span.hpp; BASELINE configs 5 and 2): a lane owns a 256-byte span
+      // of two / four whole rows -- the half-row kernel's memory path and four waves per SIMD.  Programs whose tables decode UTF-8: first pass
+      // + ONE gated follow-up over the tiles it marked (last_path 18; the counter groups alternate on the host, so a stream under hipGraph
+      // capture keeps the one-launch kernel); candidate-list driver programs: the general row procedure for the rows the tables cannot answer
+      // inside the same launch (GEN, last_path 19: no host-side state).  FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook).
+      int span_k = (first_pass == FX_FP_OWN && out_mode == 0u && !half && !tiny) ? span_kind(h, scheme, d_rows, row_len, d_from != nullptr && d_to != nullptr) : 0;
+      if (span_k == 1) {
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+         else if (cap != hipStreamCaptureStatusNone) span_k = 0;
+      }
+      const bool span = span_k != 0, span_gen = span_k == 2;
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !fx_env().multipass;
+      if (first_pass != FX_FP_DONE && !one_launch && !(span && span_gen)) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
@@ -883,6 +920,34 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          const bool gen = !utf8_tables;
          FX_HIP(launch_one_any(scheme, ob, gen, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode));
          p->last_path = (ob == 0 ? 9 : (scheme == 0 ? 10 : 11)) + (gen ? 3 : 0);
+         return FXAMD_OK;
+      }
+      if (span) {
+         FastParams fps = params_of(h, 0, false);
+         if (span_gen) {
+            FX_HIP(row_len == 128 ? (launch_span<128, 0, true>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st))
+                                  : (launch_span<64, 0, true>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st)));
+            p->last_path = 19;
+            return FXAMD_OK;
+         }
+         fps.defer_tiles = fx_env().no_adapt ? 1u : 3u;   // (bit 1: FX_ADAPT_CALLS -- batches that are mostly UTF-8 skip the first pass's loads)
+         FX_HIP(row_len == 128 ? (launch_span<128, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st))
+                               : (launch_span<64, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st)));
+         const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
+         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+         const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
+         const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
+#define FX_MARKED(CH)                                                                                                              \
+   {                                                                                                                                  \
+      if (ob == 3) FX_HIP((launch_one_marked<CH, 3>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));          \
+      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
+      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
+      else FX_HIP((launch_one_marked<CH, 0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));                  \
+   }
+         if (row_len == 128) FX_MARKED(8)
+         else FX_MARKED(4)
+#undef FX_MARKED
+         p->last_path = 18;
          return FXAMD_OK;
       }
       // worklist of the rows the tile kernels cannot answer: structurally invalid or non-canonical UTF-8 for the byte-level tables;
@@ -1318,6 +1383,13 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
    po.half = half_rows(h, scheme, row_len, d_from != nullptr) && half_staging(scheme, d_from != nullptr);
+   if (!po.half && span_kind(h, scheme, d_rows, row_len, d_from != nullptr) == 1) {   // the span kernel's first pass
+      FastParams fps = params_of(h, 0, false);
+      fps.defer_tiles = 1u;
+      FX_HIP(row_len == 128 ? (launch_span<128, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream))
+                            : (launch_span<64, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream)));
+      return FXAMD_OK;
+   }
    if (scheme != 0 && bytes && !po.half && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles
       po.worklist = sc->d_worklist;
       FX_HIP(fast_by<2>(bytes_scheme(h), h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, po));

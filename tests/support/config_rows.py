@@ -199,6 +199,149 @@ def crc_of(rows):
     return zlib.crc32(np.ascontiguousarray(rows).tobytes()) & 0xFFFFFFFF
 
 
+# ---- round 5: the kernels round 4 added, pinned to the REAL reference (VERDICT r04 "Next round" item 3) --------------------------------
+# (a) rows of 2..32 bytes (`fx_match_tiny` / `fx_search_tiny`, last_path 17; with spans: the one-launch kernel's ragged instantiations),
+# (b) chain- and nibble-table programs over 256- and 128-byte rows (half-row first passes on those tables), (c) a chain-table program
+# over rows of 400 and 1024 bytes (128-byte segments), (d) the speculative forward pass at 64 / 128 / 256 bytes: the match at the row's
+# first character, at its second, later, behind a broken sequence, nowhere.
+TINY_LENGTHS = [2, 3, 5, 8, 12, 20, 31, 32]
+TINY_ROWS = 576
+TINY_PATTERNS = [("M", "\\d+-?\\d*"), ("R", "[a-z]+\\d+"), ("R", "\\d+$")]
+
+
+def _tiny_rows(L, pi, n):
+    if L == 8 and pi == 0:   # BASELINE config 1's generator (its pattern is the section's)
+        return _cfg_rows("cfg1", list(range(5000, 5000 + n)))
+    alpha = [b"0123456789", b"0123456789-", b"abcdefghijklmnopqrstuvwxyz0123456789 ", b"abc  019", b"0123456789abc\n"]
+    rows = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        rng = _Rng(0x7469 + 64 * pi + L, i)
+        a = alpha[rng.next(len(alpha))]
+        b = bytearray(a[rng.next(len(a))] for _ in range(L))
+        k = rng.next(8)
+        if k == 0:
+            b[L - 1] = 48 + rng.next(10)           # a digit at the row's last byte
+        elif k == 1:
+            b[0] = 97 + rng.next(26)               # a letter at its first
+        elif k == 2 and L >= 3:
+            b[rng.next(L - 1)] = 45                # a '-'
+        elif k == 3:
+            b[rng.next(L)] = [0, 10, 13, 32, 9][rng.next(5)]
+        rows[i] = np.frombuffer(bytes(b), dtype=np.uint8)
+    return rows
+
+
+def tiny_sections():
+    out = []
+    for L in TINY_LENGTHS:
+        for pi, (op, pat) in enumerate(TINY_PATTERNS):
+            if L == 8 and pi == 0:
+                pat = synth.PATTERNS["cfg1"]
+            out.append(("tiny_%s%d_L%d" % (op, pi, L), op, pat, L, TINY_ROWS, lambda L=L, pi=pi: _tiny_rows(L, pi, TINY_ROWS)))
+    return out
+
+
+# chain tables only (17 / 23 states), nibble tables (`\d{3}-\d{4}` 10 / 9 states; the e-mail pattern's class-level automata fit them)
+TABLE_PATTERNS = [("R", "[a-z]{6}\\d{1,3}[a-z ]{6}"), ("M", "[a-z ]{6}[a-z ]*\\d{0,3}[a-z ]{6}[a-z ]*"), ("R", "\\d{3}-\\d{4}"),
+                  ("R", "[a-z0-9]+@[a-z0-9]+\\.[a-z]{2,4}")]
+TABLE_ROWS = 192
+_PLANTS = [b"123-4567", b"12-34567", b"999-0000x", b"ab@cd.com", b"x1@y2.org9", b"@a.bc", b"abcdef12ghijkl", b"abcdefg123 hijkl ", b"abcde1fghijk"]
+
+
+def _table_rows(L, pi, n):
+    cfg = "cfg3" if L == 256 else "cfg5"
+    base = _cfg_rows(cfg, [777000 + 1000 * pi + i for i in range(n)])
+    rows = base.copy()
+    for i in range(n):
+        rng = _Rng(0x7462 + 16 * pi + (L >> 7), i)
+        if pi == 1 and rng.next(2) == 0:      # `.match.` of the 23-state pattern: letters and blanks, at most one short digit run
+            b = bytearray(97 + rng.next(26) if rng.next(8) else 32 for _ in range(L))
+            if rng.next(3):
+                k = 6 + rng.next(L - 16)
+                for j in range(1 + rng.next(3 + rng.next(2))):
+                    b[k + j] = 48 + rng.next(10)
+            rows[i] = np.frombuffer(bytes(b), dtype=np.uint8)
+        elif rng.next(3) == 0:
+            pl = _PLANTS[rng.next(len(_PLANTS))]
+            k = rng.next(L - len(pl) + 1)
+            rows[i, k:k + len(pl)] = np.frombuffer(pl, dtype=np.uint8)
+    return rows
+
+
+def table_sections():
+    out = []
+    for pi, (op, pat) in enumerate(TABLE_PATTERNS):
+        for L in (256, 128):
+            out.append(("tab_p%d_L%d" % (pi, L), op, pat, L, TABLE_ROWS, lambda L=L, pi=pi: _table_rows(L, pi, TABLE_ROWS)))
+    return out
+
+
+LONG_CHAIN = [(400, 96), (1024, 48)]
+
+
+def _long_rows(L, n):
+    per = (L + 255) // 256
+    base = _cfg_rows("cfg3", [888000 + i for i in range(n * per)]).reshape(n, per * 256)[:, :L].copy()
+    for i in range(n):
+        rng = _Rng(0x6C6F + L, i)
+        if rng.next(2) == 0:   # a match of the 17-state pattern somewhere, also across the 128-byte segment borders
+            pl = _PLANTS[6 + rng.next(2)]
+            k = [rng.next(L - len(pl) + 1), 128 * (1 + rng.next((L >> 7) - 1)) - rng.next(len(pl)), L - len(pl)][rng.next(3)]
+            k = max(0, min(L - len(pl), k))
+            base[i, k:k + len(pl)] = np.frombuffer(pl, dtype=np.uint8)
+    return base
+
+
+def long_sections():
+    return [("long_chain_L%d" % L, "R", TABLE_PATTERNS[0][1], L, n, lambda L=L, n=n: _long_rows(L, n)) for L, n in LONG_CHAIN]
+
+
+SPEC_LENGTHS = [64, 128, 256]
+SPEC_ROWS = 256
+
+
+def _spec_rows(L, n):
+    base_idx = [300000 + 2 * i for i in range(n)]
+    a = _cfg_rows("cfg4", base_idx)
+    b = _cfg_rows("cfg4", [j + 1 for j in base_idx])
+    junk = [bytes([0x80]), bytes([0xE3, 0x81]), bytes([0xCE]), bytes([0xFF]), bytes([0xC0, 0xAF]), bytes([0xF0, 0x9F]), bytes([0xBF, 0xBF])]
+    rows = np.empty((n, L), dtype=np.uint8)
+    for i in range(n):
+        rng = _Rng(0x7370 + L, i)
+        text = bytes(a[i][:190]) + bytes(b[i][:190])
+        kind = rng.next(6)
+        if kind == 0:     # the match starts at the row's first character
+            row = text
+        elif kind == 1:   # ... at its second
+            row = bytes([97 + rng.next(26)]) + text
+        elif kind == 2:   # later
+            row = bytes(97 + rng.next(26) if rng.next(5) else 32 for _ in range(2 + rng.next(L // 2))) + text
+        elif kind == 3:   # behind a broken sequence
+            row = junk[rng.next(len(junk))] + text
+        elif kind == 4:   # a broken sequence ends it early; another match follows
+            k = 2 * (1 + rng.next(6))
+            row = text[:k] + junk[rng.next(len(junk))] + b"x" + text[k:]
+        else:             # nowhere
+            row = bytes(97 + rng.next(26) if rng.next(6) else [32, 10, 0][rng.next(3)] for _ in range(L))
+        rows[i] = np.frombuffer((row + b" " * L)[:L], dtype=np.uint8)
+    return rows
+
+
+def spec_sections():
+    return [("spec_L%d" % L, "R", synth.PATTERNS["cfg4"], L, SPEC_ROWS, lambda L=L: _spec_rows(L, SPEC_ROWS)) for L in SPEC_LENGTHS]
+
+
+_ROWS_CACHE = {}
+
+
+def _cached(name, getter):
+    def get():
+        if name not in _ROWS_CACHE:
+            _ROWS_CACHE[name] = getter()
+        return _ROWS_CACHE[name]
+    return get
+
+
 def all_sections():
     """(name, op, pattern, row_len, n_rows, rows-getter) of every batch section (the probes are per-record cases)."""
     out = []
@@ -206,7 +349,8 @@ def all_sections():
         out.append((nm, op, pat, L, len(idx), lambda nm=nm: config_section_rows(nm)))
     for nm, op, pat, L, idx in mutation_sections():
         out.append((nm, op, pat, L, len(idx), lambda nm=nm: mutation_section_rows(nm)))
-    return out
+    out += tiny_sections() + table_sections() + long_sections() + spec_sections()
+    return [(nm, op, pat, L, n, _cached(nm, g)) for nm, op, pat, L, n, g in out]
 
 
 def load_fixture(path):

@@ -44,7 +44,8 @@ fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 dom = None   # dominant kernel = the fx_* kernel with the largest fetched volume
 best = -1.0
 for (name, ctr), vals in fetch.items():
-    if ("fx_search_fast" in name or "fx_search_one" in name or "fx_general" in name or "fx_nfa" in name) and sum(vals) > best:
+    if ("fx_search_fast" in name or "fx_search_one" in name or "fx_search_span" in name or "fx_search_tiny" in name or "fx_match" in name or "fx_general" in name or
+            "fx_nfa" in name) and sum(vals) > best:
         dom, best = name, sum(vals)
 if dom:
     f = fetch.get((dom, "FETCH_SIZE"), [])
