@@ -3,14 +3,15 @@
 
 A "step" is ONE pass of the hot path over the resident batch: fxamd_match_batch_device (flags + (from,to) spans
 for every row) on BASELINE.json config 3 -- `[a-z]+\\d+` over 10M x 256 B synthetic rows, inputs already in HBM.
-With --gpus N each rank owns its own shard of an N-times larger batch (weak scaling, the default, no data-path collective);
-`--scaling strong` keeps the TOTAL at the config's row count (10M rows for config 3, as BASELINE.json's north star words it:
-"a 10M-string batch at 1, 2, 4 and 8 GPUs") and gives rank i the contiguous rows [i*N/W, (i+1)*N/W).  The packed-result gather
-over RCCL is timed separately and reported as `gather_ms`.
+With --gpus N > 1 the headline workload is what BASELINE.json's north star words: "a 10M-string synthetic batch at 1, 2, 4 and 8 GPUs" --
+config 3's 10M rows split into N contiguous shards, rank i = rows [i*N/W, (i+1)*N/W) (`"scaling": "strong"`, the default for config 3 since
+round 5; no data-path collective); the same run also times N x 10M rows (every rank its own config-sized shard) and reports it as
+`weak_scaling_extra`.  `--scaling weak` makes that the headline instead (the default of rounds 1-4), `--rows R` fixes the rows per rank.
+The packed-result gather over RCCL is timed separately and reported as `gather_ms`.
 
 Documented multi-GPU invocations (the driver's `--gpus N --steps K --warmup W` form is the first):
-    python bench.py --gpus 8                         weak scaling on config 3: 8 x 10M x 256 B
-    python bench.py --gpus 8 --scaling strong        config 3's 10M rows split over 8 GPUs
+    python bench.py --gpus 8                         config 3's 10M rows split over 8 GPUs (+ weak_scaling_extra: 8 x 10M rows)
+    python bench.py --gpus 8 --scaling weak          weak scaling on config 3: 8 x 10M x 256 B as the headline
     python bench.py --gpus 8 --config cfg5           BASELINE config 5: 100M x 128 B sharded over 8 GPUs + RCCL gather of the spans
 
 Launch: `python bench.py --gpus N` starts the N rank processes itself (one per GPU, RCCL rendezvous on 127.0.0.1) when no
@@ -307,8 +308,9 @@ def main():
                     help="untimed steps first; the clocks settle over the first ~20-30 back-to-back launches after an idle gap (DESIGN.md 4.1)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's size; cfg5: 12.5M)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every GPU scans its own config-sized shard; strong: the config's rows are split over the GPUs")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: every GPU scans its own config-sized shard; strong: the config's rows are split over the GPUs "
+                         "(default: strong for config 3 at --gpus > 1 -- the north star's 10M-string batch at 1, 2, 4, 8 GPUs --, else weak)")
     ap.add_argument("--flags-only", action="store_true", help="time the flags-only `.in.` entry instead of flags+spans")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the whole-batch host check (profiling runs)")
@@ -323,6 +325,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    scaling_defaulted = args.scaling is None
+    if scaling_defaulted:
+        args.scaling = "strong" if (world > 1 and args.config == "cfg3" and not args.rows) else "weak"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -433,11 +438,31 @@ def main():
         step()
     dt_settled = timed(args.steps)
 
+    # ---- multi-GPU runs of the north star's split batch: the weak-scaling figure (every rank its own config-sized shard) as a named extra ----
+    weak_extra = None
+    if world > 1 and args.scaling == "strong" and scaling_defaulted:
+        rows_w = synth.batch(cfg, rank * n_cfg, n_cfg, dev)
+        out_w = (torch.empty(n_cfg, dtype=torch.uint8, device=dev), torch.empty(n_cfg, dtype=torch.int32, device=dev) if spans else None,
+                 torch.empty(n_cfg, dtype=torch.int32, device=dev) if spans else None)
+        main_step = step
+
+        def step():   # noqa: F811 (timed() calls the module-level name)
+            prog.match_device(rows_w, spans=spans, out=out_w)
+        for _ in range(SETTLE):
+            step()
+        dt_w = timed(args.steps)
+        weak_extra = {"value": world * n_cfg * row_len * args.steps / dt_w / 1e9, "unit": "GB/s", "ms_per_step": dt_w / args.steps * 1e3, "rows_per_gpu": n_cfg,
+                      "rows_total": world * n_cfg, "scaling": "weak", "note": "every rank scans its own %d-row shard of a %d-times larger batch; same steps, settled clocks" % (n_cfg, world)}
+        step = main_step
+        del rows_w, out_w
+        step()   # (the handle's results of the headline shard again)
+        torch.cuda.synchronize()
+
     # ---- roofline leg: the dominant kernel alone, HIP events on its launch stream --------------------------------------------------
     L = forgex_amd.lib()
     stream = torch.cuda.current_stream(dev)
     reps = max(5, min(args.steps, 200))
-    one_launch = prog.last_path() in (9, 10, 11, 12, 13, 14, 19)   # fx_search_one / fx_search_span with the general procedure inside: the step IS one kernel launch
+    one_launch = prog.last_path() in (9, 10, 11, 12, 13, 14)   # fx_search_one: the step IS one kernel launch
     fast = one_launch or prog.last_path() in (1, 3, 5, 6, 7, 8, 16, 18)
     whole_step = one_launch or cfg == "cfg4"   # multi-pass pipeline on non-ASCII rows: several passes share the work -> time the whole step
 
@@ -480,8 +505,8 @@ def main():
             traffic = None
     if prog.last_path() == 16:   # 256- / 128-byte rows: first pass (the timed kernel; half-row staging when spans are asked for) + one gated follow-up
         kname = ("fx_search_fast<%d, true, 0, 0, false, true> (half-row staging)" % (row_len // 32)) if spans else "fx_search_fast<16, false, 0, 0, false, false>"
-    elif prog.last_path() in (18, 19):   # the span kernel (rows of 128 / 64 bytes: a lane owns 256 bytes of whole rows); 18: + one gated follow-up
-        kname = "fx_search_span<%d, %s, 0, %s>" % (row_len, "true" if spans else "false", "true" if prog.last_path() == 19 else "false")
+    elif prog.last_path() == 18:   # the span kernel (rows of 128 / 64 / 32 / 16 bytes: a lane owns 128 bytes of whole rows) + one gated follow-up
+        kname = "fx_search_span<%d, 0>" % row_len
     else:
         kname = ("fx_search_one<%d>" if one_launch else "fx_search_fast<%d>") % (row_len // 16)
     if whole_step and not one_launch:
@@ -590,14 +615,17 @@ def main():
             "metric": "input GB/s scanned (.in. over 10M strings)", "value": total_bytes / dt / 1e9, "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: `%s` .in. (flags%s) over %d x %d B rows per GPU, counter-based PRNG rows resident in HBM" % (
-                cfg, pattern, " + (from,to) spans" if spans else " only", rows_per_gpu, row_len),
+            "config": {"workload": ("%s: `%s` .in. (flags%s) over %d x %d B rows per GPU, counter-based PRNG rows resident in HBM" % (
+                cfg, pattern, " + (from,to) spans" if spans else " only", rows_per_gpu, row_len)) if not (world > 1 and args.scaling == "strong") else (
+                "%s: `%s` .in. (flags%s) over the config's %d x %d B rows split into %d contiguous shards (rank 0: %d rows), counter-based PRNG rows resident in HBM" % (
+                    cfg, pattern, " + (from,to) spans" if spans else " only", rows_all, row_len, world, rows_per_gpu)),
                 "rows_per_gpu": rows_per_gpu, "rows_total": rows_all, "row_len": row_len, "pattern": pattern, "parallelism": "shard%d" % world,
                 "outputs": "flag u8 + from/to int32" if spans else "flag u8", "matches_rank0": n_matches},
             "frac_of_hbm_peak": total_bytes / dt / 1e9 / (HBM_PEAK_GBS * world),
             "settled": {"value": total_bytes / dt_settled / 1e9, "ms_per_step": dt_settled / args.steps * 1e3,
                         "note": "the same %d timed steps after %d more untimed launches (clock transient over)" % (args.steps, SETTLE)},
             "roofline": roofline, "gather_ms": gather_ms, "packed_step_ms": packed_step_ms, "flags_only": flags_only, "host_path": host_path,
+            "weak_scaling_extra": weak_extra,
             # multi-GPU runs prove themselves: ranks and devices as the collectives saw them, every rank's own step time, the gather's bytes
             # what happened before the W warm-up steps (outside warm-up and timed region): the program's start-up, as a service does it once
             "init": {"rows": 64, "ms": init_ms, "what": "one match call on 64 generated rows (tables uploaded, code objects loaded) + fxamd_program_reserve, "

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
                cur = nxt;
             }
          }
-         const FastParams P{par[0], par[1], par[2], par[3], par[4], par[5], 0u, 0u, par[6], 0u};
+         const FastParams P{par[0], par[1], par[2], par[3], par[4], par[5], 0u, 0u, par[6], 0u, 0u};
          const int64_t base = (int64_t)par[7] * n;
          auto emit = [&](const int64_t r, const bool live, const bool, const uint32_t flag, const int32_t fr, const int32_t tt, const bool) {
             if (live) {

@@ -849,7 +849,8 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
 __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : 1))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
-                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr) {
+                                                       uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr,
+                                                       const uint8_t* __restrict__ marks = nullptr) {
    if (MARKED && blockIdx.x == 0 && threadIdx.x == 0) {
       // (FX_ADAPT_CALLS, fx_tile.hpp) the persistent word behind the two counter groups: count down while it is set, else look at what the
       // first pass sampled -- more than half of its tiles deferred sets it.  No other block of this kernel reads it; the next call's first
@@ -1090,7 +1091,9 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    uint64_t pend_mask = 0;     // lanes whose row of the last byte-level scan is an exception not yet queued (wave-uniform)
    uint32_t pend_row = 0;      // that row (per lane)
    // marked-tile mode: does tile t hold a row the first pass left behind (FX_NEEDS_GENERAL)?  wave-uniform
+   // (a first pass that writes PACKED results leaves a byte per 64-row tile in `marks` instead: the flag array holds bit words)
    auto tile_marked = [&](const int64_t t) -> bool {
+      if (marks != nullptr) return t < n_tiles && __builtin_amdgcn_readfirstlane((uint32_t)marks[t < n_tiles ? t : 0]) != 0u;
       const int64_t rr = (t << 6) + lane;
       return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
    };
@@ -1143,7 +1146,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
          row = (t << 6) + lane;
          row_ok = row < n;
          const bool process = live;
-         if (MARKED) hint = true;   // (that is why the first pass left the tile)
+         if (MARKED && !GEN) hint = true;   // (that is why the first pass left the tile; GEN: it may also be a row in the overlap state -- the sampled look decides as in a whole-batch launch)
          else if (!ALLB && !raw && (HAS_B || !GEN)) {
             // (ragged rows: the staging registers behind chunk nch - 1 were not loaded)
             const uint32_t smp = RAGGED ? (stage[0].x | stage[0].y | stage[0].w) : (stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z);
@@ -1428,7 +1431,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
          if (e != hipSuccess) return e;
       }
       cap_grid(fn);
-      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, (const uint32_t*)nullptr);
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, (const uint32_t*)nullptr, (const uint8_t*)nullptr);
       return hipGetLastError();
    };
    constexpr bool RAG_OK = (CH & (CH - 1)) == 0;   // ragged rows run on the power-of-two instantiations (fxamd.hip: one_chunks)
@@ -1446,30 +1449,38 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    return spans ? go(&fx_search_one<CH, true, SCH, BSCH, false, GEN>) : go(&fx_search_one<CH, false, SCH, BSCH, false, GEN>);
 }
 
-// the gated follow-up of the half-row first pass: 256-byte rows, 8-state class-level tables, marked tiles only
-template <int CH, int BSCH>
+// the gated follow-up of the half-row first pass (256-byte rows) and of the span kernel (fx_span.hpp: rows of 128 / 64 / 32 / 16 bytes, spans
+// only): 8-state class-level tables, marked tiles only.  GEN: programs whose class-level tables cannot decode UTF-8 (the general row
+// procedure for the rows the tables cannot answer, inside the launch)
+template <int CH, int BSCH, bool GEN>
 hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
-                             uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate) {
-   static_assert(CH == 16 || CH == 8 || CH == 4, "follow-up of the half-row first pass (256-byte rows) and of the span kernel (128- / 64-byte rows)");
+                             uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate, uint32_t out_mode, const uint8_t* marks) {
+   static_assert(CH == 16 || CH == 8 || CH == 4 || CH == 2 || CH == 1, "follow-up of the half-row first pass (256-byte rows) and of the span kernel");
+   static_assert(CH != 16 || !GEN, "the half-row pipeline is for programs whose tables decode");
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    const size_t static_b = 4096 + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64;
-   const uint32_t map_lds = (tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
+   const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;
    const int64_t n_tiles = (n + 63) >> 6;
    int64_t blocks = (n_tiles + 3) / 4;
    if (blocks > 256 * 2) blocks = 256 * 2;   // what is resident: an empty follow-up is one round of blocks that leave at once
    const bool spans = from && to;
-   const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_one<CH, true, 0, BSCH, false, false, true>)
-                          : reinterpret_cast<const void*>(&fx_search_one<CH, false, 0, BSCH, false, false, true>);
-   if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
+   auto go = [&](auto kern) -> hipError_t {
+      if (lds > 64 * 1024) {
+         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 16u * CH, out_mode, gate, marks);
+      return hipGetLastError();
+   };
+   if constexpr (BSCH == 3 && GEN) return hipErrorInvalidValue;   // (never dispatched: the speculative pass's table is for programs that decode)
+   else {
+      if (spans) return go(&fx_search_one<CH, true, 0, BSCH, false, GEN, true>);
+      if constexpr (CH == 16) return go(&fx_search_one<CH, false, 0, BSCH, false, GEN, true>);
+      return hipErrorInvalidValue;   // (the span kernel answers searches with spans only)
    }
-   if (spans) hipLaunchKernelGGL((fx_search_one<CH, true, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 16u * CH, 0u, gate);
-   else hipLaunchKernelGGL((fx_search_one<CH, false, 0, BSCH, false, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 16u * CH, 0u, gate);
-   return hipGetLastError();
 }
-#define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*)
+#define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*, uint32_t, const uint8_t*)
 
 // every (CH, SCH, BSCH, GEN) the dispatch code of fxamd.hip can ask for
 #define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 0, 3, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)

@@ -23,10 +23,10 @@
 // Test / experiment hooks (environment variables FXAMD_*), read ONCE per process -- the library's scalar callers make match calls in
 // loops, and a dozen getenv per enqueue is host time on their path.  fxamd_reload_env() (C ABI, tests only) reads them again.
 struct FxEnv {
-   bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, no_span, span_bytes, no_adapt, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
+   bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, no_span, no_pack_first, no_adapt, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
       host_register;
    int64_t slice_rows;                                      // rows per enqueue (a multiple of 64)
-   int one_grid, one_round_mb, one_blocks, half_rounds, half_sch;     // launch-grid experiments (0 = the built-in rule)
+   int one_grid, one_round_mb, one_blocks, half_rounds, half_sch, span_lens;     // launch-grid experiments (0 = the built-in rule)
 };
 const FxEnv& fx_env();   // (fxamd.hip)
 
@@ -301,15 +301,36 @@ __device__ __forceinline__ FxTail fx_tail_of(const uint32_t Lr) {
 // tile loads: CH (a power of two here: the dispatch rounds a ragged row's chunk count up to one) lanes share a row -- lane = (r0, k) =
 // (lane / CH, lane % CH) reads the 16 bytes at row byte 16k of row q * (64 / CH) + r0 in instruction q: voff = r0 * Lr + 16k per lane,
 // the rows' distance q * (64 / CH) * Lr in the scalar offset (the range check includes it).  Lanes whose chunk holds no text (k >= nch)
-// ask for an address behind the extent and fetch nothing.  The extent is the tile's bytes + 3: a dword is dropped whole when it
-// straddles the extent, and the last row's last dword does unless Lr % 4 == 0 (at most 3 bytes behind the batch's last row are read,
-// never used -- as in load_tile).
+// ask for an address behind the extent and fetch nothing.  The extent is the tile's bytes + 3 (a dword is dropped whole when it
+// straddles the extent, and the last row's last dword does unless Lr % 4 == 0) -- except for the batch's last tile, whose extent is exact
+// and whose straddling dword is rebuilt from byte loads (fx_patch_tail_piece): nothing behind the caller's last byte is read.
+// The batch's LAST tile gets its exact extent -- nothing behind the caller's last byte is read, whatever page it ends on -- and
+// the dword that straddles that extent, dropped whole by the range check, is rebuilt here from byte loads: `po` = this piece's offset in
+// the tile, `valid` = the tile's bytes.
+__device__ __forceinline__ void fx_patch_tail_piece(uint4& v, const uint8_t* __restrict__ tile_base, const uint32_t po, const uint32_t valid) {
+   uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+   for (int i = 0; i < 4; ++i) {
+      const uint32_t o = po + 4u * (uint32_t)i;
+      if (o < valid && o + 4u > valid) {
+         uint32_t r = 0;
+         for (uint32_t j = 0; o + j < valid; ++j) r |= (uint32_t)tile_base[o + j] << (8u * j);
+         w[i] = r;
+      }
+   }
+   v = make_uint4(w[0], w[1], w[2], w[3]);
+}
 template <int CH>
 __device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, const FxTail& T,
                                               bool enable = true) {
    static_assert((CH & (CH - 1)) == 0, "ragged rows: the chunk count of the instantiation is a power of two");
    const int64_t rows_left = n - row0;
-   const uint32_t valid = (!enable || rows_left <= 0) ? 0u : (rows_left >= 64 ? 64u : (uint32_t)rows_left) * T.Lr + 3u;
+   // (a tile that is followed by at least 3 more bytes of the batch reads up to 3 of them: the last row's last dword straddles the tile's end
+   //  unless Lr % 4 == 0; the batch's last tile -- wave-uniform -- ends its extent at the batch's last byte)
+   const uint32_t tile_bytes = rows_left <= 0 ? 0u : (rows_left >= 64 ? 64u : (uint32_t)rows_left) * T.Lr;
+   const int64_t room = rows_left > 64 ? (rows_left - 64) * (int64_t)T.Lr : 0;   // bytes of the batch behind this tile
+   const bool last_tile = room < 3;
+   const uint32_t valid = (!enable || rows_left <= 0) ? 0u : (last_tile ? tile_bytes + (uint32_t)room : tile_bytes + 3u);
    const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)row0 * (uint64_t)T.Lr;
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
@@ -322,6 +343,12 @@ __device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __r
    for (int q = 0; q < CH; ++q) {
       const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)q * step, FX_LOAD_AUX);
       v[q] = make_uint4(t.x, t.y, t.z, t.w);
+   }
+   if (enable && last_tile && tile_bytes != 0u && (T.Lr & 3u) != 0u) {   // (wave-uniform: the batch's last tile only)
+      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+         if (k < T.nch) fx_patch_tail_piece(v[q], tb8, voff + (uint32_t)q * step, valid);
    }
 }
 template <int CH>
@@ -417,6 +444,9 @@ struct FastParams {
    uint32_t lit_len;        // > 0: literal INDEX search (FXP_F_RAW_BYTES): no forward pass, the match is lit_len bytes from the start
    uint32_t spec;           // byte-level tables of fx_search_one: bit 0 = FXP_F_SPEC_FWD (the speculative forward pass from the row's first character is
                             // sound), bit 1 = FXP_F_NEEDS_NONASCII (a row without a byte >= 0x80 holds no match)
+   uint32_t out_mode;       // first passes that write PACKED results themselves (round 5: the half-row kernel of 256-byte rows, the span kernel):
+                            // 0 = flags u8[n], from / to int32[n]; 1 / 2 / 4 = flag bit words + spans of that many bytes, and "this 64-row tile is left
+                            // to the follow-up" goes to a byte per tile (`marks`) instead of the rows' flag bytes
 };
 
 // 8 independent table lookups for 8 bytes.  Three table schemes share the kernels (template parameter SCH):
@@ -833,7 +863,9 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       if (__builtin_amdgcn_readfirstlane(hintw[0]) != 0u) {   // mostly UTF-8 lately: every tile to the follow-up, unread
          for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
             const int64_t row = (t << 6) + lane;
-            if (row < n) flags[row] = FX_NEEDS_GENERAL;
+            if (HALFROW && MODE == 0 && SCH == 0 && SPANS && fp.out_mode != 0u) {
+               if (lane == 0) reinterpret_cast<uint8_t*>(worklist)[t] = 1u;
+            } else if (row < n) flags[row] = FX_NEEDS_GENERAL;
          }
          if (lane == 0) n_deferred[0] = 1u;
          return;
@@ -932,6 +964,11 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
    };
    const uint32_t list_count = LIST ? n_deferred[1] : 0u;
+   // PACKED results straight from the half-row first pass (round 5): the tile's flag word is the wave's ballot, spans are stored narrow,
+   // and a deferred tile is recorded in a byte per tile (the follow-up reads those instead of the rows' flag bytes)
+   constexpr bool PACK_OK = HALFROW && MODE == 0 && SCH == 0 && SPANS && !DEFER;
+   const uint32_t out_mode = PACK_OK ? fp.out_mode : 0u;
+   uint8_t* const marks = reinterpret_cast<uint8_t*>(worklist);   // (packed calls only: the half-row first pass lists no rows)
    // Forward pass over the symbol stream of one row from text index j (state `cur`, 0 = this lane does not walk): first 32 symbols
    // straight-line -- five aligned 8-byte row reads, a byte shift to start exactly at j, all 32 table lookups issued before the
    // chain; per 8-byte group only "any accept" (v_max3) + entry state are kept and the last accepting group is re-walked for the
@@ -1100,7 +1137,9 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
             if (!process) return;
          }
          if (defer_early) {
-            if (row_ok) flags[row] = FX_NEEDS_GENERAL;
+            if (PACK_OK && out_mode != 0u) {
+               if (lane == 0) marks[t] = 1u;
+            } else if (row_ok) flags[row] = FX_NEEDS_GENERAL;
             any_deferred = true;
             n_def += 1u;
             return;
@@ -1345,7 +1384,26 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       if (nonascii) flag = FX_NEEDS_GENERAL;
       any_deferred = any_deferred || defer_tile;
       n_def += defer_tile ? 1u : 0u;
-      if (row_ok) {
+      if (PACK_OK && out_mode != 0u) {
+         // (a deferred tile's word is written by the follow-up; rows behind the batch's end contribute a zero bit)
+         const uint64_t m = __builtin_amdgcn_ballot_w64(row_ok && flag == 1u);
+         if (lane == 0) {
+            marks[t] = defer_tile ? 1u : 0u;
+            if (!defer_tile) reinterpret_cast<uint64_t*>(flags)[t] = m;
+         }
+         if (row_ok && !defer_tile) {
+            if (out_mode == 1u) {
+               reinterpret_cast<uint8_t*>(from)[row] = (uint8_t)fr;
+               reinterpret_cast<uint8_t*>(to)[row] = (uint8_t)tt;
+            } else if (out_mode == 2u) {
+               reinterpret_cast<uint16_t*>(from)[row] = (uint16_t)fr;
+               reinterpret_cast<uint16_t*>(to)[row] = (uint16_t)tt;
+            } else {
+               from[row] = fr;
+               to[row] = tt;
+            }
+         }
+      } else if (row_ok) {
          flags[row] = (uint8_t)flag;
          if (SPANS && !queued) {
             from[row] = fr;

@@ -22,11 +22,20 @@ FX_ONE_COMBOS_G(FX_Y, FX_INST_CH, true)
 #if FX_INST_CH <= 8   // (the many-pattern pass takes rows of up to 128 bytes: beyond, one pipeline per pattern is faster -- fxamd.hip)
 template hipError_t launch_multi<FX_INST_CH> FX_MULTI_SIG;
 #endif
-#if FX_INST_CH == 16 || FX_INST_CH == 8 || FX_INST_CH == 4
-template hipError_t launch_one_marked<FX_INST_CH, 0> FX_ONE_MARKED_SIG;
-template hipError_t launch_one_marked<FX_INST_CH, 1> FX_ONE_MARKED_SIG;
-template hipError_t launch_one_marked<FX_INST_CH, 2> FX_ONE_MARKED_SIG;
-template hipError_t launch_one_marked<FX_INST_CH, 3> FX_ONE_MARKED_SIG;
+#if FX_INST_CH == 16
+template hipError_t launch_one_marked<FX_INST_CH, 0, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 1, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 2, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 3, false> FX_ONE_MARKED_SIG;
+#endif
+#if FX_INST_CH == 8 || FX_INST_CH == 4 || FX_INST_CH == 2 || FX_INST_CH == 1   // (the span kernel's follow-ups)
+template hipError_t launch_one_marked<FX_INST_CH, 0, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 1, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 2, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 3, false> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 0, true> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 1, true> FX_ONE_MARKED_SIG;
+template hipError_t launch_one_marked<FX_INST_CH, 2, true> FX_ONE_MARKED_SIG;
 #endif
 #endif
 #undef FX_Y

@@ -33,19 +33,28 @@ __device__ __forceinline__ void fx_tiny_load(uint4 (&stage)[4], const uint8_t* _
    using T = FxTiny<L>;
    const int64_t off0 = t * (int64_t)(64 * T::LS);
    const int64_t left = total - off0;
-   // (+3: a dword is dropped whole when it straddles the extent, and with rows that are not a multiple of 4 bytes the batch's last
-   //  dword may -- at most 3 bytes behind the batch's last row are read, never used: as in load_tile)
-   const uint32_t valid = left <= 0 ? 0u : (uint32_t)(left >= 64 * T::LS ? 64 * T::LS : left) + (L % 4 == 0 ? 0u : 3u);
-   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)off0;
+   // (a dword is dropped whole when it straddles the extent, and with rows that are not a multiple of 4 bytes a span's last dword may: a
+   //  tile that is followed by another gets 3 more bytes of extent; the batch's LAST tile gets its exact extent and the straddling dword
+   //  is rebuilt from byte loads -- nothing behind the caller's last byte is read)
+   const uint32_t tile_bytes = left <= 0 ? 0u : (uint32_t)(left >= 64 * T::LS ? 64 * T::LS : left);
+   const int64_t room = left > 64 * T::LS ? left - 64 * T::LS : 0;   // bytes of the batch behind this tile
+   const bool last_tile = room < 3;                                  // wave-uniform
+   const uint32_t valid = left <= 0 ? 0u : (L % 4 == 0 ? tile_bytes : (last_tile ? tile_bytes + (uint32_t)room : tile_bytes + 3u));
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)(left > 0 ? off0 : 0);
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
                                                                          __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+   const bool fix = L % 4 != 0 && last_tile && (valid & 3u) != 0u;   // (LS == 64: pieces are dword-aligned in the tile, the extent is not)
+   const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
    if constexpr (T::LS == 64) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
          const fx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + (uint32_t)q * 1024u, 0, FX_LOAD_AUX);
          stage[q] = make_uint4(v.x, v.y, v.z, v.w);
       }
+      if (fix)
+#pragma unroll
+         for (int q = 0; q < 4; ++q) fx_patch_tail_piece(stage[q], tb8, lane * 16u + (uint32_t)q * 1024u, valid);
    } else {
       const uint32_t r0 = lane >> 2, k = lane & 3u;   // four lanes per span, sixteen spans per instruction
       const uint32_t voff = k < (uint32_t)T::NCH ? r0 * (uint32_t)T::LS + 16u * k : 0x7FFFFFF0u;
@@ -54,6 +63,9 @@ __device__ __forceinline__ void fx_tiny_load(uint4 (&stage)[4], const uint8_t* _
          const fx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)(q * 16 * T::LS), FX_LOAD_AUX);
          stage[q] = make_uint4(v.x, v.y, v.z, v.w);
       }
+      if (L % 4 != 0 && last_tile && tile_bytes != 0u && k < (uint32_t)T::NCH)
+#pragma unroll
+         for (int q = 0; q < 4; ++q) fx_patch_tail_piece(stage[q], tb8, voff + (uint32_t)(q * 16 * T::LS), valid);
    }
 }
 template <int L>
@@ -94,7 +106,8 @@ template <int L>
 __device__ __forceinline__ void fx_tiny_emit(uint8_t* __restrict__ flags, const int64_t row_first, const int64_t n, const uint32_t (&out)[(FxTiny<L>::RPL + 3) / 4]) {
    constexpr int RPL = FxTiny<L>::RPL;
    if constexpr (RPL == 2 || RPL == 4 || RPL == 8 || RPL == 16) {
-      if (row_first + RPL <= n) {
+      // (one wide store only where it is aligned: result set i of a many-pattern call starts at flags + i * n -- wave-uniform)
+      if (row_first + RPL <= n && (reinterpret_cast<uintptr_t>(flags) & (uintptr_t)(RPL - 1)) == 0) {
          uint8_t* dst = flags + row_first;
          if constexpr (RPL == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)out[0];
          else if constexpr (RPL == 4) *reinterpret_cast<uint32_t*>(dst) = out[0];

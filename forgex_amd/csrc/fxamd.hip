@@ -30,21 +30,21 @@ FX_TILE_ALL(FX_X)
 #define FX_X(CH, S, B, G) extern template hipError_t launch_one<CH, S, B, G> FX_ONE_SIG;
 FX_ONE_ALL(FX_X)
 #undef FX_X
-#define FX_Z(CH)                                                            \
-   extern template hipError_t launch_one_marked<CH, 0> FX_ONE_MARKED_SIG;   \
-   extern template hipError_t launch_one_marked<CH, 1> FX_ONE_MARKED_SIG;   \
-   extern template hipError_t launch_one_marked<CH, 2> FX_ONE_MARKED_SIG;   \
-   extern template hipError_t launch_one_marked<CH, 3> FX_ONE_MARKED_SIG;
-FX_Z(16)
-FX_Z(8)
-FX_Z(4)
+#define FX_Z(CH, G)                                                            \
+   extern template hipError_t launch_one_marked<CH, 0, G> FX_ONE_MARKED_SIG;   \
+   extern template hipError_t launch_one_marked<CH, 1, G> FX_ONE_MARKED_SIG;   \
+   extern template hipError_t launch_one_marked<CH, 2, G> FX_ONE_MARKED_SIG;
+FX_Z(16, false) FX_Z(8, false) FX_Z(4, false) FX_Z(2, false) FX_Z(1, false) FX_Z(8, true) FX_Z(4, true) FX_Z(2, true) FX_Z(1, true)
 #undef FX_Z
-#define FX_S(RL, SCH)                                                  \
-   extern template hipError_t launch_span<RL, SCH, false> FX_SPAN_SIG;  \
-   extern template hipError_t launch_span<RL, SCH, true> FX_SPAN_SIG;
-FX_S(128, 0)
-FX_S(64, 0)
-#undef FX_S
+extern template hipError_t launch_one_marked<16, 3, false> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<8, 3, false> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<4, 3, false> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<2, 3, false> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_one_marked<1, 3, false> FX_ONE_MARKED_SIG;
+extern template hipError_t launch_span<128, 0> FX_SPAN_SIG;
+extern template hipError_t launch_span<64, 0> FX_SPAN_SIG;
+extern template hipError_t launch_span<32, 0> FX_SPAN_SIG;
+extern template hipError_t launch_span<16, 0> FX_SPAN_SIG;
 extern template hipError_t launch_multi<1> FX_MULTI_SIG;
 extern template hipError_t launch_multi<2> FX_MULTI_SIG;
 extern template hipError_t launch_multi<3> FX_MULTI_SIG;
@@ -54,6 +54,9 @@ extern template hipError_t launch_multi<8> FX_MULTI_SIG;
 #endif
 
 // ---- test / experiment hooks: the FXAMD_* environment variables, read once (FxEnv, fx_tile.hpp) ----
+#ifndef FX_SPAN_LENS_DEFAULT
+#define FX_SPAN_LENS_DEFAULT 15   // row lengths the span kernel takes by default (bit mask: 128, 64, 32, 16)
+#endif
 static FxEnv g_env;
 static std::once_flag g_env_once;
 static void env_load() {
@@ -71,7 +74,8 @@ static void env_load() {
    e.no_spec = on("FXAMD_NO_SPEC");
    e.no_tiny = on("FXAMD_NO_TINY");
    e.no_span = on("FXAMD_NO_SPAN");
-   e.span_bytes = on("FXAMD_SPAN_BYTES");
+   e.no_pack_first = on("FXAMD_NO_PACK_FIRST");
+   e.span_lens = std::getenv("FXAMD_SPAN_LENS") ? std::atoi(std::getenv("FXAMD_SPAN_LENS")) : FX_SPAN_LENS_DEFAULT;
    e.no_adapt = on("FXAMD_NO_ADAPT");
    e.multipass = on("FXAMD_MULTIPASS");
    e.no_cache = on("FXAMD_NO_CACHE");
@@ -548,6 +552,7 @@ struct PassOpts {
    uint32_t* worklist = nullptr;   // BYTES passes append exception rows, the worklist decode pass (MODE 4) reads them
    int64_t grid_tiles = 0;         // MODE 4: upper bound of the worklist's tiles (the count itself lives on the device)
    bool half = false;              // first pass over 256-byte rows with the 8-state tables: stage HALF rows (CH = 8 segment walker)
+   uint32_t out_mode = 0;          // the half-row first pass writes PACKED results (marks in `worklist`'s memory)
 };
 // 256-byte rows: the multi-pass pipeline whose first pass stages HALF rows (8 KB of LDS per wave: four waves per SIMD instead of two).
 // Round 2: the 8-state v_perm tables.  Round 4: the chain tables (one dependent LDS read per byte: latency-bound, so twice the waves is
@@ -586,7 +591,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TA_bytes : h.chain_TA_bytes) + 15u) & ~15u) : 0u;
-   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, 0u, po.defer_tiles, po.gate_word, 0, 0};
+   FastParams fp{0, BYTES ? h.byte_A_init : (CHAIN ? h.chain_A_init : h.fast_A_init * 0x01010101u), 0, 0, BYTES ? h.byte_inv_A : 0u, 0u, po.defer_tiles, po.gate_word, 0, 0, 0};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
       fp.inv = BYTES ? h.bw16_inv_A : 0u;
@@ -646,7 +651,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
    const uint32_t chain_bytes = CHAIN ? ((512u + (BYTES ? h.byte_TR_bytes + h.byte_TA_bytes : h.chain_TR_bytes + h.chain_TA_bytes) + 15u) & ~15u) : 0u;
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 0u, 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u, 0u};
+                 0u, 0u, po.defer_tiles, po.gate_word, h.mode == FXP_MODE_SEARCH_LITERAL ? h.len_all : 0u, 0u, po.out_mode};
    if (WIDE) {   // encoded state bytes, replicated like the 8-state scheme's
       fp.R_start = BYTES ? h.bw16_R_start : h.w16_R_start;
       fp.A_init = BYTES ? h.bw16_A_init : h.w16_A_init;
@@ -687,7 +692,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
 // FastParams of one table family: class-level tables of scheme `sch`, or (bytes) the byte-level tables in the chain / wide format
 static FastParams params_of(const FxpHeader& h, int sch, bool bytes) {
    FastParams fp{h.fast_R_start * 0x01010101u, h.fast_A_init * 0x01010101u, h.fast_hitR_min * 0x01010101u, h.fast_accA_min * 0x01010101u,
-                 0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u, 0u};
+                 0u, 0u, 0u, 0u, (!bytes && h.mode == FXP_MODE_SEARCH_LITERAL) ? h.len_all : 0u, 0u, 0u};
    if (sch == 3) {   // byte-level tables, FXP_F_BYTE_A8: nibble format backwards, 8-state v_perm format (replicated state bytes) forwards
       fp = params_of(h, 2, true);
       fp.A_init = h.b8_A_init * 0x01010101u;
@@ -725,7 +730,7 @@ template <int SCH, int BSCH, bool GEN>
 static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len, uint8_t* d_flags,
                                 int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode) {
    const bool is_match = h.mode == FXP_MODE_MATCH_ENGINE;
-   const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+   const FastParams fp = params_of(h, SCH, false), fpb = BSCH != 0 ? params_of(h, BSCH, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
    const uint32_t class_map_bytes = (1024u + h.n_pages * 64u) * 2u;
    const uint32_t table_bytes = (SCH == 1 ? ((512u + h.chain_TR_bytes + h.chain_TA_bytes + 15u) & ~15u) : 0u) +
                                 (BSCH == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u);
@@ -785,18 +790,21 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
    return (h.flags & (sch == 0 ? FXP_F_FAST_UTF8 : (sch == 2 ? FXP_F_W16_UTF8 : FXP_F_CHAIN_UTF8))) != 0;
 }
 
-// The span kernel (fx_span.hpp; round 5): searches with spans over rows of 128 / 64 bytes on the 8-state tables.  0 = not its case,
-// 1 = first pass + ONE gated follow-up (programs whose class-level tables decode UTF-8: tiles with bytes >= 0x80 are marked for the
-// one-launch kernel's MARKED instantiation), 2 = GEN: one launch, rows the tables cannot answer walked by the general row procedure
-// inside it (candidate-list driver programs; FXAMD_SPAN_BYTES=1, experiment hook: also when the program has byte-level tables, which the
-// one-launch kernel would use on such tiles).  FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook).
-static int span_kind(const FxpHeader& h, int scheme, const uint8_t* d_rows, int64_t row_len, bool spans) {
-   if (!spans || scheme != 0 || (row_len != 128 && row_len != 64) || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) ||
-       fx_env().multipass || fx_env().no_span)
-      return 0;
-   if (scheme_decodes_utf8(h, scheme)) return 1;
-   if (one_bytes_scheme(h, d_rows, row_len, scheme) != 0 && !fx_env().span_bytes) return 0;   // (byte-level tables answer UTF-8 tiles: the one-launch kernel)
-   return 2;
+// The span kernel (fx_span.hpp; round 5): searches with spans over rows of 128 / 64 / 32 / 16 bytes on the 8-state tables -- first pass + ONE
+// gated follow-up (the one-launch kernel's MARKED instantiation over the tiles the first pass marked: bytes >= 0x80, rows in the overlap
+// state of a bordered prefix literal).  Measured against the one-launch kernel in one allocation (gpurun call r05_c4): config 5's shard
+// 0.372 -> 0.342 ms; `[a-z]+\d+` over config-5 bytes viewed as rows of 64 / 32 / 16 B (one row in 4 / 8 / 16 matches) 0.454 -> 0.362,
+// 0.722 -> 0.410, 0.970 -> 0.516 ms.  NOT for candidate-list driver programs on rows of up to 64 bytes: their matches are sparse (a
+// literal prefix), and there the one-launch kernel's match compaction -- 64 gathered rows per finish pass ACROSS tiles -- beats one
+// finish pass per 8 KB tile (BASELINE config 2, one row in ten matching: 18.2 us against 19.5 us + 1.6 us of follow-up launch).
+// FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook); FXAMD_SPAN_LENS: bit mask of the row lengths it takes (1: 128, 2: 64,
+// 4: 32, 8: 16; +16: candidate-list driver programs at every length; experiment hook).
+static bool span_kind(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
+   if (!spans || scheme != 0 || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) || fx_env().multipass || fx_env().no_span)
+      return false;
+   const int lens = fx_env().span_lens;
+   if (row_len != 128 && (h.flags & FXP_F_PREFILTER) && !(lens & 16)) return false;
+   return (row_len == 128 && (lens & 1)) || (row_len == 64 && (lens & 2)) || (row_len == 32 && (lens & 4)) || (row_len == 16 && (lens & 8));
 }
 
 // ---- the pipeline of one batch call, enqueued on `st` with the scratch set `sc` (p->mu held) ----------------------------------
@@ -820,10 +828,17 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
                          SharedFirstPass* shared = nullptr) {
    const FxpHeader& h = p->prog.hdr();
    if (out_mode != 0u) {
+      // who writes packed results itself: the one-launch kernel; round 5: the half-row first pass of 256-byte rows (8-state tables, spans) and
+      // the span kernel, each with its follow-up (the first pass leaves a byte per deferred tile where the unpacked form marks the rows' flags)
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
+      const bool spans_p = d_from != nullptr && d_to != nullptr;
+      const bool half0 = sc0 == 0 && h.mode == FXP_MODE_SEARCH_ENGINE && spans_p && row_len == 256 && half_rows(h, sc0, row_len, true) && scheme_decodes_utf8(h, sc0) &&
+                         first_pass == FX_FP_OWN && !fx_env().no_pack_first;
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(h, sc0, row_len) : !half_rows(h, sc0, row_len, d_from != nullptr)) && !fx_env().multipass;
+                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(h, sc0, row_len) : (!half_rows(h, sc0, row_len, d_from != nullptr) || half0)) &&
+                       !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
+      // (FXAMD_NO_PACK_FIRST=1, test / A-B hook: 256-byte rows unpacked + fx_pack, the span kernel's rows packed by the one-launch kernel -- as before round 5)
    }
    const unsigned gblocks = (unsigned)((n + 255) / 256);
    const bool aligned16 = (reinterpret_cast<uintptr_t>(d_rows) & 15u) == 0 && (row_len & 15) == 0 && row_len > 0;
@@ -888,15 +903,15 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // + ONE gated follow-up over the tiles it marked (last_path 18; the counter groups alternate on the host, so a stream under hipGraph
       // capture keeps the one-launch kernel); candidate-list driver programs: the general row procedure for the rows the tables cannot answer
       // inside the same launch (GEN, last_path 19: no host-side state).  FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook).
-      int span_k = (first_pass == FX_FP_OWN && out_mode == 0u && !half && !tiny) ? span_kind(h, scheme, d_rows, row_len, d_from != nullptr && d_to != nullptr) : 0;
-      if (span_k == 1) {
+      bool span = first_pass == FX_FP_OWN && (out_mode == 0u || (out_mode == 1u && !fx_env().no_pack_first)) && !half && !tiny &&
+                  span_kind(h, scheme, row_len, d_from != nullptr && d_to != nullptr);
+      if (span) {   // (a stream under hipGraph capture keeps the one-launch kernel: the counter groups alternate on the host)
          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-         else if (cap != hipStreamCaptureStatusNone) span_k = 0;
+         else if (cap != hipStreamCaptureStatusNone) span = false;
       }
-      const bool span = span_k != 0, span_gen = span_k == 2;
       const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !fx_env().multipass;
-      if (first_pass != FX_FP_DONE && !one_launch && !(span && span_gen)) sc->parity ^= 1u;
+      if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
@@ -924,29 +939,42 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       }
       if (span) {
          FastParams fps = params_of(h, 0, false);
-         if (span_gen) {
-            FX_HIP(row_len == 128 ? (launch_span<128, 0, true>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st))
-                                  : (launch_span<64, 0, true>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st)));
-            p->last_path = 19;
-            return FXAMD_OK;
+         fps.defer_tiles = (fx_env().no_adapt || !utf8_tables) ? 1u : 3u;   // (bit 1: FX_ADAPT_CALLS -- batches that are mostly UTF-8 skip the first pass's loads)
+         fps.out_mode = out_mode;
+         uint8_t* marks = nullptr;
+         if (out_mode != 0u) {   // packed results: a byte per 64-row tile says "left to the follow-up" (in the worklist's memory: this pipeline lists no rows)
+            const int rcw = grow_worklist(sc, (n >> 8) + 64);
+            if (rcw != FXAMD_OK) return rcw;
+            marks = reinterpret_cast<uint8_t*>(sc->d_worklist);
          }
-         fps.defer_tiles = fx_env().no_adapt ? 1u : 3u;   // (bit 1: FX_ADAPT_CALLS -- batches that are mostly UTF-8 skip the first pass's loads)
-         FX_HIP(row_len == 128 ? (launch_span<128, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st))
-                               : (launch_span<64, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st)));
-         const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
-         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+         const bool gen = !utf8_tables;
+         int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
+         if (gen && ob == 3) ob = 2;   // (the v_perm forward automaton rides with the speculative pass: programs that decode; the nibble tables exist whenever it does)
+         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
          const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
-#define FX_MARKED(CH)                                                                                                              \
+#define FX_MARKED_G(CH, G)                                                                                                            \
    {                                                                                                                                  \
-      if (ob == 3) FX_HIP((launch_one_marked<CH, 3>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));          \
-      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
-      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
-      else FX_HIP((launch_one_marked<CH, 0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));                  \
+      if (ob == 2) FX_HIP((launch_one_marked<CH, 2, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));       \
+      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));  \
+      else FX_HIP((launch_one_marked<CH, 0, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));               \
    }
-         if (row_len == 128) FX_MARKED(8)
-         else FX_MARKED(4)
-#undef FX_MARKED
+#define FX_SPAN_CASE(RL, CH)                                                                                                          \
+   case RL:                                                                                                                           \
+      FX_HIP((launch_span<RL, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, marks)));                                    \
+      if (gen) FX_MARKED_G(CH, true)                                                                                                  \
+      else if (ob == 3) FX_HIP((launch_one_marked<CH, 3, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks))); \
+      else FX_MARKED_G(CH, false)                                                                                                     \
+      break;
+         switch (row_len) {
+            FX_SPAN_CASE(128, 8)
+            FX_SPAN_CASE(64, 4)
+            FX_SPAN_CASE(32, 2)
+            FX_SPAN_CASE(16, 1)
+            default: return FXAMD_E_ARG;
+         }
+#undef FX_SPAN_CASE
+#undef FX_MARKED_G
          p->last_path = 18;
          return FXAMD_OK;
       }
@@ -1029,17 +1057,25 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // queues inside) -- instead of a pass over marked tiles plus a pass over a worklist
       if (marked_followup) {
          if (!fx_env().no_adapt) first.defer_tiles |= 2u;   // (FX_ADAPT_CALLS: batches that are mostly UTF-8 skip the first pass's loads)
+         uint8_t* marks = nullptr;
+         if (out_mode != 0u) {   // packed results from the half-row first pass (round 5): a byte per tile says "left to the follow-up"
+            const int rcw = grow_worklist(sc, (n >> 8) + 64);
+            if (rcw != FXAMD_OK) return rcw;
+            marks = reinterpret_cast<uint8_t*>(sc->d_worklist);
+            first.worklist = sc->d_worklist;
+            first.out_mode = out_mode;
+         }
          FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
          const int ob = one_bytes_scheme(h, d_rows, row_len, scheme);
-         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+         const FastParams fpc = params_of(h, 0, false), fpb = ob != 0 ? params_of(h, ob, true) : FastParams{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
          const uint32_t cmb = (1024u + h.n_pages * 64u) * 2u;
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
 #define FX_MARKED(CH)                                                                                                              \
    {                                                                                                                                  \
-      if (ob == 3) FX_HIP((launch_one_marked<CH, 3>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));          \
-      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
-      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));     \
-      else FX_HIP((launch_one_marked<CH, 0>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr)));                  \
+      if (ob == 3) FX_HIP((launch_one_marked<CH, 3, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));          \
+      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));     \
+      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));     \
+      else FX_HIP((launch_one_marked<CH, 0, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));                  \
    }
          FX_MARKED(16)
 #undef FX_MARKED
@@ -1383,11 +1419,15 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
    po.half = half_rows(h, scheme, row_len, d_from != nullptr) && half_staging(scheme, d_from != nullptr);
-   if (!po.half && span_kind(h, scheme, d_rows, row_len, d_from != nullptr) == 1) {   // the span kernel's first pass
+   if (!po.half && n > 0 && span_kind(h, scheme, row_len, d_from != nullptr)) {   // the span kernel's first pass
       FastParams fps = params_of(h, 0, false);
       fps.defer_tiles = 1u;
-      FX_HIP(row_len == 128 ? (launch_span<128, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream))
-                            : (launch_span<64, 0, false>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream)));
+      switch (row_len) {
+         case 128: FX_HIP((launch_span<128, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
+         case 64: FX_HIP((launch_span<64, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
+         case 32: FX_HIP((launch_span<32, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
+         default: FX_HIP((launch_span<16, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
+      }
       return FXAMD_OK;
    }
    if (scheme != 0 && bytes && !po.half && sc->worklist_rows >= n) {   // the dominant pass of these programs is the byte-level one over all tiles

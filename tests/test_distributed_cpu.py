@@ -138,6 +138,14 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     assert len(line["per_rank_ms_per_step"]) == 2 and line["per_rank_ms_per_step"][1] > line["per_rank_ms_per_step"][0]
     line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong", "--config", "cfg5"])
     assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["gather_ok"] is True and line["scaling"] == "strong"
+    # the driver's own form -- `--gpus N --steps K --warmup W`, nothing else -- is the north star's 10M-string batch split N ways (round 5):
+    # strong scaling on config 3; config 5 and explicit --rows keep their per-rank shard sizes
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg5"])
+    assert line["scaling"] == "weak"
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "weak"])
+    assert line["scaling"] == "weak"
 
 
 def test_bench_under_torch_distributed_run():

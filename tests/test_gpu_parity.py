@@ -84,7 +84,7 @@ def test_config_rows_vs_oracle(fx, cfg, n):
     _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
     assert np.array_equal(f2, of)
     if cfg in ("cfg2", "cfg3", "cfg5"):
-        assert prog.last_path() in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16, 18, 19)   # tile kernels (9-11: the one-launch kernel; 18 / 19: the span kernel)
+        assert prog.last_path() in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16, 18)   # tile kernels (9-11: the one-launch kernel; 18: the span kernel)
 
 
 def test_fast_and_general_kernels_agree(fx, monkeypatch):
@@ -98,7 +98,7 @@ def test_fast_and_general_kernels_agree(fx, monkeypatch):
         p = fx.Program(pat, fx.OP_SEARCH)
         f1, a1, b1 = p.match_device(rows)
         tile_path = p.last_path()
-        assert tile_path in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16, 18, 19)
+        assert tile_path in (1, 3, 8, 9, 10, 11, 12, 13, 14, 16, 18)
         for off in (1, 4, 7):   # base addresses that are not 16-byte aligned: still the tile kernels
             buf = torch.empty(rows.numel() + 16, dtype=torch.uint8, device=rows.device)
             wide = buf[off:off + rows.numel()].view(rows.shape)
@@ -329,7 +329,7 @@ def test_fast_kernel_fuzz_patterns_and_row_lengths(fx, byte_tables, monkeypatch)
         rows_few[[5, 6, 70, 130, 191]] = rows_m[[0, 1, 2, 3, 4]]
         for rows in (rows_a, rows_m, np.concatenate([rows_a[:64], rows_m[:64], rows_a[64:128]]), rows_few):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 19), (pat, L)   # (2: chain tables too large for LDS next to the tiles)
+            assert prog.last_path() in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18), (pat, L)   # (2: chain tables too large for LDS next to the tiles)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -367,9 +367,9 @@ def test_utf8_rows_byte_tables_and_decode_pass(fx, monkeypatch):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             if bytes_on:
                 assert prog.info()["flags"] & 4096, pat
-                assert prog.last_path() in (7, 8, 10, 11, 13, 14, 16, 18, 19), (pat, prog.last_path())
+                assert prog.last_path() in (7, 8, 10, 11, 13, 14, 16, 18), (pat, prog.last_path())
             else:
-                assert prog.last_path() in (1, 3, 5, 6, 9, 12, 16, 18, 19), (pat, prog.last_path())
+                assert prog.last_path() in (1, 3, 5, 6, 9, 12, 16, 18), (pat, prog.last_path())
             assert np.array_equal(f, of), (pat, bytes_on)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, bytes_on)
             _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
@@ -787,7 +787,7 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
         for pat in (rb"--[a-z]+", rb"aa[bc]", rb"abab\d", rb"zz\d+", rb"aba[a-z]+", rb"aba[a-z]*y", rb"aa.*b0", rb"--[a-z ]+--"):
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
             assert prog.info()["flags"] & 0x20000, pat
-            assert prog.last_path() in (3, 6, 12, 19), (pat, L, prog.last_path())   # (19: the span kernel, 64-byte rows)
+            assert prog.last_path() in (3, 6, 12, 18), (pat, L, prog.last_path())   # (18: the span kernel, 64-byte rows)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -1165,7 +1165,7 @@ def test_long_rows_last_bytes_of_a_tile(fx):
 
 
 @pytest.mark.parametrize("hook", ["", "FXAMD_MULTIPASS", "FXAMD_NO_A8", "FXAMD_NO_BYTE_DFA", "FXAMD_NO_W16", "FXAMD_NO_HALF", "FXAMD_FORCE_GENERAL",
-                                  "FXAMD_NO_TINY", "FXAMD_NO_SPEC", "FXAMD_HALF_SCH=1", "FXAMD_HALF_SCH=7", "FXAMD_NO_ADAPT", "FXAMD_NO_SPAN", "FXAMD_SPAN_BYTES"])
+                                  "FXAMD_NO_TINY", "FXAMD_NO_SPEC", "FXAMD_HALF_SCH=1", "FXAMD_HALF_SCH=7", "FXAMD_NO_ADAPT", "FXAMD_NO_SPAN", "FXAMD_SPAN_LENS=31"])
 def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
     """tests/golden/config_rows.tsv: the REAL reference's flag / from / to (recorded in the container by
     tests/golden/make_config_goldens.py through oracle/_ref/ref_driver) on 2000-6144 rows of each BASELINE config (first and last
@@ -1205,7 +1205,7 @@ def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
         n_rows += n
     # the BASELINE configs run on the tile kernels (one-launch kernel / half-row pipeline), not on the general kernel
     if not hook:
-        assert paths["cfg3"] == 16 and paths["cfg2"] in (9, 10, 11, 12, 13, 14, 19) and paths["cfg4"] in (10, 11) and paths["cfg5"] == 18, paths
+        assert paths["cfg3"] == 16 and paths["cfg2"] in (9, 10, 11, 12, 13, 14) and paths["cfg4"] in (10, 11) and paths["cfg5"] == 18, paths
         assert paths["tiny_M0_L8"] == 17 and paths["tab_p0_L256"] in (5, 6, 8) and paths["long_chain_L1024"] == 7, paths
     elif hook == "FXAMD_FORCE_GENERAL":
         assert set(paths.values()) == {2}, paths
@@ -1242,9 +1242,8 @@ def test_one_launch_calls_replay_from_a_hip_graph(fx):
         out = prog.match_device(rows, spans=spans)   # (first call: tables uploaded, scratch allocated, code objects loaded)
         torch.cuda.synchronize()
         # (config 1's 8-byte rows run fx_match_tiny -- a first pass with counter words -- outside a capture and the one-launch kernel inside one)
-        # (... as do config 5's 128-byte rows with the span kernel's first pass + follow-up, 18; config 2's span kernel, 19, is one launch without host-side state)
-        assert prog.last_path() in (9, 10, 11, 12, 13, 14) or (cfg == "cfg1" and prog.last_path() == 17) or (cfg == "cfg5" and prog.last_path() == 18) or (
-            cfg == "cfg2" and prog.last_path() == 19), (cfg, prog.last_path())
+        # (... as do config 5's 128-byte rows -- and config 2's 64-byte ones where the span kernel takes them -- with its first pass + follow-up, 18)
+        assert prog.last_path() in (9, 10, 11, 12, 13, 14) or (cfg == "cfg1" and prog.last_path() == 17) or (cfg in ("cfg5", "cfg2") and prog.last_path() == 18), (cfg, prog.last_path())
         assert fx.lib().fxamd_program_reserve(prog._h, n, torch.cuda.current_stream().cuda_stream) == 0
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):   # the capture stream needs its own scratch set: reserve it before capturing

@@ -65,6 +65,10 @@ SHAPES = {
     "ragged_100":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 100 B", "search", [r"[a-z]+\d+"], "cfg3", 100, 25_600_000, False, True),
     "ragged_132":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 132 B", "search", [r"[a-z]+\d+"], "cfg3", 132, 19_393_939, False, True),
     "ragged_200":   ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 200 B", "search", [r"[a-z]+\d+"], "cfg3", 200, 12_800_000, False, True),
+    # rows of 64 / 32 / 16 bytes with spans (the span kernel, fx_span.hpp): config 5's bytes viewed at that length (one row in 4 / 8 / 16 matches)
+    "rows_64":      ("`[a-z]+\\d+` `.in.` + spans, config-5 bytes viewed as 25 M rows of 64 B", "search", [r"[a-z]+\d+"], "cfg5", 64, 25_000_000, False, True),
+    "rows_32":      ("`[a-z]+\\d+` `.in.` + spans, config-5 bytes viewed as 50 M rows of 32 B", "search", [r"[a-z]+\d+"], "cfg5", 32, 50_000_000, False, True),
+    "rows_16":      ("`[a-z]+\\d+` `.in.` + spans, config-5 bytes viewed as 100 M rows of 16 B", "search", [r"[a-z]+\d+"], "cfg5", 16, 100_000_000, False, True),
     "ragged_20":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 20 B", "search", [r"[a-z]+\d+"], "cfg3", 20, 64_000_000, False, True),
     # short rows of a length that does not divide 64 (character(10), (12), (20), (24)): the tiny-row kernels' ragged spans
     "match_rows_12": ("`.match.` `[a-z ]+\\d*[a-z ]*` over config-3 bytes viewed as 100M rows of 12 B (fx_match_tiny, ragged spans)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg3", 12, 100_000_000, False, False),
