@@ -1098,7 +1098,10 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       return __builtin_amdgcn_ballot_w64(rr < n && flags[rr] == FX_NEEDS_GENERAL) != 0;
    };
    bool live = MARKED ? tile_marked(wave_global) : true;   // the tile in `stage` is to be scanned
-   if constexpr (MARKED) load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
+   if constexpr (MARKED) {
+      if constexpr (RAGGED) load_tile_rag<CH>(stage, rows, wave_global << 6, n, lane, tl, live);
+      else load_tile<CH>(stage, rows, wave_global << 6, n, lane, live);
+   }
    // speculative pass: on while it pays (wave-uniform).  A tile where more than FX_SPEC_FAIL_MAX rows fail is scanned in place and turns
    // it off; it is tried again FX_SPEC_RETRY tiles later (batches are rarely uniform: sorted inputs, sections of a file).
    bool spec_on = SPEC && (fpb.spec & 1u) != 0u;
@@ -1454,7 +1457,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
 // procedure for the rows the tables cannot answer, inside the launch)
 template <int CH, int BSCH, bool GEN>
 hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, FastParams fpb, uint8_t* flags, int32_t* from, int32_t* to,
-                             uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate, uint32_t out_mode, const uint8_t* marks) {
+                             uint32_t class_map_bytes, uint32_t table_bytes, hipStream_t st, const uint32_t* gate, uint32_t out_mode, const uint8_t* marks, uint32_t Lr) {
    static_assert(CH == 16 || CH == 8 || CH == 4 || CH == 2 || CH == 1, "follow-up of the half-row first pass (256-byte rows) and of the span kernel");
    static_assert(CH != 16 || !GEN, "the half-row pipeline is for programs whose tables decode");
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
@@ -1470,17 +1473,23 @@ hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_bl
          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, 16u * CH, out_mode, gate, marks);
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, fpb, flags, from, to, map_lds, Lr, out_mode, gate, marks);
       return hipGetLastError();
    };
    if constexpr (BSCH == 3 && GEN) return hipErrorInvalidValue;   // (never dispatched: the speculative pass's table is for programs that decode)
    else {
+      if (Lr != 16u * CH) {   // ragged rows (the span kernel's): any length 2 <= Lr < 16 * CH on the power-of-two instantiations
+         if constexpr (CH != 16) {
+            if (spans && Lr >= 2u && Lr < 16u * CH) return go(&fx_search_one<CH, true, 0, BSCH, true, GEN, true>);
+         }
+         return hipErrorInvalidValue;
+      }
       if (spans) return go(&fx_search_one<CH, true, 0, BSCH, false, GEN, true>);
       if constexpr (CH == 16) return go(&fx_search_one<CH, false, 0, BSCH, false, GEN, true>);
       return hipErrorInvalidValue;   // (the span kernel answers searches with spans only)
    }
 }
-#define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*, uint32_t, const uint8_t*)
+#define FX_ONE_MARKED_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, hipStream_t, const uint32_t*, uint32_t, const uint8_t*, uint32_t)
 
 // every (CH, SCH, BSCH, GEN) the dispatch code of fxamd.hip can ask for
 #define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 0, 3, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)

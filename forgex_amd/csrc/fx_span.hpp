@@ -32,14 +32,23 @@
 #ifndef FX_SPAN_GB
 #define FX_SPAN_GB 1   // compacted finish passes: 8-symbol groups of the forward window whose lookups are issued together (registers)
 #endif
+#ifndef FX_SPAN_RAG_WAVES
+#define FX_SPAN_RAG_WAVES 3   // waves per SIMD the ragged instantiations are compiled for (their wave-uniform guards cost ~50 SGPRs: at four waves they spill)
+#endif
 #ifndef FX_SPAN_MIN_ROUNDS
 #define FX_SPAN_MIN_ROUNDS 1   // launch grid: at least this many rounds of the 1024 resident blocks
 #endif
 
+// RL = bytes of LDS a row gets: 16 * (its chunk count rounded up to a power of two).  Rows of exactly RL bytes are the aligned
+// instantiations; RAG: rows of ANY other length 2 <= Lr < RL (character(20), (80), (100): what Fortran programs declare) stay
+// LEFT-ALIGNED in their RL bytes with what follows the text in the wrapped string behind it -- the trailing NUL at byte Lr, then KILL
+// symbols (the pad-free scheme of fx_tile.hpp, "Ragged rows, round 4": the loader reads per-row pieces at the row stride, the chunk the
+// row ends in is patched after every staging store, the backward pass starts at the row's last byte) -- so every left-to-right walk is
+// the aligned kernels' code and the work follows the row length.
 template <int RL>
 struct FxSpan {
-   static_assert(RL == 128 || RL == 64 || RL == 32 || RL == 16, "span kernel: rows of 128, 64, 32 or 16 bytes");
-   static constexpr int K = 128 / RL;     // rows per lane (one 128-byte span)
+   static_assert(RL == 128 || RL == 64 || RL == 32 || RL == 16, "span kernel: rows of up to 128, 64, 32 or 16 bytes");
+   static constexpr int K = 128 / RL;     // rows per lane (one 128-byte span of LDS)
    static constexpr int NCH = RL / 16;    // chunks per row
 };
 
@@ -61,6 +70,39 @@ __device__ __forceinline__ void fx_span_load(uint4 (&v)[8], const uint8_t* __res
    }
 }
 
+// RAG: tile t = rows [64 K t, 64 K t + 64 K).  Piece q * 64 + lane = lane-span 8 q + lane / 8, cell lane % 8 of it = chunk k = cell % NCH of
+// the span's row j = cell / NCH: the 16 bytes at row byte 16 k of row (8 q + lane / 8) K + j -- unaligned loads at the row stride; cells whose
+// chunk holds no text ask for an address behind the extent and fetch nothing.  The extent: fx_tile.hpp, load_tile_rag (the batch's last
+// tile ends it at the batch's last byte and rebuilds the straddling dword from byte loads).
+template <int RL>
+__device__ __forceinline__ void fx_span_load_rag(uint4 (&v)[8], const uint8_t* __restrict__ rows, const int64_t n, const int64_t t, const uint32_t lane, const FxTail& T) {
+   constexpr uint32_t K = (uint32_t)FxSpan<RL>::K, NCH = (uint32_t)FxSpan<RL>::NCH;
+   const int64_t row0 = (t << 6) * (int64_t)K;
+   const int64_t rows_left = n - row0;
+   const uint32_t tile_rows = rows_left <= 0 ? 0u : (rows_left >= 64 * (int64_t)K ? 64u * K : (uint32_t)rows_left);
+   const uint32_t tile_bytes = tile_rows * T.Lr;
+   const int64_t room = rows_left > 64 * (int64_t)K ? (rows_left - 64 * (int64_t)K) * (int64_t)T.Lr : 0;   // bytes of the batch behind this tile
+   const bool last_tile = room < 3;
+   const uint32_t valid = tile_rows == 0u ? 0u : (last_tile ? tile_bytes + (uint32_t)room : tile_bytes + 3u);
+   const uint64_t base = reinterpret_cast<uint64_t>(rows) + (uint64_t)(rows_left > 0 ? row0 : 0) * (uint64_t)T.Lr;
+   const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(valid), 0x00020000);
+   const uint32_t cell = lane & 7u, j = cell / NCH, k = cell % NCH;
+   const uint32_t voff = k < T.nch ? ((lane >> 3) * K + j) * T.Lr + 16u * k : 0x7FFFFFF0u;
+   const uint32_t step = __builtin_amdgcn_readfirstlane(8u * K * T.Lr);
+#pragma unroll
+   for (int q = 0; q < 8; ++q) {
+      const fx_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)q * step, FX_LOAD_AUX);
+      v[q] = make_uint4(x.x, x.y, x.z, x.w);
+   }
+   if (last_tile && tile_rows != 0u && (T.Lr & 3u) != 0u && k < T.nch) {   // (the batch's last tile only)
+      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fx_patch_tail_piece(v[q], tb8, voff + (uint32_t)q * step, valid);
+   }
+}
+
 // 8 symbols of the row that starts at chunk c0 of lane R's cells, from row position p (a multiple of 8, any value): text, then the
 // trailing NUL at position RL, then KILL symbols (the shared end-of-row cell)
 template <int RL>
@@ -75,15 +117,72 @@ __device__ __forceinline__ void fx_span_group(uint32_t& lo, uint32_t& hi, const 
 // Right-to-left pass over ONE row (chunks c0 .. c0 + NCH - 1 of the lane's own cells): the half-row kernel's lean loop (fx_tile.hpp,
 // FX_HALF4: running maximum instead of the group's eight states, one chunk of LDS prefetch).  gsel = the leftmost 8-byte group that
 // holds a hit (0xFFFFFFFF: none), esel = the state entering it, state = the state after the leading NUL.
-template <int RL, int SCH, class TabT>
+template <int RL, int SCH, bool RAG, class TabT>
 __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t lane, const uint32_t c0, const TabT* __restrict__ tabR, const uint8_t* TRp,
-                                             const FastParams& fp, uint32_t& na, uint32_t& gsel, uint32_t& esel, uint32_t& state) {
+                                             const FastParams& fp, const FxTail& T, uint32_t& na, uint32_t& gsel, uint32_t& esel, uint32_t& state) {
    using F = typename FxF<SCH>::type;
    constexpr int NCH = FxSpan<RL>::NCH;
    state = fp.R_start;
    gsel = 0xFFFFFFFFu;
    esel = 0;
    F fa[8], fb[8];
+   if constexpr (RAG) {
+      // from the row's LAST byte: the chunk the row ends in over its text bytes only, then the whole chunks behind wave-uniform guards (cell
+      // addresses stay immediates); chunks behind the text are skipped -- fx_scan_tile's TAIL loop (fx_one.hpp) with the lean chain
+      if (T.nb != 0u) {
+         const uint4 wp = tile[tile_cell(lane, c0 + T.kt)];
+         na |= fx_tail_or(wp, T.nb);
+         if (T.nb > 8u) {
+            lookup8(fa, wp.z, wp.w, tabR);
+            const uint32_t entry = state;
+            const uint32_t mx = chain8_back_n(fa, state, TRp, T.nb - 8u);
+            gsel = mx >= fp.hit_min ? 2u * T.kt + 1u : gsel;
+            esel = mx >= fp.hit_min ? entry : esel;
+         }
+         lookup8(fb, wp.x, wp.y, tabR);
+         const uint32_t entry = state;
+         const uint32_t nv0 = T.nb < 8u ? T.nb : 8u;
+         const uint32_t mx = nv0 == 8u ? chain8_back<F, true>(fb, state, TRp) : chain8_back_n(fb, state, TRp, nv0);
+         gsel = mx >= fp.hit_min ? 2u * T.kt : gsel;
+         esel = mx >= fp.hit_min ? entry : esel;
+      }
+      if (T.kt != 0u) {
+         uint4 wk = tile[tile_cell(lane, c0 + T.kt - 1u)];
+         lookup8(fa, wk.z, wk.w, tabR);
+#pragma unroll
+         for (int k = NCH - 2; k >= 0; --k) {   // (kt <= NCH - 1: a ragged row is shorter than RL bytes)
+            if ((uint32_t)k < T.kt) {
+               na |= wk.x | wk.y | wk.z | wk.w;
+               lookup8(fb, wk.x, wk.y, tabR);
+               __builtin_amdgcn_sched_barrier(0);
+               {
+                  const uint32_t entry = state;
+                  const uint32_t mx = chain8_back<F, true>(fa, state, TRp);
+                  gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
+                  esel = mx >= fp.hit_min ? entry : esel;
+                  asm volatile("" : "+v"(esel));
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               if (k >= 1) {
+                  wk = tile[tile_cell(lane, c0 + (uint32_t)k - 1u)];
+                  lookup8(fa, wk.z, wk.w, tabR);
+               }
+               __builtin_amdgcn_sched_barrier(0);
+               {
+                  const uint32_t entry = state;
+                  const uint32_t mx = chain8_back<F, true>(fb, state, TRp);
+                  gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
+                  esel = mx >= fp.hit_min ? entry : esel;
+                  asm volatile("" : "+v"(esel));
+               }
+               __builtin_amdgcn_sched_barrier(0);
+            }
+         }
+      }
+      const F fz = tabR[0];   // leading NUL: a hit there is the leftmost start
+      state = fxstep(fz, state, TRp);
+      return;
+   }
    uint4 wk = tile[tile_cell(lane, c0 + (uint32_t)NCH - 1u)];
    lookup8(fa, wk.z, wk.w, tabR);
 #pragma unroll
@@ -120,10 +219,10 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
 // FINISH of one row per lane; the result in ONE register: flag | from << 8 | to << 16 (from, to <= 128)
 // the row: the row = chunks c0 .. of lane R's cells (R, c0 per lane: a compacted slot, or the lane's own row), g = its
 // leftmost hit group, e = the state entering it, nul = the start is the leading NUL; on = this lane has a row.
-template <int RL, int SCH, int GB, class TabT>
+template <int RL, int SCH, int GB, bool RAG, class TabT>
 __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint8_t* eor, const uint32_t R, const uint32_t c0, const uint32_t g, const uint32_t e,
                                                    const bool nul, const bool on, const TabT* __restrict__ tabR, const TabT* __restrict__ tabA,
-                                                   const uint8_t* TRp, const uint8_t* TAp, const FastParams& fp) {
+                                                   const uint8_t* TRp, const uint8_t* TAp, const FastParams& fp, const uint32_t L) {
    using F = typename FxF<SCH>::type;
    // exact byte of the leftmost hit: re-walk the hit group
    uint32_t s;   // wrapped start index (1 = leading NUL, j + 2 for text byte j)
@@ -135,8 +234,15 @@ __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint
       uint32_t st = e, loc = 0;
 #pragma unroll
       for (int i = 7; i >= 0; --i) {
-         st = fxstep(f[i], st, TRp);
-         loc = st >= fp.hit_min ? (uint32_t)i : loc;
+         if constexpr (RAG) {   // the group the row ends in: only its text bytes were walked (the NUL / KILL symbols behind them are not the row's)
+            const uint32_t nx = fxstep(f[i], st, TRp);
+            const bool in_text = g * 8u + (uint32_t)i < L;
+            st = in_text ? nx : st;
+            loc = (in_text && nx >= fp.hit_min) ? (uint32_t)i : loc;
+         } else {
+            st = fxstep(f[i], st, TRp);
+            loc = st >= fp.hit_min ? (uint32_t)i : loc;
+         }
       }
       s = nul ? 1u : g * 8u + 2u + loc;
    }
@@ -234,7 +340,7 @@ __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint
    uint32_t out = 0;
    if (on && mm > 2u) {
       const uint32_t fr = s >= 2u ? s - 1u : 1u;
-      const uint32_t tt = mm >= (uint32_t)RL + 2u ? (uint32_t)RL : mm - 2u;
+      const uint32_t tt = mm >= L + 2u ? L : mm - 2u;
       out = 1u | (fr << 8) | (tt << 16);
    }
    return out;
@@ -242,10 +348,11 @@ __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint
 
 // n_deferred: this call's group of four counter words (words of consecutive calls alternate; [0] "tiles were deferred", [2] / [3] the
 // sample FX_ADAPT_CALLS describes)
-template <int RL, int SCH, bool PACKED>
-__global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restrict__ rows, const int64_t n, const uint8_t* __restrict__ prog, const FastParams fp,
+template <int RL, int SCH, bool PACKED, bool RAG>
+__global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_span(const uint8_t* __restrict__ rows, const int64_t n, const uint8_t* __restrict__ prog, const FastParams fp,
                                                           uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
-                                                          uint32_t* __restrict__ n_deferred, uint32_t* __restrict__ clear_next, uint8_t* __restrict__ marks) {
+                                                          uint32_t* __restrict__ n_deferred, uint32_t* __restrict__ clear_next, uint8_t* __restrict__ marks,
+                                                          const uint32_t Lr_in) {
    // fp.out_mode == 1: PACKED results (what a multi-GPU host gathers): `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit
    // word i >> 6), `from` / `to` = one byte per row (rows of up to 128 bytes); "this tile is left to the follow-up" = marks[64-row tile] = 1
    static_assert(SCH == 0 || SCH == 2, "class-level v_perm or nibble tables");
@@ -264,8 +371,10 @@ __global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restri
    __shared__ __attribute__((aligned(16))) uint4 tiles[4 * 512 + 4];   // 4 waves x 64 spans x 8 cells, then the four shared end-of-row cells
    __shared__ uint32_t slot_q[COMPACT ? 4 * 128 : 1];   // compaction: per wave a ring of 128 slots (K > 2: whole passes are finished in between so that it never overflows)
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-   const int64_t total = n * (int64_t)RL;
-   const int64_t n_tiles = (total + 8191) >> 13;
+   const uint32_t Lr = RAG ? Lr_in : (uint32_t)RL;   // row length in bytes (RAG: 2 <= Lr < RL)
+   const FxTail tl = fx_tail_of(Lr);
+   const int64_t total = n * (int64_t)RL;               // (aligned rows: the batch's bytes)
+   const int64_t n_tiles = (n + 64 * K - 1) / (64 * K);
    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave, wave_stride = (int64_t)gridDim.x * 4;
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // first passes whose tiles mostly hold UTF-8 (FX_ADAPT_CALLS, fx_tile.hpp): the follow-up's persistent word says "skip the loads"
@@ -292,12 +401,21 @@ __global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restri
    const uint2 t_a = reinterpret_cast<const uint2*>(prog + (SCH == 2 ? h->off_w16A : h->off_fastA))[threadIdx.x];
    __builtin_amdgcn_sched_barrier(0);
    uint4 stage[8];
-   fx_span_load(stage, rows, total, wave_global, lane);
+   if constexpr (RAG) fx_span_load_rag<RL>(stage, rows, n, wave_global, lane, tl);
+   else fx_span_load(stage, rows, total, wave_global, lane);
    reinterpret_cast<uint2*>(tabR_s)[threadIdx.x] = t_r;
    reinterpret_cast<uint2*>(tabA_s)[threadIdx.x] = t_a;
    uint4* const tile = tiles + wave * 512u;
    uint4* const eor_cell = tiles + 4 * 512 + wave;
-   if (lane == 0) *eor_cell = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   // (ragged rows: the NUL sits inside the row's cells, right behind the text, and the shared cell holds KILL symbols only -- a second NUL
+   //  would be a second line end to patterns like `$$`)
+   if (lane == 0) *eor_cell = make_uint4(RAG ? 0xFEFEFEFEu : 0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   if constexpr (RAG) {   // chunks behind the text of each of the lane's rows: the trailing NUL / KILL symbols, written ONCE (the loader never touches them)
+      for (uint32_t j = 0; j < (uint32_t)K; ++j)
+         for (uint32_t k = tl.nch; k < (uint32_t)NCH; ++k)
+            tile[tile_cell(lane, j * (uint32_t)NCH + k)] = (k == tl.kt) ? make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu)
+                                                                         : make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   }
    __syncthreads();
    const F* tabR = tabR_s;
    const F* tabA = tabA_s;
@@ -320,8 +438,25 @@ __global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restri
          const uint32_t smp = stage[0].x | stage[0].w | stage[4].y | stage[7].z;
          defer_tile = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
       }
-      store_tile<8>(stage, tile, lane);
-      fx_span_load(stage, rows, total, t_next, lane);   // the ONE place the staging registers are reloaded
+      if constexpr (RAG) {
+         if ((lane & 7u) % (uint32_t)NCH < tl.nch) store_tile<8>(stage, tile, lane);   // (the chunks behind the text keep their KILL symbols)
+         fx_span_load_rag<RL>(stage, rows, n, t_next, lane, tl);   // the ONE place the staging registers are reloaded
+         if (tl.nb != 0u) {   // what follows the text in the chunk each row ends in: the trailing NUL, then KILL symbols
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+               const uint32_t cc = tile_cell(lane, (uint32_t)(j * NCH) + tl.kt);
+               uint4 c = tile[cc];
+               c.x = fx_tail_word(c.x, 0u, tl.nb);
+               c.y = fx_tail_word(c.y, 4u, tl.nb);
+               c.z = fx_tail_word(c.z, 8u, tl.nb);
+               c.w = fx_tail_word(c.w, 12u, tl.nb);
+               tile[cc] = c;
+            }
+         }
+      } else {
+         store_tile<8>(stage, tile, lane);
+         fx_span_load(stage, rows, total, t_next, lane);   // the ONE place the staging registers are reloaded
+      }
       uint32_t res[K];   // flag | from << 8 | to << 16
 #pragma unroll
       for (int i = 0; i < K; ++i) res[i] = 0u;
@@ -330,12 +465,12 @@ __global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restri
       if (!defer_tile) {
          if constexpr (!COMPACT) {
             uint32_t gsel, esel, state;
-            fx_span_back<RL, SCH>(tile, lane, 0u, tabR, nullptr, fp, na, gsel, esel, state);
+            fx_span_back<RL, SCH, RAG>(tile, lane, 0u, tabR, nullptr, fp, tl, na, gsel, esel, state);
             const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
             sink = fp.inv_on != 0u && state == fp.inv;
             const bool want = hit || nul;
             if (__builtin_amdgcn_ballot_w64(want) != 0)
-               res[0] = fx_span_finish<RL, SCH, 2>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, nullptr, nullptr, fp);
+               res[0] = fx_span_finish<RL, SCH, 2, RAG>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, nullptr, nullptr, fp, Lr);
          } else {
             // every row's backward pass; the rows that need the finish take a slot: lane | row << 6 | hit group << 9 | nul << 13 | entry state << 14.
             // Until its slot is finished a row's result register holds the slot number (bit 31 set).
@@ -344,15 +479,15 @@ __global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restri
                const bool on = base + lane < cnt;
                const uint32_t en = on ? sq[(base + lane) % QCAP] : 0u;
                const uint32_t e8 = en >> 14;
-               const uint32_t r = fx_span_finish<RL, SCH, FX_SPAN_GB>(tb, eor, en & 63u, ((en >> 6) & 7u) * (uint32_t)NCH, (en >> 9) & 15u, SCH == 0 ? e8 * 0x01010101u : e8,
-                                                                      ((en >> 13) & 1u) != 0u, on, tabR, tabA, nullptr, nullptr, fp);
+               const uint32_t r = fx_span_finish<RL, SCH, FX_SPAN_GB, RAG>(tb, eor, en & 63u, ((en >> 6) & 7u) * (uint32_t)NCH, (en >> 9) & 15u, SCH == 0 ? e8 * 0x01010101u : e8,
+                                                                           ((en >> 13) & 1u) != 0u, on, tabR, tabA, nullptr, nullptr, fp, Lr);
                if (on) sq[(base + lane) % QCAP] = r;
             };
             uint32_t done = 0;   // slots finished (wave-uniform; K > 2: the ring holds 128 and whole passes are finished when the next row's slots may not fit)
 #pragma unroll
             for (int jr = K - 1; jr >= 0; --jr) {
                uint32_t gsel, esel, state;
-               fx_span_back<RL, SCH>(tile, lane, (uint32_t)(jr * NCH), tabR, nullptr, fp, na, gsel, esel, state);
+               fx_span_back<RL, SCH, RAG>(tile, lane, (uint32_t)(jr * NCH), tabR, nullptr, fp, tl, na, gsel, esel, state);
                const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
                sink = sink || (fp.inv_on != 0u && state == fp.inv);
                const bool want = hit || nul;
@@ -516,10 +651,12 @@ __global__ __launch_bounds__(256, 4) void fx_search_span(const uint8_t* __restri
 // ctr: this call's counter group
 template <int RL, int SCH>
 hipError_t launch_span(const uint8_t* rows, int64_t n, const uint8_t* d_blob, FastParams fp, uint8_t* flags, int32_t* from, int32_t* to, uint32_t* ctr,
-                       hipStream_t st, uint8_t* marks) {
+                       hipStream_t st, uint8_t* marks, uint32_t Lr) {
    uint32_t* clear_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(ctr) ^ 16u);   // the other parity's group of four words
-   const int64_t total = n * (int64_t)RL;
-   const int64_t n_tiles = (total + 8191) >> 13;
+   const int64_t total = n * (int64_t)Lr;
+   constexpr int64_t TROWS = 64 * FxSpan<RL>::K;
+   const int64_t n_tiles = (n + TROWS - 1) / TROWS;
+   if (Lr < 2u || Lr > (uint32_t)RL) return hipErrorInvalidValue;
    int64_t blocks = (n_tiles + 3) / 4;
    // whole rounds of the four resident blocks per CU, one per 225 MB of rows (the half-row kernel's rule: fx_tile.hpp); FXAMD_HALF_ROUNDS: experiment hook
    int64_t rounds = fx_env().half_rounds;
@@ -533,8 +670,16 @@ hipError_t launch_span(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    if (env_blocks > 0 && blocks > env_blocks) blocks = env_blocks;
    if (blocks < 1) blocks = 1;
    if (!from || !to) return hipErrorInvalidValue;   // (searches with spans only: fxamd.hip, span_kind)
-   if (fp.out_mode != 0u) hipLaunchKernelGGL((fx_search_span<RL, SCH, true>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks);
-   else hipLaunchKernelGGL((fx_search_span<RL, SCH, false>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks);
+   const bool rag = Lr != (uint32_t)RL;
+#define FX_SPAN_GO(P, R) hipLaunchKernelGGL((fx_search_span<RL, SCH, P, R>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks, Lr)
+   if (fp.out_mode != 0u) {
+      if (rag) FX_SPAN_GO(true, true);
+      else FX_SPAN_GO(true, false);
+   } else {
+      if (rag) FX_SPAN_GO(false, true);
+      else FX_SPAN_GO(false, false);
+   }
+#undef FX_SPAN_GO
    return hipGetLastError();
 }
-#define FX_SPAN_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, hipStream_t, uint8_t*)
+#define FX_SPAN_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, hipStream_t, uint8_t*, uint32_t)

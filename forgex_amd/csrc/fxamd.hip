@@ -55,7 +55,7 @@ extern template hipError_t launch_multi<8> FX_MULTI_SIG;
 
 // ---- test / experiment hooks: the FXAMD_* environment variables, read once (FxEnv, fx_tile.hpp) ----
 #ifndef FX_SPAN_LENS_DEFAULT
-#define FX_SPAN_LENS_DEFAULT 15   // row lengths the span kernel takes by default (bit mask: 128, 64, 32, 16)
+#define FX_SPAN_LENS_DEFAULT 47   // row lengths the span kernel takes by default (bit mask: 128, 64, 32, 16; 32 = ragged rows)
 #endif
 static FxEnv g_env;
 static std::once_flag g_env_once;
@@ -798,13 +798,18 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
 // literal prefix), and there the one-launch kernel's match compaction -- 64 gathered rows per finish pass ACROSS tiles -- beats one
 // finish pass per 8 KB tile (BASELINE config 2, one row in ten matching: 18.2 us against 19.5 us + 1.6 us of follow-up launch).
 // FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook); FXAMD_SPAN_LENS: bit mask of the row lengths it takes (1: 128, 2: 64,
-// 4: 32, 8: 16; +16: candidate-list driver programs at every length; experiment hook).
+// 4: 32, 8: 16 -- the LDS bytes a row gets: its length rounded up to those; +16: candidate-list driver programs at every length; +32: ragged
+// rows, any length 2..127 that is not one of the four; experiment hook).
+static int span_cell(int64_t row_len) { return row_len <= 16 ? 16 : (row_len <= 32 ? 32 : (row_len <= 64 ? 64 : 128)); }   // bytes of LDS a row gets (fx_span.hpp: RL)
 static bool span_kind(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
    if (!spans || scheme != 0 || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) || fx_env().multipass || fx_env().no_span)
       return false;
+   if (row_len < 2 || row_len > 128) return false;
    const int lens = fx_env().span_lens;
-   if (row_len != 128 && (h.flags & FXP_F_PREFILTER) && !(lens & 16)) return false;
-   return (row_len == 128 && (lens & 1)) || (row_len == 64 && (lens & 2)) || (row_len == 32 && (lens & 4)) || (row_len == 16 && (lens & 8));
+   if (row_len <= 64 && (h.flags & FXP_F_PREFILTER) && !(lens & 16)) return false;
+   if (row_len != span_cell(row_len) && !(lens & 32)) return false;   // ragged rows (any other length: bit 5)
+   const int rl = span_cell(row_len);
+   return (rl == 128 && (lens & 1)) || (rl == 64 && (lens & 2)) || (rl == 32 && (lens & 4)) || (rl == 16 && (lens & 8));
 }
 
 // ---- the pipeline of one batch call, enqueued on `st` with the scratch set `sc` (p->mu held) ----------------------------------
@@ -955,18 +960,18 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
 #define FX_MARKED_G(CH, G)                                                                                                            \
    {                                                                                                                                  \
-      if (ob == 2) FX_HIP((launch_one_marked<CH, 2, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));       \
-      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));  \
-      else FX_HIP((launch_one_marked<CH, 0, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));               \
+      if (ob == 2) FX_HIP((launch_one_marked<CH, 2, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, (uint32_t)row_len)));       \
+      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, (uint32_t)row_len)));  \
+      else FX_HIP((launch_one_marked<CH, 0, G>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, (uint32_t)row_len)));               \
    }
 #define FX_SPAN_CASE(RL, CH)                                                                                                          \
    case RL:                                                                                                                           \
-      FX_HIP((launch_span<RL, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, marks)));                                    \
+      FX_HIP((launch_span<RL, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, marks, (uint32_t)row_len)));                 \
       if (gen) FX_MARKED_G(CH, true)                                                                                                  \
-      else if (ob == 3) FX_HIP((launch_one_marked<CH, 3, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks))); \
+      else if (ob == 3) FX_HIP((launch_one_marked<CH, 3, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, (uint32_t)row_len))); \
       else FX_MARKED_G(CH, false)                                                                                                     \
       break;
-         switch (row_len) {
+         switch (span_cell(row_len)) {
             FX_SPAN_CASE(128, 8)
             FX_SPAN_CASE(64, 4)
             FX_SPAN_CASE(32, 2)
@@ -1072,10 +1077,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          const uint32_t tb = ob == 1 ? ((512u + h.byte_TR_bytes + h.byte_TA_bytes + 15u) & ~15u) : 0u;
 #define FX_MARKED(CH)                                                                                                              \
    {                                                                                                                                  \
-      if (ob == 3) FX_HIP((launch_one_marked<CH, 3, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));          \
-      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));     \
-      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));     \
-      else FX_HIP((launch_one_marked<CH, 0, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks)));                  \
+      if (ob == 3) FX_HIP((launch_one_marked<CH, 3, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, 16u * CH)));          \
+      else if (ob == 2) FX_HIP((launch_one_marked<CH, 2, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, 16u * CH)));     \
+      else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, 16u * CH)));     \
+      else FX_HIP((launch_one_marked<CH, 0, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, 16u * CH)));                  \
    }
          FX_MARKED(16)
 #undef FX_MARKED
@@ -1422,11 +1427,11 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (!po.half && n > 0 && span_kind(h, scheme, row_len, d_from != nullptr)) {   // the span kernel's first pass
       FastParams fps = params_of(h, 0, false);
       fps.defer_tiles = 1u;
-      switch (row_len) {
-         case 128: FX_HIP((launch_span<128, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
-         case 64: FX_HIP((launch_span<64, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
-         case 32: FX_HIP((launch_span<32, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
-         default: FX_HIP((launch_span<16, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr))); break;
+      switch (span_cell(row_len)) {
+         case 128: FX_HIP((launch_span<128, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr, (uint32_t)row_len))); break;
+         case 64: FX_HIP((launch_span<64, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr, (uint32_t)row_len))); break;
+         case 32: FX_HIP((launch_span<32, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr, (uint32_t)row_len))); break;
+         default: FX_HIP((launch_span<16, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr, (uint32_t)row_len))); break;
       }
       return FXAMD_OK;
    }

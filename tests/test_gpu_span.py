@@ -37,6 +37,14 @@ def _rows(L, n, seed, hi_frac=0.0):
     hi = ["α".encode(), "ω".encode(), "あ".encode(), "é".encode(), b"\xf0\x9f\x98\x80", b"\x80", b"\xe3\x81", b"\xff", b"\xc0\xaf"]
     for i in range(n):
         kind = rng.random()
+        if L < 8:           # very short rows: a small alphabet, so that matches of every pattern occur
+            b = bytearray(rng.choice(b"ab01 -zfo\n") for _ in range(L))
+            if rng.random() < hi_frac:
+                s_ = rng.choice([x for x in hi if len(x) <= L])
+                k = rng.randint(0, L - len(s_))
+                b[k:k + len(s_)] = s_
+            out[i] = np.frombuffer(bytes(b), dtype=np.uint8)
+            continue
         if kind < 0.30:     # letters and blanks, digits planted late (config 3 / 5)
             b = bytearray(rng.choice(alpha + b"    ") for _ in range(L))
             if rng.random() < 0.5:
@@ -86,15 +94,20 @@ def _rows(L, n, seed, hi_frac=0.0):
     return out
 
 
+def _cell(L):
+    """bytes of LDS a row of L bytes gets in the span kernel (its length rounded up to 16 / 32 / 64 / 128)"""
+    return 16 if L <= 16 else (32 if L <= 32 else (64 if L <= 64 else 128))
+
+
 def _span_path(prog, L):
     """The path a search with spans over 128- / 64- / 32- / 16-byte rows takes by fxamd.hip's rule: 18 (span kernel + gated follow-up) for
     programs on the 8-state tables; None = another kernel."""
     fl = prog.info()["flags"]
     if not (fl & 8) or (fl & ((1 << 20) | (1 << 10))) or prog.info()["mode"] != 1:   # FXP_F_FAST_OK; FXP_F_NEEDS_NONASCII, FXP_F_RAW_BYTES
         return None
-    if (fl & 2) and L != 128 and not (int(os.environ.get("FXAMD_SPAN_LENS", "15")) & 16):   # FXP_F_PREFILTER: sparse matches -- the one-launch kernel's match compaction
+    if (fl & 2) and L <= 64 and not (int(os.environ.get("FXAMD_SPAN_LENS", "47")) & 16):   # FXP_F_PREFILTER: sparse matches -- the one-launch kernel's match compaction
         return None
-    return 18
+    return 18 if 2 <= L <= 128 else None
 
 
 def _check(fx, pat, rows_np, dev_rows, want_path, label):
@@ -114,21 +127,21 @@ def _check(fx, pat, rows_np, dev_rows, want_path, label):
     return prog, f, a, b
 
 
-@pytest.mark.parametrize("L", [128, 64, 32, 16])
+@pytest.mark.parametrize("L", [128, 64, 32, 16, 100, 80, 65, 48, 33, 20, 17, 12, 5, 2])
 @pytest.mark.parametrize("hi_frac", [0.0, 0.01, 0.5])
 def test_span_kernel_vs_oracle(fx, L, hi_frac, monkeypatch):
     """Every row kind x patterns of both kinds; a batch that ends inside a lane's span; the default grid and a two-block grid (many
     tiles per wave: the general procedure's queue overflows mid-loop); then the same rows through the one-launch kernel."""
     import torch
-    K = 128 // L
+    K = 128 // _cell(L)
     n = 64 * K * 37 + (K + 1 if K > 2 else 1)   # not a multiple of K * 64, nor of K
     rows = _rows(L, n, 100 * L + int(hi_frac * 100), hi_frac)
     dev_rows = torch.from_numpy(rows).cuda()
     n_span = 0
     for pat in PATS_DECODE + PATS_GEN:
         gen = pat in PATS_GEN
-        # (candidate-list driver programs take the span kernel at 128-byte rows only by default: FXAMD_SPAN_LENS=31 sends them there at every length)
-        monkeypatch.setenv("FXAMD_SPAN_LENS", "31") if gen else monkeypatch.delenv("FXAMD_SPAN_LENS", raising=False)
+        # (candidate-list driver programs take the span kernel at 128-byte rows only by default: FXAMD_SPAN_LENS=63 sends them there at every length)
+        monkeypatch.setenv("FXAMD_SPAN_LENS", "63") if gen else monkeypatch.delenv("FXAMD_SPAN_LENS", raising=False)
         for blocks in ("", "2"):
             monkeypatch.setenv("FXAMD_ONE_BLOCKS", blocks) if blocks else monkeypatch.delenv("FXAMD_ONE_BLOCKS", raising=False)
             monkeypatch.delenv("FXAMD_NO_SPAN", raising=False)
@@ -150,12 +163,12 @@ def test_span_kernel_vs_oracle(fx, L, hi_frac, monkeypatch):
     assert n_span >= 2 * 12, n_span   # (the span kernel did take the patterns it is meant for)
 
 
-@pytest.mark.parametrize("L", [128, 64, 32, 16])
+@pytest.mark.parametrize("L", [128, 64, 32, 16, 127, 99, 50, 21, 7, 3])
 def test_span_kernel_batch_ends_and_base_addresses(fx, L):
     """Every batch length around the tile's (K * 64 rows) and the span's (K rows) boundaries, 1 row included; base addresses that are
     not 16-byte aligned (unaligned tile loads, same kernel); results behind the batch's end stay untouched."""
     import torch
-    K = 128 // L
+    K = 128 // _cell(L)
     big = _rows(L, 64 * K * 3 + 7, 4242 + L, 0.02)
     pats = [r"[a-z]+\d+", r"foo(bar|baz)", r"\d+$"]
     refs = {p: oracle_lib.batch(2, p.encode(), big, NT) for p in pats}
@@ -194,7 +207,7 @@ def test_span_kernel_generated_configs_and_handle_reuse(fx, monkeypatch):
     pat = r"[a-z]+\d+"
     prog = fx.Program(pat, fx.OP_SEARCH)
     for rep in range(3):
-        for L in (128, 256, 64, 100, 32, 128, 16, 64):
+        for L in (128, 256, 64, 100, 32, 128, 16, 20, 200, 64):
             rows = _rows(L, 64 * 30 + 5, 9000 + L + rep, 0.05 if rep != 1 else 0.0)
             of, oa, ob = oracle_lib.batch(2, pat.encode(), rows, NT)
             f, a, b = prog.match_device(torch.from_numpy(rows).cuda())
@@ -237,8 +250,8 @@ def test_span_kernel_fuzz_patterns(fx):
     npat = int(os.environ.get("FX_FUZZ_PATTERNS", "60"))
     rng = random.Random(seed * 7919 + 5)
     paths = set()
-    for L in (128, 64, 32, 16):
-        rows = _rows(L, 64 * (128 // L) * 5 + 3, seed * 31 + L, 0.03)
+    for L in (128, 64, 32, 16, 100, 24, 9):
+        rows = _rows(L, 64 * (128 // _cell(L)) * 5 + 3, seed * 31 + L, 0.03)
         dev_rows = torch.from_numpy(rows).cuda()
         for _ in range(npat):
             pat = fuzz_diff.gen_pattern(rng).encode()
@@ -256,7 +269,7 @@ def test_span_kernel_fuzz_patterns(fx):
     assert 18 in paths, paths
 
 
-@pytest.mark.parametrize("L", [256, 128, 64, 32, 16])
+@pytest.mark.parametrize("L", [256, 128, 64, 32, 16, 100, 20, 6])
 def test_packed_results_from_the_first_pass_kernels(fx, L, monkeypatch):
     """Round 5: the half-row first pass of 256-byte rows and the span kernel write PACKED results themselves (the wave's ballot / the lanes'
     K bits folded into bytes, narrow spans) and leave a byte per deferred tile for the follow-up instead of the rows' flag bytes.  Against
@@ -266,7 +279,7 @@ def test_packed_results_from_the_first_pass_kernels(fx, L, monkeypatch):
     import torch
     from forgex_amd import dist as fxdist
     dev = torch.device("cuda")
-    K = max(1, 128 // L)
+    K = max(1, 128 // _cell(L)) if L <= 128 else 1
     sizes = [1, 63, 64, 65, 64 * K - 1, 64 * K, 64 * K + 1, 64 * K * 5 + 3, 64 * K * 41 + 64 + 7]
     pats = [r"[a-z]+\d+", r"\d+$", r"^[a-z]+"] + ([r"aa[bc]", r"foo(bar|baz)"] if L == 128 else [])
     for hi_frac in (0.0, 0.03, 0.9):
