@@ -98,10 +98,11 @@ def lib():
     L.fxamd_batch_info.argtypes = [vp, c.POINTER(i64), c.POINTER(i64)]
     L.fxamd_batch_run.argtypes = [c.POINTER(vp), c.c_int32, vp, c.c_int]
     L.fxamd_batch_sync.argtypes = [vp]
+    L.fxamd_batch_after.argtypes = [vp, vp]
     L.fxamd_batch_fetch.argtypes = [vp, c.c_int32, vp, vp, vp]
     L.fxamd_batch_count.argtypes = [vp, c.c_int32, c.POINTER(i64)]
     L.fxamd_batch_results.argtypes = [vp, c.POINTER(vp), c.POINTER(vp), c.POINTER(vp), i32p, c.POINTER(vp)]
-    for name in ("fxamd_batch_upload", "fxamd_batch_wrap", "fxamd_batch_info", "fxamd_batch_run", "fxamd_batch_sync", "fxamd_batch_fetch",
+    for name in ("fxamd_batch_upload", "fxamd_batch_wrap", "fxamd_batch_info", "fxamd_batch_run", "fxamd_batch_sync", "fxamd_batch_after", "fxamd_batch_fetch",
                  "fxamd_batch_count", "fxamd_batch_results"):
         getattr(L, name).restype = c.c_int
     L.fxamd_host_register.argtypes = [vp, i64]
@@ -117,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "fxamd_program_blob", "fxamd_program_from_blob", "fxamd_program_info", "fxamd_strerror", "fxamd_strerror_copy", "fxamd_program_upload", "fxamd_program_reserve",
     "fxamd_match_batch_device", "fxamd_packed_layout", "fxamd_match_batch_device_packed", "fxamd_unpack_results", "fxamd_match_multi_device", "fxamd_match_batch_host", "fxamd_last_path", "fxamd_last_hip_error", "fxamd_device_count",
     "fxamd_host_register", "fxamd_host_unregister", "fxamd_f_compile", "fxamd_f_program_free", "fxamd_f_strerror_copy", "fxamd_f_match_batch_host",
-    "fxamd_cache_trim", "fxamd_batch_upload", "fxamd_batch_wrap", "fxamd_batch_free", "fxamd_batch_info", "fxamd_batch_run", "fxamd_batch_sync", "fxamd_batch_fetch",
+    "fxamd_cache_trim", "fxamd_batch_upload", "fxamd_batch_wrap", "fxamd_batch_free", "fxamd_batch_info", "fxamd_batch_run", "fxamd_batch_sync", "fxamd_batch_after", "fxamd_batch_fetch",
     "fxamd_batch_count", "fxamd_batch_results", "fxamd_f_batch_upload", "fxamd_f_batch_wrap", "fxamd_f_batch_free", "fxamd_f_batch_run",
     "fxamd_f_batch_sync", "fxamd_f_batch_fetch", "fxamd_f_batch_count",
 ]

@@ -319,6 +319,9 @@ class Batch:
             n, rl = rows.shape
             self._keep = rows
             rc = L.fxamd_batch_wrap(ctypes.c_void_p(rows.data_ptr()), n, rl, ctypes.byref(h))
+            if rc == 0:   # the tensor's producer (torch's current stream on its device) goes before the batch's private stream
+                import torch
+                L.fxamd_batch_after(h, ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream))
         if rc != 0:
             raise RuntimeError("fxamd_batch_upload / _wrap failed: %d" % rc)
         self._h, self.n, self.row_len = h, int(n), int(rl)
@@ -335,7 +338,11 @@ class Batch:
     def run(self, progs, spans=True):
         progs = [progs] if isinstance(progs, Program) else list(progs)
         arr = (ctypes.c_void_p * len(progs))(*[p._h for p in progs])
+        if self._keep is not None:   # wrapped tensor: whatever torch's current stream did to it since goes first
+            import torch
+            _lib.lib().fxamd_batch_after(self._h, ctypes.c_void_p(torch.cuda.current_stream(self._keep.device).cuda_stream))
         rc = _lib.lib().fxamd_batch_run(arr, len(progs), self._h, 1 if spans else 0)
+        self._spans = bool(spans) and all(p.op == _lib.OP_SEARCH for p in progs)
         if rc != 0:
             raise RuntimeError("fxamd_batch_run failed: %d" % rc)
 
@@ -344,7 +351,9 @@ class Batch:
         if rc != 0:
             raise RuntimeError("fxamd_batch_sync failed: %d" % rc)
 
-    def fetch(self, which=0, spans=True):
+    def fetch(self, which=0, spans=None):
+        if spans is None:   # what the last run produced
+            spans = getattr(self, "_spans", True)
         flags = np.empty(self.n, np.uint8)
         frm = np.empty(self.n, np.int32) if spans else None
         to = np.empty(self.n, np.int32) if spans else None

@@ -925,14 +925,15 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    auto suffix_is_necessary_ending = [&]() -> bool {
       bool ok = lit.suffix.find('\0') == std::string::npos;
       // (Literals with NON-ASCII characters qualify since round 4.  The argument is made on characters and carries over to the bytes
-      //  the driver's INDEX works on: a match is prefix characters + a middle of >= 0 characters + suffix characters -- the length check
-      //  below keeps the two from overlapping -- so in bytes the suffix occurrence of a match starts at least |prefix| bytes behind its
-      //  start.  On pure-ASCII rows a non-ASCII literal never occurs: a necessary one means "no match", which is what the driver
+      //  the driver's INDEX works on.  The property used: every match is LONGER than the suffix (the length check below), so the suffix
+      //  occurrence that ends a match lies at least one character -- at least one byte -- behind the match's start; prefix and suffix
+      //  MAY overlap inside a match (`ab{2,}`: prefix `abb`, suffix `bb`).  On pure-ASCII rows a non-ASCII literal never occurs: a
+      //  necessary one means "no match", which is what the driver
       //  (prefix absent: brute force; suffix absent: no match) and the brute-force scan both say.  On rows the byte-level tables
       //  answer themselves -- valid CANONICAL UTF-8: overlong forms, which decode to the same code point but are other bytes, send a
       //  row of such a program to the general procedure -- byte occurrences are exactly the character-aligned ones.
       //  tests/support/fuzz_prefilter.py with FX_FUZZ_UTF8=1: see DESIGN.md 3.6.)
-      const std::vector<int32_t> sc = decode_chars(lit.suffix), pc = decode_chars(lit.prefix);
+      const std::vector<int32_t> sc = decode_chars(lit.suffix);
       Bits Wb = rclos[static_cast<size_t>(nfa.exit)];
       for (size_t i = sc.size(); ok && i-- > 0;) {
          if (bt(Wb, nfa.entry)) ok = false;
@@ -978,7 +979,6 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
          //  rounds 1-3 asked for m >= |prefix| + |suffix|, which sent `ab{2,}` (prefix `abb`, suffix `bb`) to the general kernel.  A match
          //  that IS the suffix -- `A{1,2}bb` on `Abb`: prefix `A`, suffix `Abb` -- is cut off by the reference when no later occurrence
          //  follows: such programs keep the statement-for-statement driver.)
-         (void)pc;
          if (shortest < 0 || static_cast<size_t>(shortest) < sc.size() + 1) ok = false;
       }
       return ok;

@@ -2007,6 +2007,7 @@ struct fxamd_batch {
    int32_t *d_from = nullptr, *d_to = nullptr;
    int64_t cap_flags = 0, cap_spans = 0;   // result sets the buffers hold (in rows: sets * n)
    unsigned long long* d_count = nullptr;
+   hipEvent_t ev = nullptr;                 // fxamd_batch_after: orders a producer stream before the batch's stream
    int32_t sets = 0;                        // result sets of the last run
    bool spans = false;                      // ... and whether it wrote from / to
    std::mutex mu;
@@ -2018,13 +2019,27 @@ static int batch_make(const uint8_t* d_rows, bool owns, int64_t n, int64_t row_l
    b->owns_rows = owns;
    b->n = n;
    b->row_len = row_len;
-   if (hipGetDevice(&b->dev) != hipSuccess || hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess ||
-       hipMalloc((void**)&b->d_count, sizeof(unsigned long long)) != hipSuccess) {
+   // the device the rows live on (a wrapped pointer need not be on the current one): the batch's stream and buffers are made there
+   int cur = -1;
+   bool ok = hipGetDevice(&cur) == hipSuccess;
+   b->dev = cur;
+   if (ok && d_rows != nullptr) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, d_rows) == hipSuccess) b->dev = at.device;
+      else (void)hipGetLastError();
+   }
+   if (ok && b->dev != cur) ok = hipSetDevice(b->dev) == hipSuccess;
+   ok = ok && hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void**)&b->d_count, sizeof(unsigned long long)) == hipSuccess &&
+        hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) == hipSuccess;
+   if (!ok) {
       g_last_hip_error = (int)hipGetLastError();
       if (b->st) (void)hipStreamDestroy(b->st);
+      if (b->d_count) (void)hipFree(b->d_count);
+      if (cur >= 0 && b->dev != cur) (void)hipSetDevice(cur);
       delete b;
       return FXAMD_E_HIP;
    }
+   if (b->dev != cur) (void)hipSetDevice(cur);
    *out = b;
    return FXAMD_OK;
 }
@@ -2062,7 +2077,18 @@ void fxamd_batch_free(fxamd_batch* b) {
    if (b->d_from) (void)hipFree(b->d_from);
    if (b->d_to) (void)hipFree(b->d_to);
    if (b->d_count) (void)hipFree(b->d_count);
+   if (b->ev) (void)hipEventDestroy(b->ev);
    delete b;
+}
+// Everything enqueued so far on `producer_hip_stream` (the kernel that wrote wrapped rows, a consumer still reading the result buffers of
+// fxamd_batch_results) happens before whatever the batch enqueues next: the batch runs on a private non-blocking stream that nothing
+// else orders against the caller's streams.
+int fxamd_batch_after(fxamd_batch* b, void* producer_hip_stream) {
+   if (!b) return FXAMD_E_ARG;
+   std::lock_guard<std::mutex> g(b->mu);
+   FX_HIP(hipEventRecord(b->ev, (hipStream_t)producer_hip_stream));
+   FX_HIP(hipStreamWaitEvent(b->st, b->ev, 0));
+   return FXAMD_OK;
 }
 int fxamd_batch_info(const fxamd_batch* b, int64_t* n, int64_t* row_len) {
    if (!b) return FXAMD_E_ARG;
@@ -2097,6 +2123,9 @@ int fxamd_batch_run(fxamd_program* const* progs, int32_t m, fxamd_batch* b, int 
    for (int32_t i = 0; i < m; ++i)
       if (!progs[i]) return FXAMD_E_ARG;
    std::lock_guard<std::mutex> g(b->mu);
+   // (the buffers may be reallocated below: until this run has succeeded the batch advertises no result sets -- ADVICE r04)
+   b->sets = 0;
+   b->spans = false;
    int cur = -1;
    FX_HIP(hipGetDevice(&cur));
    if (cur != b->dev) FX_HIP(hipSetDevice(b->dev));
@@ -2125,6 +2154,15 @@ int fxamd_batch_fetch(fxamd_batch* b, int32_t which, uint8_t* h_flags, int32_t* 
    if (!b || which < 0 || (h_from == nullptr) != (h_to == nullptr)) return FXAMD_E_ARG;
    std::lock_guard<std::mutex> g(b->mu);
    if (which >= b->sets || (h_from && !b->spans)) return FXAMD_E_ARG;
+   int cur = -1;
+   FX_HIP(hipGetDevice(&cur));
+   if (cur != b->dev) FX_HIP(hipSetDevice(b->dev));
+   struct Back {
+      int cur, dev;
+      ~Back() {
+         if (cur != dev) (void)hipSetDevice(cur);
+      }
+   } back{cur, b->dev};
    const size_t o = (size_t)which * (size_t)b->n;
    if (b->n != 0) {
       if (h_flags) FX_HIP(hipMemcpyAsync(h_flags, b->d_flags + o, (size_t)b->n, hipMemcpyDeviceToHost, b->st));
@@ -2141,6 +2179,15 @@ int fxamd_batch_count(fxamd_batch* b, int32_t which, int64_t* n_matches) {
    if (!b || which < 0 || !n_matches) return FXAMD_E_ARG;
    std::lock_guard<std::mutex> g(b->mu);
    if (which >= b->sets) return FXAMD_E_ARG;
+   int cur = -1;
+   FX_HIP(hipGetDevice(&cur));
+   if (cur != b->dev) FX_HIP(hipSetDevice(b->dev));
+   struct Back {
+      int cur, dev;
+      ~Back() {
+         if (cur != dev) (void)hipSetDevice(cur);
+      }
+   } back{cur, b->dev};
    unsigned long long c = 0;
    if (b->n != 0) {
       FX_HIP(hipMemsetAsync(b->d_count, 0, sizeof(unsigned long long), b->st));

@@ -143,7 +143,13 @@ int64_t fxamd_cache_trim(void);
  * batch's own stream (asynchronous) and leaves the results in device buffers the batch owns: result set i = flags[i*n .. i*n+n) and,
  * with spans, from / to likewise (`.match.` programs: flags only).  fxamd_batch_fetch copies one result set to host arrays,
  * fxamd_batch_count reduces its flags on the device (8 bytes cross the bus), fxamd_batch_results hands out the device pointers.
- * fetch / count / sync are synchronous; the entries of one batch are serialised. */
+ * fetch / count / sync are synchronous; the entries of one batch are serialised.
+ * Stream ordering: a batch works on a PRIVATE non-blocking stream (fxamd_batch_results hands it out) on the device its rows live on.
+ * Nothing orders that stream against the caller's: wrapped rows must be complete when fxamd_batch_run is called -- or the caller says
+ * which stream produces them: fxamd_batch_after(b, stream) makes everything enqueued on `stream` so far happen before the batch's next
+ * work (an event recorded on `stream`, waited for on the batch's stream; also how a consumer that still reads the result buffers of the
+ * previous run is put before the next one).  Results handed out by fxamd_batch_results are complete after fxamd_batch_sync, or for work
+ * the caller orders behind the batch's stream itself. */
 typedef struct fxamd_batch fxamd_batch;
 int fxamd_batch_upload(const uint8_t* h_rows, int64_t n, int64_t row_len, fxamd_batch** out);
 int fxamd_batch_wrap(const uint8_t* d_rows, int64_t n, int64_t row_len, fxamd_batch** out);
@@ -151,6 +157,7 @@ void fxamd_batch_free(fxamd_batch* b);
 int fxamd_batch_info(const fxamd_batch* b, int64_t* n, int64_t* row_len);
 int fxamd_batch_run(fxamd_program* const* progs, int32_t m, fxamd_batch* b, int with_spans);
 int fxamd_batch_sync(fxamd_batch* b);
+int fxamd_batch_after(fxamd_batch* b, void* producer_hip_stream);
 int fxamd_batch_fetch(fxamd_batch* b, int32_t which, uint8_t* h_flags, int32_t* h_from, int32_t* h_to);
 int fxamd_batch_count(fxamd_batch* b, int32_t which, int64_t* n_matches);
 int fxamd_batch_results(fxamd_batch* b, const uint8_t** d_flags, const int32_t** d_from, const int32_t** d_to, int32_t* sets, void** hip_stream);
