@@ -355,6 +355,9 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
                                                           const uint32_t Lr_in) {
    // fp.out_mode == 1: PACKED results (what a multi-GPU host gathers): `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit
    // word i >> 6), `from` / `to` = one byte per row (rows of up to 128 bytes); "this tile is left to the follow-up" = marks[64-row tile] = 1
+   // (The chain tables were tried as well -- 128-byte rows of a 17-state pattern: 0.504 ms against 0.494 ms for the 64-byte halves of
+   //  fx_search_fast<4, ..., LONG>, gpurun call r05_c14: whole lines instead of split ones, but the dependent LDS read per byte is what that
+   //  scheme waits for -- and are not built.)
    static_assert(SCH == 0 || SCH == 2, "class-level v_perm or nibble tables");
    using S = FxSpan<RL>;
    using F = typename FxF<SCH>::type;
@@ -419,6 +422,8 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
    __syncthreads();
    const F* tabR = tabR_s;
    const F* tabA = tabA_s;
+   const uint8_t* const TRp = nullptr;   // (the v_perm and nibble steps read no table through the state)
+   const uint8_t* const TAp = nullptr;
    const uint8_t* const tb = reinterpret_cast<const uint8_t*>(tile);
    const uint8_t* const eor = reinterpret_cast<const uint8_t*>(eor_cell);
    constexpr uint32_t QCAP = 128u;
@@ -465,12 +470,12 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
       if (!defer_tile) {
          if constexpr (!COMPACT) {
             uint32_t gsel, esel, state;
-            fx_span_back<RL, SCH, RAG>(tile, lane, 0u, tabR, nullptr, fp, tl, na, gsel, esel, state);
+            fx_span_back<RL, SCH, RAG>(tile, lane, 0u, tabR, TRp, fp, tl, na, gsel, esel, state);
             const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
             sink = fp.inv_on != 0u && state == fp.inv;
             const bool want = hit || nul;
             if (__builtin_amdgcn_ballot_w64(want) != 0)
-               res[0] = fx_span_finish<RL, SCH, 2, RAG>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, nullptr, nullptr, fp, Lr);
+               res[0] = fx_span_finish<RL, SCH, 2, RAG>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, TRp, TAp, fp, Lr);
          } else {
             // every row's backward pass; the rows that need the finish take a slot: lane | row << 6 | hit group << 9 | nul << 13 | entry state << 14.
             // Until its slot is finished a row's result register holds the slot number (bit 31 set).
@@ -480,14 +485,14 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
                const uint32_t en = on ? sq[(base + lane) % QCAP] : 0u;
                const uint32_t e8 = en >> 14;
                const uint32_t r = fx_span_finish<RL, SCH, FX_SPAN_GB, RAG>(tb, eor, en & 63u, ((en >> 6) & 7u) * (uint32_t)NCH, (en >> 9) & 15u, SCH == 0 ? e8 * 0x01010101u : e8,
-                                                                           ((en >> 13) & 1u) != 0u, on, tabR, tabA, nullptr, nullptr, fp, Lr);
+                                                                           ((en >> 13) & 1u) != 0u, on, tabR, tabA, TRp, TAp, fp, Lr);
                if (on) sq[(base + lane) % QCAP] = r;
             };
             uint32_t done = 0;   // slots finished (wave-uniform; K > 2: the ring holds 128 and whole passes are finished when the next row's slots may not fit)
 #pragma unroll
             for (int jr = K - 1; jr >= 0; --jr) {
                uint32_t gsel, esel, state;
-               fx_span_back<RL, SCH, RAG>(tile, lane, (uint32_t)(jr * NCH), tabR, nullptr, fp, tl, na, gsel, esel, state);
+               fx_span_back<RL, SCH, RAG>(tile, lane, (uint32_t)(jr * NCH), tabR, TRp, fp, tl, na, gsel, esel, state);
                const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
                sink = sink || (fp.inv_on != 0u && state == fp.inv);
                const bool want = hit || nul;
@@ -672,7 +677,10 @@ hipError_t launch_span(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    if (!from || !to) return hipErrorInvalidValue;   // (searches with spans only: fxamd.hip, span_kind)
    const bool rag = Lr != (uint32_t)RL;
 #define FX_SPAN_GO(P, R) hipLaunchKernelGGL((fx_search_span<RL, SCH, P, R>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks, Lr)
-   if (fp.out_mode != 0u) {
+   if constexpr (SCH != 0) {   // nibble tables: aligned rows, plain results (fxamd.hip, span_first)
+      if (rag || fp.out_mode != 0u) return hipErrorInvalidValue;
+      FX_SPAN_GO(false, false);
+   } else if (fp.out_mode != 0u) {
       if (rag) FX_SPAN_GO(true, true);
       else FX_SPAN_GO(true, false);
    } else {

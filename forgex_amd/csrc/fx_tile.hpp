@@ -804,8 +804,15 @@ __device__ unsigned long long fx_stamp_acc[16];
 // LONG: rows longer than 256 bytes (any length up to 64 KiB), CH = 16: the backward pass walks the row segment by segment through the
 // same LDS tile, the short forward pass reads its bytes straight from global memory.  First-pass and BYTES modes only.
 // (no end-of-row chunk column in LDS for the segment-walking kernels once their forward pass reads global memory only)
-template <int CH, bool SPANS, bool LONG>
+// Round 5 (FX_LONG_CAP): the segment walkers with spans keep TWO more chunk columns per row -- the first 32 bytes of the segment to the
+// RIGHT of the one in the tile (or what follows the row's end: NUL, KILL symbols) -- so that the 40 bytes from a hit group on can be
+// captured into registers while its segment is in LDS: the exact start and the forward window then read registers, not global memory.
+#ifndef FX_LONG_CAP
+#define FX_LONG_CAP 1
+#endif
+template <int CH, bool SPANS, bool LONG, bool NOHALF = false>
 constexpr int fx_tile_cols() {
+   if (FX_LONG_CAP != 0 && LONG && SPANS && CH == 16) return CH + 2;
    return (!LONG || (CH <= 8 && SPANS && FX_DEFER_LONG == 0 && FX_HALF4 == 0)) ? CH + 1 : CH;
 }
 // NOHALF (round 4; LONG with CH = 8 only): rows longer than 256 bytes walked in 128-byte segments -- the half-row kernel's lean loop and
@@ -898,7 +905,12 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    __shared__ uint32_t fwd_q[DEFER ? 4 * 64 * 2 : 1];   // match compaction: per wave 64 x (row, hit group | entry state << 16)
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    // chain scheme: symbol -> 2*column map (512 B), then T_R, then T_A, behind the tiles
-   constexpr int COLS = fx_tile_cols<CH, SPANS, LONG>();   // chunk columns per row in LDS: the row's chunks [+ the end-of-row column]
+   constexpr int COLS = fx_tile_cols<CH, SPANS, LONG, NOHALF>();   // chunk columns per row in LDS: the row's chunks [+ the end-of-row column / the look-ahead columns]
+   constexpr bool CAP = FX_LONG_CAP != 0 && LONG && SPANS && CH == 16;   // (see fx_tile_cols)
+   // ... for rows below FX_LONG_NT_MIN bytes (wave-uniform): measured in one allocation against a build without it (gpurun call r05_c12): rows of
+   // 400 B 0.889 -> 0.850 ms, 1024 B 0.536 -> 0.518 ms, but 4096 B 0.489 -> 0.498 ms (the look-ahead copy per segment costs more than the rare
+   // re-read saves); the 128-byte segment walker of the chain tables (NOHALF) loses its fourth wave per SIMD to the two columns: 0.66 -> 0.78 ms, not built
+   const bool cap_on = CAP && Lr < FX_LONG_NT_MIN;
    // (HALF4: the four shared end-of-row cells come first behind the tiles, see below)
    uint16_t* cmap = reinterpret_cast<uint16_t*>(tiles + 4 * 64 * COLS + (HALF4 ? 4 : 0));
    const uint32_t tr_bytes = BYTES ? h->byte_TR_bytes : h->chain_TR_bytes, ta_bytes = BYTES ? h->byte_TA_bytes : h->chain_TA_bytes;
@@ -942,7 +954,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    // one extra chunk column per row holds what follows the text: the trailing NUL (symbol 0), then KILL symbols (0xFE, whose table
    // row is all-dead), so the forward pass reads "past the end" like any other position.  Written once, never overwritten.
    uint4* tile = tiles + wave * (64 * COLS);
-   if constexpr (COLS > CH) tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+   if constexpr (COLS > CH && !CAP) tile[tile_cell(lane, CH)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
    // HALF4: one shared end-of-row cell per wave behind the four tiles (the speculative forward pass on the half row in LDS reads it)
    uint4* const eor_cell = tiles + 4 * 64 * COLS + wave;
    if (HALF4 && lane == 0) *eor_cell = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
@@ -974,12 +986,27 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    // chain; per 8-byte group only "any accept" (v_max3) + entry state are kept and the last accepting group is re-walked for the
    // exact byte -- then 8 symbols per round trip while any lane is alive.  `src`: the LDS tile (FROM_GLOBAL false) or the row itself
    // in global memory; Lx: the length of what `src` holds (the virtual end-of-row symbols follow it).  mm: max_match so far, updated.
-   auto forward_pass = [&](auto from_global, const uint8_t* src, const uint32_t Lx, uint32_t cur, uint32_t& mm, uint32_t j) {
+   // (capd: the 40 bytes from the hit group on, captured while their segment was in LDS -- CAP; lanes that start at the leading NUL read the
+   //  row's first bytes from global memory as before)
+   auto forward_pass = [&](auto from_global, const uint8_t* src, const uint32_t Lx, uint32_t cur, uint32_t& mm, uint32_t j, const uint32_t* capd = nullptr,
+                           const bool use_cap = false) {
       constexpr bool FG = decltype(from_global)::value;
       if (__builtin_amdgcn_ballot_w64(cur != 0) == 0) return;
       uint32_t o[8];
       const uint8_t* const eor = FG ? nullptr : eor8;
-      fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor);
+      if (capd != nullptr) {
+         if (__builtin_amdgcn_ballot_w64(cur != 0 && !use_cap) != 0) fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor);
+         else
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = 0u;
+         const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
+         uint32_t e[9];
+#pragma unroll
+         for (int k = 0; k < 9; ++k) e[k] = (up & capd[k + 1]) | (~up & capd[k]);
+#pragma unroll
+         for (int k = 0; k < 8; ++k) o[k] = use_cap ? __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u) : o[k];
+      } else
+         fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor);
 #ifndef FX_FWD_GB_LDS
 #define FX_FWD_GB_LDS 4
 #endif
@@ -1116,6 +1143,9 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       uint32_t gsel = 0xFFFFFFFFu, esel = 0;   // leftmost 8-byte group holding a hit, and the state entering it
       uint32_t na = 0;
       uint32_t s_half = 0, mm_half = 0;   // half-row staging: start / max_match resolved while the right half was in LDS
+      uint32_t cap[CAP ? 10 : 1];          // CAP: the five 8-byte groups from the leftmost hit group on (row bytes, then NUL, then KILL symbols)
+#pragma unroll
+      for (int i = 0; i < (CAP ? 10 : 1); ++i) cap[i] = 0u;
       for (uint32_t seg = S - 1u;; --seg) {   // one pass unless LONG: the row's 256-byte segments, right to left
          if (!LIST) {
             const bool process = live;
@@ -1126,6 +1156,24 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                defer_early = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
             }
             if (process) STORE_TILE(stage);
+            if constexpr (CAP) {
+               // the row's LAST segment (the first one staged): what follows the text -- the trailing NUL, then KILL symbols -- behind its
+               // seg_len bytes: the chunk the row ends in is patched, up to three chunks behind it are written (the look-ahead columns when
+               // the segment is whole).  Wave-uniform positions, the lane's own cells.
+               if (cap_on && process && seg == S - 1u) {
+                  const uint32_t sl = Lr - seg * SEGB;   // 1 .. SEGB
+                  const uint32_t kt = sl >> 4, nb = sl & 15u;
+                  if (nb != 0u) {
+                     uint4 c = tile[tile_cell(lane, kt)];
+                     c.x = fx_tail_word(c.x, 0u, nb);
+                     c.y = fx_tail_word(c.y, 4u, nb);
+                     c.z = fx_tail_word(c.z, 8u, nb);
+                     c.w = fx_tail_word(c.w, 12u, nb);
+                     tile[tile_cell(lane, kt)] = c;
+                  } else tile[tile_cell(lane, kt)] = make_uint4(0xFEFEFE00u, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+                  for (uint32_t k = kt + 1u; k <= kt + 3u && k < (uint32_t)COLS; ++k) tile[tile_cell(lane, k)] = make_uint4(0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu, 0xFEFEFEFEu);
+               }
+            }
             STAMP(0);
             // (wave-private tile: LDS operations of one wave complete in order, no barrier needed)
             // the ONE place the staging registers are reloaded (a second load site would meet this one in a register merge at the
@@ -1247,6 +1295,27 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
             if (seg_len == SEGB) walk(std::true_type{});
             else walk(std::false_type{});
          }
+         if constexpr (CAP) {
+            // a hit in THIS segment is the leftmost so far: the 40 bytes from its group on go to registers while they are in LDS (its own
+            // chunks and, past the segment's right edge, the look-ahead columns)
+            const bool newhit = gsel < gbase + 2u * (uint32_t)CH;   // (segments go right to left: a hit recorded further right has a larger group number; none: 0xFFFFFFFF)
+            if (cap_on && __builtin_amdgcn_ballot_w64(newhit) != 0) {
+               const uint32_t gl = newhit ? gsel - gbase : 0u;
+#pragma unroll
+               for (int q = 0; q < 5; ++q) {
+                  const uint32_t p = (gl + (uint32_t)q) << 3;   // local byte position: < 16 * (CH + 2)
+                  const uint2 r = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, p >> 4) << 4) + (p & 8u));
+                  cap[2 * q] = newhit ? r.x : cap[2 * q];
+                  cap[2 * q + 1] = newhit ? r.y : cap[2 * q + 1];
+               }
+            }
+            // the segment's first 32 bytes become the look-ahead of the one to its left (before that one is stored over them)
+            if (cap_on && seg != 0u) {
+               const uint4 h0 = tile[tile_cell(lane, 0)], h1 = tile[tile_cell(lane, 1)];
+               tile[tile_cell(lane, CH)] = h0;
+               tile[tile_cell(lane, CH + 1)] = h1;
+            }
+         }
          if constexpr (HALFROW && !DEFER) {
             // Half-row staging (two segments per row): the right half is in LDS now and will be overwritten by the left one.  A row
             // whose leftmost hit SO FAR lies here gets its exact start and -- speculatively: a hit in the left half supersedes it --
@@ -1290,7 +1359,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          const uint32_t g = (gsel != 0xFFFFFFFFu && here) ? gsel : 0u;
          uint2 rw;
          uint32_t nv = 8;   // LONG: valid bytes of the group (the row may end inside it)
-         if (LONG && !HALFROW) {   // (its segment left the tile: from global memory)
+         if (CAP && cap_on) {   // (captured while its segment was in LDS)
+            rw = make_uint2(cap[0], cap[1]);
+            if (g * 8u + 8u > L) nv = L - g * 8u;   // the row ends inside the group: only its text bytes were walked
+         } else if (LONG && !HALFROW) {   // (its segment left the tile: from global memory)
             rw = make_uint2(0, 0);
             if (row_ok) {
                const uint8_t* rp = rows + row * (int64_t)L;
@@ -1364,7 +1436,8 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          mm = cur >= fp.acc_min ? 2u : 0u;
       }
       STAMP(3);
-      forward_pass(std::integral_constant<bool, LONG>{}, fsrc, (uint32_t)L, cur, mm, j);
+      if constexpr (CAP) forward_pass(std::integral_constant<bool, LONG>{}, fsrc, (uint32_t)L, cur, mm, j, cap, cap_on && s >= 2u);   // (always the array itself: a pointer that may be null would send it to scratch memory)
+      else forward_pass(std::integral_constant<bool, LONG>{}, fsrc, (uint32_t)L, cur, mm, j);
       if (HALFROW && !DEFER && !fwd_here && fp.lit_len == 0) mm = mm_half;
       STAMP(5);
       uint32_t flag = 0;

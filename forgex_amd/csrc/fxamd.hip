@@ -45,6 +45,10 @@ extern template hipError_t launch_span<128, 0> FX_SPAN_SIG;
 extern template hipError_t launch_span<64, 0> FX_SPAN_SIG;
 extern template hipError_t launch_span<32, 0> FX_SPAN_SIG;
 extern template hipError_t launch_span<16, 0> FX_SPAN_SIG;
+extern template hipError_t launch_span<128, 2> FX_SPAN_SIG;
+extern template hipError_t launch_span<64, 2> FX_SPAN_SIG;
+extern template hipError_t launch_span<32, 2> FX_SPAN_SIG;
+extern template hipError_t launch_span<16, 2> FX_SPAN_SIG;
 extern template hipError_t launch_multi<1> FX_MULTI_SIG;
 extern template hipError_t launch_multi<2> FX_MULTI_SIG;
 extern template hipError_t launch_multi<3> FX_MULTI_SIG;
@@ -55,7 +59,7 @@ extern template hipError_t launch_multi<8> FX_MULTI_SIG;
 
 // ---- test / experiment hooks: the FXAMD_* environment variables, read once (FxEnv, fx_tile.hpp) ----
 #ifndef FX_SPAN_LENS_DEFAULT
-#define FX_SPAN_LENS_DEFAULT 47   // row lengths the span kernel takes by default (bit mask: 128, 64, 32, 16; 32 = ragged rows)
+#define FX_SPAN_LENS_DEFAULT 111  // row lengths the span kernel takes by default (bit mask: 128, 64, 32, 16; 32 = ragged rows; 64 = nibble tables)
 #endif
 static FxEnv g_env;
 static std::once_flag g_env_once;
@@ -799,7 +803,7 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
 // finish pass per 8 KB tile (BASELINE config 2, one row in ten matching: 18.2 us against 19.5 us + 1.6 us of follow-up launch).
 // FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook); FXAMD_SPAN_LENS: bit mask of the row lengths it takes (1: 128, 2: 64,
 // 4: 32, 8: 16 -- the LDS bytes a row gets: its length rounded up to those; +16: candidate-list driver programs at every length; +32: ragged
-// rows, any length 2..127 that is not one of the four; experiment hook).
+// rows, any length 2..127 that is not one of the four; +64: first pass of the multi-pass pipeline on the nibble tables; experiment hook).
 static int span_cell(int64_t row_len) { return row_len <= 16 ? 16 : (row_len <= 32 ? 32 : (row_len <= 64 ? 64 : 128)); }   // bytes of LDS a row gets (fx_span.hpp: RL)
 static bool span_kind(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
    if (!spans || scheme != 0 || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) || fx_env().multipass || fx_env().no_span)
@@ -915,7 +919,20 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
          else if (cap != hipStreamCaptureStatusNone) span = false;
       }
-      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !fx_env().multipass;
+      // ... and as the FIRST PASS of the multi-pass pipeline for automata of 9..16 states (round 5): aligned rows of 128 / 64 / 32 / 16 bytes on
+      // the nibble tables; the tiles it marks go to the passes that pipeline has (byte-level tables over marked tiles / the decode pass), so it
+      // needs one of the two.  last_path 20.  Measured (gpurun calls r05_c14 / c15, FXAMD_NO_SPAN=1 as the other arm): 16-byte rows 0.862 -> 0.575 ms,
+      // 128-byte rows 0.3225 -> 0.3177 ms.  (The chain tables at 128-byte rows: 0.504 against 0.494 ms on round 4's 64-byte halves -- not built.)
+      bool span_first = false;
+      if (first_pass == FX_FP_OWN && out_mode == 0u && !is_match && !tiny && !span && h.mode == FXP_MODE_SEARCH_ENGINE && d_from != nullptr && d_to != nullptr &&
+          !(h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) && !fx_env().multipass && !fx_env().no_span && (fx_env().span_lens & 64) &&
+          scheme == 2 && (row_len == 128 || row_len == 64 || row_len == 32 || row_len == 16) &&
+          (scheme_decodes_utf8(h, scheme) || bytes_ok(h, d_rows, row_len))) {
+         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+         span_first = cap == hipStreamCaptureStatusNone;
+      }
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !span_first && !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
@@ -1050,7 +1067,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
          p->last_path = 1 + big;
          return FXAMD_OK;
       }
-      if (bytes && scheme != 0 && first_pass == FX_FP_OWN && !first.half) {
+      if (bytes && scheme != 0 && first_pass == FX_FP_OWN && !first.half && !span_first) {
          // no 8-state class-level tables to be faster with on ASCII: the byte-level tables take every tile, UTF-8 or not, in one pass
          if (is_match) FX_HIP(match_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
          else FX_HIP(fast_by<2>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
@@ -1091,7 +1108,14 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       if (first_pass == FX_FP_DONE) {
          // (done by the shared kernel)
       } else if (is_match) FX_HIP(match_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, first));
-      else FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
+      else if (span_first) {
+         FastParams fps = params_of(h, scheme, false);
+         fps.defer_tiles = 1u;
+         if (row_len == 128) FX_HIP((launch_span<128, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 128u)));
+         else if (row_len == 64) FX_HIP((launch_span<64, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 64u)));
+         else if (row_len == 32) FX_HIP((launch_span<32, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 32u)));
+         else FX_HIP((launch_span<16, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 16u)));
+      } else FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
       if (bytes) {
          // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass
          // (a shared first pass that scanned those tiles itself has deferred none: only its exception rows are left)
@@ -1102,14 +1126,14 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
             }
          } else if (is_match) FX_HIP(match_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
          else FX_HIP(fast_by<3>(bsch, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
-         p->last_path = 8;
+         p->last_path = span_first ? 20 : 8;
          return exceptions();
       }
       if (utf8_tables) {
          // deferred tiles: the decode pass rewrites UTF-8 to symbol ids in LDS and scans only those tiles
          if (is_match) FX_HIP(match_by<1>(scheme, h, d_blob, d_rows, n, row_len, d_flags, ctr, st, marked));
          else FX_HIP(fast_by<1>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, marked));
-         p->last_path = 1 + big;
+         p->last_path = span_first ? 20 : 1 + big;
          return FXAMD_OK;
       }
       // rows holding bytes >= 0x80 (and overlap rows) were listed one by one: row-level fix-up over that list

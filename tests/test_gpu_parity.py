@@ -404,7 +404,7 @@ def test_chain_scheme_patterns_vs_oracle(fx, wide, monkeypatch):
                 off = int(nrng.integers(0, L - len(sd)))
                 rows[i, off:off + len(sd)] = sd
             prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
-            assert prog.last_path() in (5, 6, 7, 8, 9, 11, 12, 14), (pat, L, prog.last_path())   # (8: 256-byte rows, half-row first pass)
+            assert prog.last_path() in (5, 6, 7, 8, 9, 11, 12, 14, 20), (pat, L, prog.last_path())   # (8: 256-byte rows, half-row first pass; 20: the span kernel as first pass)
             of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
             assert np.array_equal(f, of), (pat, L)
             assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L)
@@ -1725,6 +1725,7 @@ def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
     pats = [rb"\d{3}-\d{4}", rb"[a-z0-9]+@[a-z0-9]+\.[a-z]{2,4}", rb"[a-z]{6}\d{1,3}[a-z ]{6}", rb"\d{4}-\d{2}-\d{2}", "[ぁ-ん]{3}[ァ-ヶ]{3}\\d+".encode(), rb"^[a-k]{5}.*\d{2}$",
             rb"(19|20)\d\d-(0[1-9]|1[012])-(0[1-9]|[12][0-9]|3[01])"]
     n_half = {256: 0, 128: 0}
+    n_span20 = [0]
     for L in (256, 128):
         n = 64 * 37 + 11
         H = L // 2
@@ -1747,13 +1748,26 @@ def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
                 of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
                 for spans in (True, False):
                     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
-                    prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
-                    fl = prog.info()["flags"]
-                    if not (fl & 8) and (fl & ((1 << 13) | 256)):   # no 8-state tables; nibble tables (taken when present) or chain tables
-                        # (FXP_F_NEEDS_NONASCII programs keep the one-launch kernel; 128-byte rows: the chain tables only)
-                        want_half = not (fl & (1 << 20)) and (L == 256 or not (fl & (1 << 13)))
-                        assert (prog.last_path() in (5, 6, 8)) == want_half, (pat, L, kind, spans, prog.last_path())
-                        n_half[L] += 1 if want_half else 0
+                    # (round 5: 128-byte rows with spans take the span kernel as their first pass -- last_path 20; FXAMD_SPAN_LENS without bit 6
+                    #  keeps round 4's dispatch, the 64-byte halves of the chain tables)
+                    for lens in ("", "47"):
+                        monkeypatch.setenv("FXAMD_SPAN_LENS", lens) if lens else monkeypatch.delenv("FXAMD_SPAN_LENS", raising=False)
+                        prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
+                        fl = prog.info()["flags"]
+                        if not (fl & 8) and (fl & ((1 << 13) | 256)):   # no 8-state tables; nibble tables (taken when present) or chain tables
+                            # (FXP_F_NEEDS_NONASCII programs keep the one-launch kernel; 128-byte rows: the chain tables only)
+                            want_half = not (fl & (1 << 20)) and (L == 256 or not (fl & (1 << 13)))
+                            if L == 128 and spans and not lens and not (fl & (1 << 20)):
+                                assert prog.last_path() in (20, 5, 6, 8), (pat, L, kind, prog.last_path())   # (5 / 6 / 8: chain tables too large for the span kernel's LDS)
+                                n_span20[0] += 1 if prog.last_path() == 20 else 0
+                            else:
+                                assert (prog.last_path() in (5, 6, 8)) == want_half, (pat, L, kind, spans, lens, prog.last_path())
+                            n_half[L] += 1 if (want_half and lens) or L == 256 else 0
+                        bad0 = np.nonzero(f != of)[0]
+                        assert bad0.size == 0, (pat, L, kind, spans, lens, int(bad0[0]))
+                        if spans:
+                            assert np.array_equal(a, oa) and np.array_equal(b, ob), (pat, L, kind, lens)
+                    monkeypatch.delenv("FXAMD_SPAN_LENS", raising=False)
                     bad = np.nonzero(f != of)[0]
                     assert bad.size == 0, (pat, L, kind, spans, int(bad[0]), int(f[bad[0]]), int(of[bad[0]]))
                     if spans:
@@ -1762,7 +1776,7 @@ def test_half_rows_for_chain_and_nibble_tables(fx, monkeypatch):
                     prog2, f2, a2, b2 = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=spans)
                     assert prog2.last_path() not in (5, 6, 8) and np.array_equal(f2, of), (pat, L, kind, spans, prog2.last_path())
     monkeypatch.delenv("FXAMD_HALF_SCH", raising=False)
-    assert n_half[256] >= 24 and n_half[128] >= 12, n_half
+    assert n_half[256] >= 24 and n_half[128] >= 12 and n_span20[0] >= 6, (n_half, n_span20)
 
 
 def test_match_half_rows_for_chain_tables(fx, monkeypatch):

@@ -69,6 +69,8 @@ SHAPES = {
     "rows_64":      ("`[a-z]+\\d+` `.in.` + spans, config-5 bytes viewed as 25 M rows of 64 B", "search", [r"[a-z]+\d+"], "cfg5", 64, 25_000_000, False, True),
     "rows_32":      ("`[a-z]+\\d+` `.in.` + spans, config-5 bytes viewed as 50 M rows of 32 B", "search", [r"[a-z]+\d+"], "cfg5", 32, 50_000_000, False, True),
     "rows_16":      ("`[a-z]+\\d+` `.in.` + spans, config-5 bytes viewed as 100 M rows of 16 B", "search", [r"[a-z]+\d+"], "cfg5", 16, 100_000_000, False, True),
+    "nibble_rows_32": ("`\\d{3}-\\d{4}` (nibble tables) `.in.` + spans, config-5 bytes viewed as 50 M rows of 32 B", "search", [r"\d{3}-\d{4}"], "cfg5", 32, 50_000_000, False, True),
+    "nibble_rows_16": ("`[a-z]{2}\\d{2,3}[a-z ]?x?` (nibble tables) `.in.` + spans, config-5 bytes viewed as 100 M rows of 16 B", "search", [r"[a-z]{2}\d{2,3}[a-z ]?x?"], "cfg5", 16, 100_000_000, False, True),
     "ragged_20":    ("`[a-z]+\\d+` `.in.` + spans, config-3 bytes viewed as rows of 20 B", "search", [r"[a-z]+\d+"], "cfg3", 20, 64_000_000, False, True),
     # short rows of a length that does not divide 64 (character(10), (12), (20), (24)): the tiny-row kernels' ragged spans
     "match_rows_12": ("`.match.` `[a-z ]+\\d*[a-z ]*` over config-3 bytes viewed as 100M rows of 12 B (fx_match_tiny, ragged spans)", "match", [r"[a-z ]+\d*[a-z ]*"], "cfg3", 12, 100_000_000, False, False),

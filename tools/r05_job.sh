@@ -57,6 +57,21 @@ except Exception as e:
 PY
         done
       done ;;
+    abl:*) IFS=: read -r _ sh libp reps <<< "$step"; reps=${reps:-2}   # bench_shapes with the default library / with another build of it (FXAMD_LIB), interleaved
+      for rep in $(seq 1 $reps); do
+        for arm in on off; do
+          if [ $arm = on ]; then python tools/bench_shapes.py --shape $sh > $OUT/abl_${sh}_${arm}_$rep.json 2> $OUT/abl_${sh}_${arm}_$rep.err
+          else env FXAMD_LIB=$libp python tools/bench_shapes.py --shape $sh > $OUT/abl_${sh}_${arm}_$rep.json 2> $OUT/abl_${sh}_${arm}_$rep.err; fi
+          python3 - $OUT/abl_${sh}_${arm}_$rep.json "$sh $arm(default / $libp) $rep" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-60s L %4d  %.4f ms  %.0f GB/s  frac %.3f  path %s  matches %s" % (sys.argv[2], d["row_len"], d["ms_per_step"], d["input_gbs"], d["frac_of_hbm_peak"], d["last_path"], d["matches"]))
+except Exception as e:
+    print(sys.argv[2], "no line:", e, open(sys.argv[1].replace(".json", ".err")).read()[-400:])
+PY
+        done
+      done ;;
     k:*) expr=${step#k:}; timeout 2400 python -m pytest tests -m gpu -x -q -k "$expr" > $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log 2>&1; echo "pytest -k '$expr' rc $?"; tail -4 $OUT/k_$(echo "$expr" | tr -c 'a-zA-Z0-9\n' '_').log ;;
     shape:*) sh=${step#shape:}; python tools/bench_shapes.py --shape $sh > $OUT/shape_$sh.json 2> $OUT/shape_$sh.err; python3 - $OUT/shape_$sh.json <<'PY'
 import json, sys
