@@ -22,6 +22,10 @@
 // tile's rows are marked FX_NEEDS_GENERAL for ONE gated follow-up -- the one-launch kernel over marked tiles (fx_search_one<.., MARKED>:
 // byte-level tables or the in-LDS decode, exception queues, the general row procedure for programs whose tables cannot decode) -- exactly
 // as the half-row pipeline of 256-byte rows does (fxamd.hip, last_path 16 -> 18).
+// (Sparse matches, measured and NOT built in: tiles with few rows that need the finish handing them to a per-wave queue ACROSS tiles, 64
+//  gathered rows finished per pass from global memory as the one-launch kernel's match compaction does -- `\d{3}-\d{4}`-like nibble programs over
+//  16-byte rows, 3 % of the rows matching: 0.563 -> 0.856 ms; BASELINE config 2: 19.7 us either way (gpurun call r05_c18).  The flush waits for
+//  rows that have left every cache and scatters its results; one in-LDS finish pass per 8 KB tile costs less.)
 // (A variant that walked such rows with the general row procedure inside this launch -- one launch for BASELINE config 2 -- was measured and
 //  removed: `foo(bar|baz)` over 1 M x 64 B, one row in ten matching, 19.6-20.0 us against the one-launch kernel's 18.1 us (gpurun call
 //  r05_c3): with sparse hits the one-launch kernel's match compaction finishes 64 gathered rows per pass ACROSS tiles, this kernel one

@@ -37,16 +37,16 @@ d=json.loads(open('$OUT/bench_dist1.json').read().strip().splitlines()[-1])
 print('gathered_shards', d['parity'].get('gathered_shards'), 'rccl_ranks', d['rccl_ranks'], 'devices', d['devices'], 'distinct', d['devices_distinct'], 'per_rank', d['per_rank_ms_per_step'], 'gather', d['gather'], 'oracle parity', d['parity'].get('oracle'))" ;;
     driver) python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; line $OUT/bench_driver.json "driver protocol" ;;
     f:*) tf=${step#f:}; timeout 2400 python -m pytest tests/$tf -m gpu -x -q > $OUT/f_$tf.log 2>&1; echo "pytest $tf rc $?"; tail -6 $OUT/f_$tf.log ;;
-    ab:*) IFS=: read -r _ cfg envv reps <<< "$step"; reps=${reps:-3}
+    ab:*) IFS=: read -r _ cfg envv reps <<< "$step"; reps=${reps:-3}; case $envv in *=*) ;; *) envv="$envv=1" ;; esac
       for rep in $(seq 1 $reps); do
         python bench.py --config $cfg --no-cpu-baseline --no-extras > $OUT/ab_${cfg}_on_$rep.json 2> $OUT/ab_${cfg}_on_$rep.err; line $OUT/ab_${cfg}_on_$rep.json "$cfg default      $rep"
-        env $envv=1 python bench.py --config $cfg --no-cpu-baseline --no-extras > $OUT/ab_${cfg}_off_$rep.json 2> $OUT/ab_${cfg}_off_$rep.err; line $OUT/ab_${cfg}_off_$rep.json "$cfg $envv=1 $rep"
+        env $envv python bench.py --config $cfg --no-cpu-baseline --no-extras > $OUT/ab_${cfg}_off_$rep.json 2> $OUT/ab_${cfg}_off_$rep.err; line $OUT/ab_${cfg}_off_$rep.json "$cfg $envv $rep"
       done ;;
-    abs:*) IFS=: read -r _ sh envv reps <<< "$step"; reps=${reps:-2}
+    abs:*) IFS=: read -r _ sh envv reps <<< "$step"; reps=${reps:-2}; case $envv in *=*) ;; *) envv="$envv=1" ;; esac
       for rep in $(seq 1 $reps); do
         for arm in on off; do
           if [ $arm = on ]; then python tools/bench_shapes.py --shape $sh > $OUT/abs_${sh}_${arm}_$rep.json 2> $OUT/abs_${sh}_${arm}_$rep.err
-          else env $envv=1 python tools/bench_shapes.py --shape $sh > $OUT/abs_${sh}_${arm}_$rep.json 2> $OUT/abs_${sh}_${arm}_$rep.err; fi
+          else env $envv python tools/bench_shapes.py --shape $sh > $OUT/abs_${sh}_${arm}_$rep.json 2> $OUT/abs_${sh}_${arm}_$rep.err; fi
           python3 - $OUT/abs_${sh}_${arm}_$rep.json "$sh $arm($envv) $rep" <<'PY'
 import json, sys
 try:
