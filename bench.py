@@ -504,7 +504,7 @@ def main():
         except Exception:
             traffic = None
     if prog.last_path() == 16:   # 256- / 128-byte rows: first pass (the timed kernel; half-row staging when spans are asked for) + one gated follow-up
-        kname = ("fx_search_fast<%d, true, 0, 0, false, true> (half-row staging)" % (row_len // 32)) if spans else "fx_search_fast<16, false, 0, 0, false, false>"
+        kname = ("fx_search_fast<%d, true, 0, 0, false, true, false> (half-row staging)" % (row_len // 32)) if spans else "fx_search_fast<16, false, 0, 0, false, false, false>"
     elif prog.last_path() == 18:   # the span kernel (rows of 128 / 64 / 32 / 16 bytes: a lane owns 128 bytes of whole rows) + one gated follow-up
         kname = "fx_search_span<%d, 0>" % row_len
     else:

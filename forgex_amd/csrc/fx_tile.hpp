@@ -538,10 +538,16 @@ __device__ __forceinline__ uint32_t chain8_back_n(const F (&f)[8], uint32_t& sta
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
 // at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
 template <bool RAGGED, bool LONG = false>
-__device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L, const uint8_t* eor = nullptr) {
+__device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L, const uint8_t* eor = nullptr,
+                                            const bool live = true) {
    if (LONG) {
       // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); any L >= 8
-      if (p + 8u <= L) {
+      // (live: a lane whose walk is over reads nothing -- round 5: 86 % of config 3's tiles of 1024-byte rows hold a match longer than the
+      //  32-symbol window, and the 60-odd dead lanes riding along fetched a line each per round: 1.16 x the algorithmic bytes)
+      if (!live) {
+         lo = 0xFEFEFEFEu;
+         hi = 0xFEFEFEFEu;
+      } else if (p + 8u <= L) {
          const uint2 r = *reinterpret_cast<const uint2*>(tb + p);   // (rows start at any byte: an unaligned 8-byte load)
          lo = r.x;
          hi = r.y;
@@ -581,11 +587,12 @@ __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const ui
    hi = word(r.y, p + 4u);
 }
 template <bool RAGGED, bool LONG = false>
-__device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L, const uint8_t* eor = nullptr) {
+__device__ __forceinline__ void fetch32(uint32_t (&o)[8], const uint8_t* tb, uint32_t lane, uint32_t j, uint32_t L, const uint8_t* eor = nullptr,
+                                        const bool live = true) {
    const uint32_t base = j & ~7u, sh = j & 7u;
    uint32_t d[10];
 #pragma unroll
-   for (int g = 0; g < 5; ++g) group_words<RAGGED, LONG>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L, eor);
+   for (int g = 0; g < 5; ++g) group_words<RAGGED, LONG>(d[2 * g], d[2 * g + 1], tb, lane, base + 8u * g, L, eor, live);
    const uint32_t up = 0u - ((sh >> 2) & 1u);   // all ones when the stream starts in the odd dword (bit-select, not indexing)
    uint32_t e[9];
 #pragma unroll
@@ -640,7 +647,7 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
    {
       const uint32_t base0 = on ? g * 8u : 0u;
 #pragma unroll
-      for (int q = 0; q < NW + 1; ++q) group_words<false, true>(d[2 * q], d[2 * q + 1], rp, lane, base0 + 8u * q, L);
+      for (int q = 0; q < NW + 1; ++q) group_words<false, true>(d[2 * q], d[2 * q + 1], rp, lane, base0 + 8u * q, L, nullptr, on);
    }
    // the hit group = the window's first group; the row may end inside it: only its text bytes are walked (the loader put the NUL / KILL
    // symbols behind them)
@@ -714,11 +721,11 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
          const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
          uint32_t gbp = j & ~7u;
          uint32_t t0[2], t1[2];
-         group_words<false, true>(t0[0], t0[1], rp, lane, gbp, L);
-         group_words<false, true>(t1[0], t1[1], rp, lane, gbp + 8u, L);
+         group_words<false, true>(t0[0], t0[1], rp, lane, gbp, L, nullptr, cur != 0);
+         group_words<false, true>(t1[0], t1[1], rp, lane, gbp + 8u, L, nullptr, cur != 0);
          do {
             uint32_t t2[2];
-            group_words<false, true>(t2[0], t2[1], rp, lane, gbp + 16u, L);
+            group_words<false, true>(t2[0], t2[1], rp, lane, gbp + 16u, L, nullptr, cur != 0);
             const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
             const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
             FA f8[8];
@@ -995,7 +1002,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       uint32_t o[8];
       const uint8_t* const eor = FG ? nullptr : eor8;
       if (capd != nullptr) {
-         if (__builtin_amdgcn_ballot_w64(cur != 0 && !use_cap) != 0) fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor);
+         if (__builtin_amdgcn_ballot_w64(cur != 0 && !use_cap) != 0) fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor, cur != 0 && !use_cap);
          else
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = 0u;
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
 #pragma unroll
          for (int k = 0; k < 8; ++k) o[k] = use_cap ? __builtin_amdgcn_alignbyte(e[k + 1], e[k], sh & 3u) : o[k];
       } else
-         fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor);
+         fetch32<RAGGED, FG>(o, src, lane, j, Lx, eor, cur != 0);
 #ifndef FX_FWD_GB_LDS
 #define FX_FWD_GB_LDS 4
 #endif
@@ -1054,11 +1061,11 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          const uint32_t sh = j & 7u, up = 0u - ((sh >> 2) & 1u);
          uint32_t gb = j & ~7u;
          uint32_t t0[2], t1[2];
-         group_words<RAGGED, FG>(t0[0], t0[1], src, lane, gb, Lx, eor);
-         group_words<RAGGED, FG>(t1[0], t1[1], src, lane, gb + 8u, Lx, eor);
+         group_words<RAGGED, FG>(t0[0], t0[1], src, lane, gb, Lx, eor, cur != 0);
+         group_words<RAGGED, FG>(t1[0], t1[1], src, lane, gb + 8u, Lx, eor, cur != 0);
          do {
             uint32_t t2[2];
-            group_words<RAGGED, FG>(t2[0], t2[1], src, lane, gb + 16u, Lx, eor);
+            group_words<RAGGED, FG>(t2[0], t2[1], src, lane, gb + 16u, Lx, eor, cur != 0);
             const uint32_t e0 = (up & t0[1]) | (~up & t0[0]), e1 = (up & t1[0]) | (~up & t0[1]), e2 = (up & t1[1]) | (~up & t1[0]);
             const uint32_t o0 = __builtin_amdgcn_alignbyte(e1, e0, sh & 3u), o1 = __builtin_amdgcn_alignbyte(e2, e1, sh & 3u);
             F f8[8];
@@ -1364,7 +1371,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
             if (g * 8u + 8u > L) nv = L - g * 8u;   // the row ends inside the group: only its text bytes were walked
          } else if (LONG && !HALFROW) {   // (its segment left the tile: from global memory)
             rw = make_uint2(0, 0);
-            if (row_ok) {
+            if (row_ok && gsel != 0xFFFFFFFFu) {   // (lanes without a hit read nothing)
                const uint8_t* rp = rows + row * (int64_t)L;
                if (g * 8u + 8u <= L) rw = *reinterpret_cast<const uint2*>(rp + g * 8u);
                else {   // the row's last 8 bytes, shifted down to the group's place (nothing behind the row is read)

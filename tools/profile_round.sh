@@ -18,3 +18,5 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CY
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $OUT/pmc_inst -- python3 $REPO/bench.py $P > $OUT/pmc_inst.log 2>&1
 cd $REPO && python3 tools/summarize_prof.py $OUT $TAG $CFG > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# gpurun copies at most 64 MiB back: the summary holds what the raw counter CSVs said, so only the kernel-stats CSV is kept
+[ "${KEEP_RAW:-0}" = 1 ] || { rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_inst; find $OUT/kt -name '*kernel_trace.csv' -delete; }

@@ -20,4 +20,6 @@ for sh in $SHAPES; do
   fi
   (cd $REPO && python3 tools/summarize_shapes.py $OUT $TAG $sh) > $OUT/summary.txt 2>&1
   cat $OUT/summary.txt
+  # gpurun copies at most 64 MiB back: the summary holds what the raw counter CSVs said, so only the kernel-stats CSV is kept
+  [ "${KEEP_RAW:-0}" = 1 ] || { rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_inst; find $OUT/kt -name '*kernel_trace.csv' -delete; }
 done
