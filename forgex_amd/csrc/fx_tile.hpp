@@ -537,6 +537,9 @@ __device__ __forceinline__ uint32_t chain8_back_n(const F (&f)[8], uint32_t& sta
 // non-continuation byte within 3 to its left is a lead whose whole sequence is continuation bytes).
 // Symbol stream of one row for the forward pass, starting at ANY byte index j: text bytes, then 0x00 for the trailing NUL
 // at index L, then 0xFE (the symbol id whose table row is all-dead) -- so end-of-row needs no per-byte test.
+#ifndef FX_LIVE_PRED
+#define FX_LIVE_PRED 1   // (0: the round-4 behaviour, for A/B builds)
+#endif
 template <bool RAGGED, bool LONG = false>
 __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const uint8_t* tb, uint32_t lane, uint32_t p, uint32_t L, const uint8_t* eor = nullptr,
                                             const bool live = true) {
@@ -544,7 +547,7 @@ __device__ __forceinline__ void group_words(uint32_t& lo, uint32_t& hi, const ui
       // long rows: `tb` is the row itself in global memory (the LDS tile only ever holds one 256-byte segment); any L >= 8
       // (live: a lane whose walk is over reads nothing -- round 5: 86 % of config 3's tiles of 1024-byte rows hold a match longer than the
       //  32-symbol window, and the 60-odd dead lanes riding along fetched a line each per round: 1.16 x the algorithmic bytes)
-      if (!live) {
+      if (FX_LIVE_PRED != 0 && !live) {
          lo = 0xFEFEFEFEu;
          hi = 0xFEFEFEFEu;
       } else if (p + 8u <= L) {
@@ -1371,7 +1374,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
             if (g * 8u + 8u > L) nv = L - g * 8u;   // the row ends inside the group: only its text bytes were walked
          } else if (LONG && !HALFROW) {   // (its segment left the tile: from global memory)
             rw = make_uint2(0, 0);
-            if (row_ok && gsel != 0xFFFFFFFFu) {   // (lanes without a hit read nothing)
+            if (row_ok && (FX_LIVE_PRED == 0 || gsel != 0xFFFFFFFFu)) {   // (lanes without a hit read nothing)
                const uint8_t* rp = rows + row * (int64_t)L;
                if (g * 8u + 8u <= L) rw = *reinterpret_cast<const uint2*>(rp + g * 8u);
                else {   // the row's last 8 bytes, shifted down to the group's place (nothing behind the row is read)

@@ -565,7 +565,7 @@ struct PassOpts {
 // (128-byte rows with 64-byte halves were tried in round 3 and are NOT dispatched: a 64-byte piece is half of a 128-byte line, every line
 //  is fetched twice -- config 5's shard 0.73-0.76 ms against 0.377 ms on the one-launch kernel, gpurun call r03_c14; round 4, with the
 //  default cache policy on the loads so that the second half meets its line in L2: 0.45 ms against 0.366 ms, gpurun call r04_c26)
-static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
+static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len) {
    // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel; FXAMD_HALF_SCH: bit s = table scheme s takes half rows)
    if (fx_env().no_half) return false;
    // 128-byte rows on the chain tables: 64-byte halves (bit 4 of the hook).  The chain scheme's dependent LDS read per byte is latency-bound:
@@ -586,7 +586,7 @@ static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len, bool span
 static bool half_staging(int scheme, bool spans) { return spans || scheme != 0; }
 // `.match.` over 256-byte rows on the chain tables: the multi-pass pipeline with a half-row first pass too (fx_match_fast<8,...,LONG>)
 // (128-byte rows: `.match.` of a 23-state pattern over config 5's shard 0.4518 -> 0.4443 ms on 64-byte halves -- within a box's drift: not dispatched)
-static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && row_len == 256 && half_rows(h, scheme, row_len, false); }
+static bool match_half_rows(const FxpHeader& h, int scheme, int64_t row_len) { return scheme == 1 && row_len == 256 && half_rows(h, scheme, row_len); }
 
 template <int MODE, int SCH>
 static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
@@ -841,10 +841,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // the span kernel, each with its follow-up (the first pass leaves a byte per deferred tile where the unpacked form marks the rows' flags)
       const int sc0 = (h.flags & FXP_F_NFA_SIM) ? -1 : fast_scheme(h, d_rows, row_len);
       const bool spans_p = d_from != nullptr && d_to != nullptr;
-      const bool half0 = sc0 == 0 && h.mode == FXP_MODE_SEARCH_ENGINE && spans_p && row_len == 256 && half_rows(h, sc0, row_len, true) && scheme_decodes_utf8(h, sc0) &&
+      const bool half0 = sc0 == 0 && h.mode == FXP_MODE_SEARCH_ENGINE && spans_p && row_len == 256 && half_rows(h, sc0, row_len) && scheme_decodes_utf8(h, sc0) &&
                          first_pass == FX_FP_OWN && !fx_env().no_pack_first;
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(h, sc0, row_len) : (!half_rows(h, sc0, row_len, d_from != nullptr) || half0)) &&
+                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(h, sc0, row_len) : (!half_rows(h, sc0, row_len) || half0)) &&
                        !fx_env().multipass;
       if (!one) return FX_NOT_PACKED;
       // (FXAMD_NO_PACK_FIRST=1, test / A-B hook: 256-byte rows unpacked + fx_pack, the span kernel's rows packed by the one-launch kernel -- as before round 5)
@@ -900,7 +900,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // the multi-pass pipelines alternate on the host).
       // (Rows of 129..255 bytes on the chain tables walked like long rows, in 128-byte segments, were tried too: the 17-state pattern over
       //  200-byte rows 1.283 -> 1.349 ms -- a 128-byte and a 72-byte segment pay two segments' fixed work; gpurun call r04_c34.)
-      bool half = is_match ? match_half_rows(h, scheme, row_len) : half_rows(h, scheme, row_len, d_from != nullptr);
+      bool half = is_match ? match_half_rows(h, scheme, row_len) : half_rows(h, scheme, row_len);
       if (half && (scheme != 0 || is_match)) {
          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
          if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
@@ -1156,7 +1156,8 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
 static size_t held_scratch(const fxamd_program* p) {
    size_t held = 0;
    for (const DevScratch& s : p->scratch)
-      held += (size_t)s.worklist_rows * 4 + (size_t)s.unpacked_rows * 9 + s.nfa_scratch_rows * (size_t)2 * p->prog.hdr().nfa_words * 4;
+      held += (s.worklist_rows * 4 > (int64_t(1) << 20) ? (size_t)s.worklist_rows * 4 : 0) +   // (a worklist of up to 1 MB is kept: see trim_scratch)
+              (size_t)s.unpacked_rows * 9 + s.nfa_scratch_rows * (size_t)2 * p->prog.hdr().nfa_words * 4;
    return held;
 }
 static void trim_scratch(fxamd_program* p, size_t budget) {
@@ -1447,7 +1448,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
    PassOpts po;
    po.defer_tiles = ((scheme_decodes_utf8(h, scheme) && !long_row(row_len)) || bytes) ? 1u : 0u;
-   po.half = half_rows(h, scheme, row_len, d_from != nullptr) && half_staging(scheme, d_from != nullptr);
+   po.half = half_rows(h, scheme, row_len) && half_staging(scheme, d_from != nullptr);
    if (!po.half && n > 0 && span_kind(h, scheme, row_len, d_from != nullptr)) {   // the span kernel's first pass
       FastParams fps = params_of(h, 0, false);
       fps.defer_tiles = 1u;
