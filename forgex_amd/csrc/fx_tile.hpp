@@ -1253,11 +1253,15 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          auto walk = [&](auto whole_groups) {
             constexpr bool WG = decltype(whole_groups)::value;
             F fa[8], fb[8];
-            uint4 wk = tile[tile_cell(lane, CH - 1)], wn = make_uint4(0, 0, 0, 0);
-            if (CH >= 2 && !HALF4) wn = tile[tile_cell(lane, CH - 2)];
+            // (a row's short last segment: the walk starts at the chunk the row ends in -- chunks behind it are not even looked up; round 5:
+            //  400-byte rows walked their 144-byte segment's seven empty chunks through the table reads)
+            const uint32_t kc = WG ? (uint32_t)CH : ((seg_len + 15u) >> 4);   // chunks that hold text: 1 .. CH, wave-uniform
+            uint4 wk = tile[tile_cell(lane, kc - 1u)], wn = make_uint4(0, 0, 0, 0);
+            if (CH >= 2 && !HALF4 && kc >= 2u) wn = tile[tile_cell(lane, kc - 2u)];
             lookup8(fa, wk.z, wk.w, tabR);
 #pragma unroll
             for (int k = CH - 1; k >= 0; --k) {
+               if (!WG && (uint32_t)k >= kc) continue;
                // valid bytes of this chunk's upper / lower group (8 unless LONG and the row ends here)
                const uint32_t nhi = WG ? 8u : (seg_len >= 16u * k + 16u ? 8u : (seg_len > 16u * k + 8u ? seg_len - (16u * k + 8u) : 0u));
                const uint32_t nlo = WG ? 8u : (seg_len >= 16u * k + 8u ? 8u : (seg_len > 16u * k ? seg_len - 16u * k : 0u));

@@ -92,12 +92,15 @@ def main():
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=0, help="another row count than the shape's (small-batch experiments)")
     args = ap.parse_args()
     if args.list:
         for k, v in SHAPES.items():
             print("%-14s %s" % (k, v[0]))
         return
     desc, op, pats, cfg, view, n, packed, spans = SHAPES[args.shape]
+    if args.rows > 0:
+        n = args.rows
     import torch
     import forgex_amd
     from forgex_amd import synth
