@@ -40,7 +40,8 @@
 #define FX_SPAN_RAG_WAVES 3   // waves per SIMD the ragged instantiations are compiled for (their wave-uniform guards cost ~50 SGPRs: at four waves they spill)
 #endif
 #ifndef FX_SPAN_MIN_ROUNDS
-#define FX_SPAN_MIN_ROUNDS 1   // launch grid: at least this many rounds of the 1024 resident blocks
+#define FX_SPAN_MIN_ROUNDS 3   // launch grid: at least this many rounds of the 1024 resident blocks (the half-row kernel's rule; 3 M x 64 B: 56.2 -> 53.5 us,
+                               // 3 M x 128 B packed: 94.8 -> 89.9 us, 1 M x 64 B: 23.1 -> 22.5 us against one round, gpurun call r05_c23)
 #endif
 
 // RL = bytes of LDS a row gets: 16 * (its chunk count rounded up to a power of two).  Rows of exactly RL bytes are the aligned
