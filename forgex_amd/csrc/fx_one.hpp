@@ -846,6 +846,9 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 // MARKED: the follow-up of a multi-pass first pass (the half-row kernel of 256-byte rows): only tiles whose rows that pass marked
 // FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
 // and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
+#ifndef FX_ONE_ROWS_FIRST
+#define FX_ONE_ROWS_FIRST 1
+#endif
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
 __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : 1))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
@@ -897,6 +900,15 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    // table entries written to LDS -- the block's two start-up latencies (tables from L2, rows from HBM) overlap instead of adding up, and
    // the wait for the table entries (the older loads: vmcnt counts in order) does not wait for the rows.  (The marked-tile follow-up reads the
    // flags before it loads a tile.)
+   // Round 5 (FX_ONE_ROWS_FIRST): the first tile's loads go out BEFORE the table reads -- they need no header field, the table reads wait for the
+   // header's offsets (a scalar round trip to L2), and the rows come from HBM: max(rows, header + tables) instead of header + max(tables, rows).
+   uint4 stage[CH];
+   const FxTail tl = fx_tail_of(RAGGED ? Lr : 16u * CH);
+   if constexpr (!MARKED && FX_ONE_ROWS_FIRST != 0) {
+      if constexpr (RAGGED) load_tile_rag<CH>(stage, rows, wave_global << 6, n, lane, tl);
+      else load_tile<CH>(stage, rows, wave_global << 6, n, lane, true);
+      __builtin_amdgcn_sched_barrier(0);
+   }
    uint2 t_r = make_uint2(0, 0), t_a = make_uint2(0, 0), t_br = make_uint2(0, 0), t_ba = make_uint2(0, 0);
    if (SCH == 2) {
       t_r = reinterpret_cast<const uint2*>(prog + h->off_w16R)[threadIdx.x];
@@ -909,10 +921,16 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       t_br = reinterpret_cast<const uint2*>(prog + h->off_bw16R)[threadIdx.x];
       t_ba = reinterpret_cast<const uint2*>(prog + (BSCH == 2 ? h->off_bw16A : h->off_b8A))[threadIdx.x];
    }
-   __builtin_amdgcn_sched_barrier(0);   // (the table reads stay ahead of the tile's loads: their addresses wait for the header's offsets)
-   uint4 stage[CH];
-   const FxTail tl = fx_tail_of(RAGGED ? Lr : 16u * CH);
-   if constexpr (!MARKED) {
+   // the BMP class map of the in-LDS decode (2 KB page index + 128 B per page): 16-byte pieces, the first 256 of them read HERE with the
+   // tables (round 5: a 2-byte copy loop behind the tables' LDS stores was five dependent round trips to L2 at the start of every block --
+   // config 4 is a 57 us kernel)
+   const uint32_t cm_n4 = class_map_in_lds ? 128u + h->n_pages * 8u : 0u;
+   uint4 t_cm = make_uint4(0, 0, 0, 0);
+   if (threadIdx.x < cm_n4)
+      t_cm = threadIdx.x < 128u ? reinterpret_cast<const uint4*>(prog + h->off_cls_page)[threadIdx.x]
+                                : reinterpret_cast<const uint4*>(prog + h->off_cls_pages)[threadIdx.x - 128u];
+   __builtin_amdgcn_sched_barrier(0);
+   if constexpr (!MARKED && FX_ONE_ROWS_FIRST == 0) {
       if constexpr (RAGGED) load_tile_rag<CH>(stage, rows, wave_global << 6, n, lane, tl);
       else load_tile<CH>(stage, rows, wave_global << 6, n, lane, true);
    }
@@ -953,8 +971,9 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    const uint16_t* pages_p = reinterpret_cast<const uint16_t*>(prog + h->off_cls_pages);
    if (class_map_in_lds) {
       uint16_t* l16 = reinterpret_cast<uint16_t*>(dyn + c_bytes + b_bytes);
-      const uint32_t n16 = 1024u + h->n_pages * 64u;
-      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      uint4* l4 = reinterpret_cast<uint4*>(l16);   // (blob offsets and the LDS offset are multiples of 16: compile.cpp Blob::put, c_bytes / b_bytes)
+      if (threadIdx.x < cm_n4) l4[threadIdx.x] = t_cm;
+      for (uint32_t i = threadIdx.x + 256u; i < cm_n4; i += 256u) l4[i] = reinterpret_cast<const uint4*>(pages_p)[i - 128u];   // (more than 16 pages)
       page_p = l16;
       pages_p = l16 + 1024;
    }

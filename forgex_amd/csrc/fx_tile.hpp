@@ -953,7 +953,11 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    if (FIXUP && class_map_in_lds) {
       uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * COLS) + chain_bytes);
       const uint32_t n16 = 1024u + h->n_pages * 64u;
-      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      {   // 16-byte pieces (blob offsets and the LDS offset are multiples of 16): one round trip instead of one per 256 entries
+         uint4* l4 = reinterpret_cast<uint4*>(l16);
+         for (uint32_t i = threadIdx.x; i < n16 / 8u; i += 256u)
+            l4[i] = i < 128u ? reinterpret_cast<const uint4*>(page_p)[i] : reinterpret_cast<const uint4*>(pages_p)[i - 128u];
+      }
       __syncthreads();
       page_p = l16;
       pages_p = l16 + 1024;
@@ -1734,7 +1738,11 @@ __global__ __launch_bounds__(256, (LONG && CH <= 8) ? 4 : 1) void fx_match_fast(
    if (FIXUP && class_map_in_lds) {
       uint16_t* l16 = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(tiles + 4 * 64 * CH) + chain_bytes);
       const uint32_t n16 = 1024u + h->n_pages * 64u;
-      for (uint32_t i = threadIdx.x; i < n16; i += 256u) l16[i] = i < 1024u ? page_p[i] : pages_p[i - 1024u];
+      {   // 16-byte pieces (blob offsets and the LDS offset are multiples of 16): one round trip instead of one per 256 entries
+         uint4* l4 = reinterpret_cast<uint4*>(l16);
+         for (uint32_t i = threadIdx.x; i < n16 / 8u; i += 256u)
+            l4[i] = i < 128u ? reinterpret_cast<const uint4*>(page_p)[i] : reinterpret_cast<const uint4*>(pages_p)[i - 128u];
+      }
       __syncthreads();
       page_p = l16;
       pages_p = l16 + 1024;
