@@ -105,10 +105,16 @@ struct FxScanCtx {
 #define FX_DEFER_DENSE 12   // tiles with more hit rows than this finish them in place (config 3 / 5: half of the rows match -- queueing those costs
                             // scattered from / to stores and a second read of the rows' bytes: measured slower, profiles/r03_defer_ab.txt)
 #endif
+#ifndef FX_DEFER_STASH
+#define FX_DEFER_STASH 0   // (1: match compaction copies a queued row's 24 bytes from its hit group on into the queue while the row is in LDS, so that the
+                           //  flush reads no global memory -- measured and NOT kept: config 2 18.2-18.6 -> 18.6-18.9 us per step, gpurun call r05_c27: three
+                           //  more LDS reads + predicated stores per tile cost more than the flush's round trip at the end of a wave)
+#endif
 struct FxFwdQueue {
    uint32_t* q;        // LDS: 64 row numbers, then 64 x (hit group | entry state << 16)
    uint32_t n;         // entries (wave-uniform)
    uint32_t family;    // table family of the queued entries: 0 class-level, 1 byte-level (wave-uniform)
+   uint2* w;           // LDS (FX_DEFER_STASH): 3 x 64 8-byte groups -- group k of slot s at w[64 k + s]: the flush's re-walk + first window read no global memory
 };
 struct FxNoFlush {
    __device__ __forceinline__ void operator()() const {}
@@ -259,10 +265,22 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          if (cnt != 0u && cnt <= (uint32_t)FX_DEFER_DENSE) {
             if (fq->n + cnt > 64u || (fq->n != 0u && fq->family != (BYTES ? 1u : 0u))) flush();
             queued = want;
+            const uint32_t slot = fq->n + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull));
             if (queued) {
-               const uint32_t slot = fq->n + (uint32_t)__builtin_popcountll(qm & ((1ull << lane) - 1ull));
                fq->q[slot] = (uint32_t)row;
                fq->q[64u + slot] = gsel | ((S_ == 0 ? (esel & 0xFFu) : esel) << 16);
+            }
+            if constexpr (FX_DEFER_STASH != 0) {
+               // Round 5: the three 8-byte groups from the hit group on (the exact start's re-walk + the flush's 16-symbol window; text, then the
+               // trailing NUL, then KILL symbols) go into the queue NOW, out of the tile -- the flush used to read them from global memory
+               // again: 1.13 x config 2's algorithmic HBM traffic, and a round trip to L2 / HBM at the end of every wave with nothing to overlap it
+               const uint32_t p0 = queued ? gsel * 8u : 0u;
+#pragma unroll
+               for (int q = 0; q < 3; ++q) {
+                  uint32_t lo, hi;
+                  group_words<false, false>(lo, hi, tb, lane, p0 + 8u * (uint32_t)q, L);
+                  if (queued) fq->w[64u * (uint32_t)q + slot] = make_uint2(lo, hi);
+               }
             }
             fq->n += cnt;
             fq->family = BYTES ? 1u : 0u;
@@ -847,7 +865,7 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 // FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
 // and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
 #ifndef FX_ONE_ROWS_FIRST
-#define FX_ONE_ROWS_FIRST 1
+#define FX_ONE_ROWS_FIRST 0   // (1: the first tile's loads before the table reads -- measured SLOWER, see the start-up comment in the kernel)
 #endif
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
 __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : 1))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
@@ -891,6 +909,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    // (config 5: +2 %, config 4: +1 %, profiles/r03_defer_ab.txt)
    constexpr bool DEFERQ = FX_DEFER_FWD != 0 && SPANS && !MARKED && !MATCH && CH <= 4 && !RAGGED;
    __shared__ uint32_t fwd_q[DEFERQ ? 4 * 128 : 1];   // per-wave queues of rows whose exact start + forward pass are finished 64 at a time
+   __shared__ uint2 fwd_w[(DEFERQ && FX_DEFER_STASH != 0) ? 4 * 192 : 1];   // ... and their first three 8-byte groups (FX_DEFER_STASH)
    extern __shared__ __attribute__((aligned(16))) uint4 tiles[];   // 4 waves x 64*(CH+1) cells [+ class chain tables] [+ byte chain tables] [+ class map]
    const FxpHeader* h = reinterpret_cast<const FxpHeader*>(prog);
    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -900,8 +919,9 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    // table entries written to LDS -- the block's two start-up latencies (tables from L2, rows from HBM) overlap instead of adding up, and
    // the wait for the table entries (the older loads: vmcnt counts in order) does not wait for the rows.  (The marked-tile follow-up reads the
    // flags before it loads a tile.)
-   // Round 5 (FX_ONE_ROWS_FIRST): the first tile's loads go out BEFORE the table reads -- they need no header field, the table reads wait for the
-   // header's offsets (a scalar round trip to L2), and the rows come from HBM: max(rows, header + tables) instead of header + max(tables, rows).
+   // (Round 5, FX_ONE_ROWS_FIRST = 1, measured and NOT kept: the first tile's loads BEFORE the table reads -- they need no header field -- so that
+   //  the start-up is max(rows, header + tables) instead of header + max(tables, rows): config 2 18.2 -> 18.8-19.4 us per step, config 4 55.1 ->
+   //  56.0 us (gpurun call r05_c26) -- the table entries then return behind 4 KB of rows per wave, and the LDS stores + barrier wait for all of it.)
    uint4 stage[CH];
    const FxTail tl = fx_tail_of(RAGGED ? Lr : 16u * CH);
    if constexpr (!MARKED && FX_ONE_ROWS_FIRST != 0) {
@@ -1050,7 +1070,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       }
    };
    // ---- match compaction: this wave's queue and its flush (every lane finishes one queued row from global memory) ----------------
-   FxFwdQueue fwdq{fwd_q + (DEFERQ ? wave * 128u : 0u), 0u, 0u};
+   FxFwdQueue fwdq{fwd_q + (DEFERQ ? wave * 128u : 0u), 0u, 0u, fwd_w + ((DEFERQ && FX_DEFER_STASH != 0) ? wave * 192u : 0u)};
    auto flush_fwd = [&]() {
       if constexpr (DEFERQ) {
          if (fwdq.n == 0u) return;
@@ -1064,7 +1084,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
             constexpr int S_ = decltype(cfg)::sch;
             with_tables(cfg, [&](auto tabR, auto tabA, const uint8_t* TRp, const uint8_t* TAp, const FastParams& P) {
                const uint32_t e = S_ == 0 ? (ge >> 16) * 0x01010101u : (ge >> 16);
-               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2, decltype(cfg)::sch_a>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm);
+               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2, decltype(cfg)::sch_a, (FX_DEFER_STASH != 0)>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm, fwdq.w);
                return 0;
             });
          };
@@ -1415,7 +1435,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    int64_t blocks = (n_tiles + 3) / 4;
    const size_t tiles_b = (size_t)4 * 64 * (CH + 1) * 16;
    // the BMP class map rides behind the tables when two blocks per CU still fit (else the decode reads it from global memory)
-   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64 + ((FX_DEFER_FWD != 0 && CH <= 4) ? 2048 : 0) +
+   const size_t static_b = (SCH == 0 ? 4096 : (SCH == 2 ? 4096 : 0)) + ((BSCH == 2 || BSCH == 3) ? 4096 : 0) + 1024 + 64 + ((FX_DEFER_FWD != 0 && CH <= 4) ? 2048 + (FX_DEFER_STASH != 0 ? 6144 : 0) : 0) +
                            ((FX_SPEC_FWD != 0 && BSCH == 3) ? 1024 : 0);
    const uint32_t map_lds = (!GEN && tiles_b + table_bytes + class_map_bytes + static_b <= 80 * 1024 && class_map_bytes <= 24u * 1024u) ? class_map_bytes : 0u;
    const size_t lds = tiles_b + table_bytes + map_lds;

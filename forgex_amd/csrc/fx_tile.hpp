@@ -636,10 +636,12 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
 // group for the exact start, then walks forward from it (first window of 8*NW symbols, lookups issued 8*GB at a time, then 8 symbols per
 // round while any lane is alive).  Returns the wrapped start index s (>= 2) and max_match mm (0 = none; lit_len != 0: s + lit_len, no
 // walk).  The same arithmetic as the in-tile path (fx_scan_tile / fx_search_fast), with the row read through group_words<.., LONG>.
-template <int S_, int NW, int GB, int S_A = S_, class TabT, class TabTA>
+// (PRE: the window's NW + 1 groups were copied into LDS when the row was queued -- `pre`[64 k + lane] = group k of this lane's row; only a
+//  match longer than the window still reads the row)
+template <int S_, int NW, int GB, int S_A = S_, bool PRE = false, class TabT, class TabTA>
 __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ tabR, const TabTA* __restrict__ tabA, const uint8_t* TRp, const uint8_t* TAp,
                                                       const FastParams& P, const uint8_t* rp, const uint32_t L, const uint32_t lane, const bool on,
-                                                      const uint32_t g, const uint32_t e, uint32_t& s_out, uint32_t& mm_out) {
+                                                      const uint32_t g, const uint32_t e, uint32_t& s_out, uint32_t& mm_out, const uint2* pre = nullptr) {
    using F = typename FxF<S_>::type;
    using FA = typename FxF<S_A>::type;
    static_assert(NW % GB == 0, "window groups: a multiple of the lookup batch");
@@ -647,7 +649,15 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
    // aligned base is 8 g whatever `loc` turns out to be), which the compiler cannot know: the loads used to wait for the re-walk's result --
    // a second round trip to L2 / HBM at the end of a wave that has nothing to overlap it with (config 2: the flush is the kernel's tail).
    uint32_t d[2 * NW + 2];
-   {
+   if constexpr (PRE) {
+      static_assert(NW == 2, "the queue holds three groups per row");
+#pragma unroll
+      for (int q = 0; q < NW + 1; ++q) {
+         const uint2 r = pre[64 * q + (int)lane];   // (slots behind the queue's end hold an earlier flush's groups: their lanes are off)
+         d[2 * q] = r.x;
+         d[2 * q + 1] = r.y;
+      }
+   } else {
       const uint32_t base0 = on ? g * 8u : 0u;
 #pragma unroll
       for (int q = 0; q < NW + 1; ++q) group_words<false, true>(d[2 * q], d[2 * q + 1], rp, lane, base0 + 8u * q, L, nullptr, on);
