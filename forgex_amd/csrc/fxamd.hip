@@ -1099,6 +1099,9 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       else if (ob == 1) FX_HIP((launch_one_marked<CH, 1, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, 16u * CH)));     \
       else FX_HIP((launch_one_marked<CH, 0, false>(d_rows, n, d_blob, fpc, fpb, d_flags, d_from, d_to, cmb, tb, st, ctr, out_mode, marks, 16u * CH)));                  \
    }
+         // (what the gated launch costs a step on a pure-ASCII batch, measured with the launch compiled out: config 3 0.4519 / 0.4618 / 0.4626 ms with it,
+         //  0.4546 / 0.4608 / 0.4620 ms without -- nothing; at 1.25 M rows, an eighth of the batch: 66.4 against 63.5-64.7 us; gpurun call r05_c28.  Under
+         //  rocprofv3 the same launch shows as 4.7 us + a 10 us longer first pass: the profiler serialises the dispatches.)
          FX_MARKED(16)
 #undef FX_MARKED
          p->last_path = 16;

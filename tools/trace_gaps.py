@@ -17,7 +17,7 @@ for s, e, n in fx:
 dom = max(tot, key=tot.get)
 print("dominant:", dom[:100])
 idx = [i for i, (s, e, n) in enumerate(rows) if n == dom]
-periods, durs, others, idles = [], [], [], []
+groups = {}   # names between two launches of the dominant kernel -> list of (period, dominant duration, other fx busy time, idle)
 for a, b in zip(idx, idx[1:]):
     s0, e0, _ = rows[a]
     s1, _, _ = rows[b]
@@ -25,15 +25,10 @@ for a, b in zip(idx, idx[1:]):
     if any("fx_" not in n for _, _, n in between):   # (something else of the process ran in between: not a back-to-back step)
         continue
     busy = sum(e - s for s, e, _ in between)
-    periods.append(s1 - s0)
-    durs.append(e0 - s0)
-    others.append(busy)
-    idles.append((s1 - s0) - (e0 - s0) - busy)
-    last_between = [n[:60] for _, _, n in between]
-def med(x):
-    return statistics.median(x) / 1e3 if x else float("nan")
-n = len(periods)
-half = periods[n // 2:], durs[n // 2:], others[n // 2:], idles[n // 2:]   # the later half: settled clocks
-print("back-to-back pairs: %d; later half (us, medians): period %.2f = dominant kernel %.2f + other fx kernels %.2f + idle %.2f" % (
-    n, med(half[0]), med(half[1]), med(half[2]), med(half[3])))
-print("between two launches:", last_between if n else None)
+    key = tuple(n.split("(")[0][:70] for _, _, n in between)
+    groups.setdefault(key, []).append((s1 - s0, e0 - s0, busy, (s1 - s0) - (e0 - s0) - busy))
+for key, v in groups.items():
+    v = v[len(v) // 2:]   # the later half: settled clocks
+    med = lambda i: statistics.median(x[i] for x in v) / 1e3
+    print("%d pairs with %s between (later half, us, medians): period %.2f = dominant kernel %.2f + other fx kernels %.2f + idle %.2f" % (
+        len(v), list(key) if key else "nothing", med(0), med(1), med(2), med(3)))
