@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TR);
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_chain_TA);
       const uint32_t nr = c_tr / 2, na = c_ta / 2;
-      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+      fx_stage_chain(cmap, g, gr, ga, nr, na);
    } else if (SCH == 2) {
       reinterpret_cast<uint2*>(wideR)[threadIdx.x] = t_r;
       reinterpret_cast<uint2*>(wideA)[threadIdx.x] = t_a;
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + h->off_byte_TR);
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + h->off_byte_TA);
       const uint32_t nr = b_tr / 2, na = b_ta / 2;
-      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) bmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+      fx_stage_chain(bmap, g, gr, ga, nr, na);
    } else if (BSCH == 2 || BSCH == 3) {
       reinterpret_cast<uint2*>(bwideR)[threadIdx.x] = t_br;
       if (BSCH == 2) reinterpret_cast<uint2*>(bwideA)[threadIdx.x] = t_ba;

@@ -631,6 +631,28 @@ __device__ __forceinline__ void fetch8(uint32_t (&o)[2], const uint8_t* tb, uint
    o[1] = __builtin_amdgcn_alignbyte(e[2], e[1], sh & 3u);
 }
 
+// Chain tables -> LDS: the 256-entry symbol map, then T_R (nr entries), then T_A (na entries), all 16-bit.  Four entries per thread are READ before
+// any is stored (round 5: a load -> store loop made every 256 entries a round trip to L2 of their own at the start of every block; measured on
+// the 17-state pattern over 256- and 128-byte rows: 0.717 -> 0.715 ms, 0.492 -> 0.495 ms -- nothing either way, gpurun call r05_c29: the
+// other blocks of a CU cover a block's start-up).
+__device__ __forceinline__ void fx_stage_chain(uint16_t* __restrict__ dst, const uint16_t* __restrict__ g, const uint16_t* __restrict__ gr,
+                                               const uint16_t* __restrict__ ga, const uint32_t nr, const uint32_t na) {
+   const uint32_t total = 256u + nr + na;
+   for (uint32_t base = threadIdx.x; base < total; base += 1024u) {
+      uint16_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         const uint32_t i = base + 256u * (uint32_t)u;
+         v[u] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : (i < total ? ga[i - 256u - nr] : (uint16_t)0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         const uint32_t i = base + 256u * (uint32_t)u;
+         if (i < total) dst[i] = v[u];
+      }
+   }
+}
+
 // ---- match compaction: one queued row per lane finished from GLOBAL memory ----------------------------------------------------------
 // Lane `on`: row bytes at rp (length L >= 8, any alignment), leftmost hit in 8-byte group g entered in reverse state e.  Re-walks the
 // group for the exact start, then walks forward from it (first window of 8*NW symbols, lookups issued 8*GB at a time, then 8 symbols per
@@ -942,7 +964,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
       const uint16_t* gr = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TR : h->off_chain_TR));
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
       const uint32_t nr = tr_bytes / 2, na = ta_bytes / 2;
-      for (uint32_t i = threadIdx.x; i < 256u + nr + na; i += 256u) cmap[i] = i < 256u ? g[i] : (i < 256u + nr ? gr[i - 256u] : ga[i - 256u - nr]);
+      fx_stage_chain(cmap, g, gr, ga, nr, na);
    } else if (WIDE) {
       reinterpret_cast<uint2*>(wideR)[threadIdx.x] = t_r;
       reinterpret_cast<uint2*>(wideA)[threadIdx.x] = t_a;
@@ -1732,7 +1754,7 @@ __global__ __launch_bounds__(256, (LONG && CH <= 8) ? 4 : 1) void fx_match_fast(
       const uint16_t* g = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_cls : h->off_chain_cls));
       const uint16_t* ga = reinterpret_cast<const uint16_t*>(prog + (BYTES ? h->off_byte_TA : h->off_chain_TA));
       const uint32_t na = ta_bytes / 2;
-      for (uint32_t i = threadIdx.x; i < 256u + na; i += 256u) cmap[i] = i < 256u ? g[i] : ga[i - 256u];
+      fx_stage_chain(cmap, g, ga, ga, 0u, na);
    } else if (WIDE) {
       wideA[threadIdx.x] = reinterpret_cast<const fx_nib*>(prog + (BYTES ? h->off_bw16A : h->off_w16A))[threadIdx.x];
    } else {
