@@ -331,6 +331,36 @@ def spec_sections():
     return [("spec_L%d" % L, "R", synth.PATTERNS["cfg4"], L, SPEC_ROWS, lambda L=L: _spec_rows(L, SPEC_ROWS)) for L in SPEC_LENGTHS]
 
 
+# ---- round 5: OVERLONG encodings.  The reference's decoder is arithmetic (src/essential/utf8_m.f90:338-430): `C0 80` is U+0000 (a line start for
+# `^`), `C1 A1` is `a`, `E0 80 B1` and `F0 80 80 B1` are `1` -- bytes >= 0x80 that decode to code points BELOW 0x80.  Rows of config-3 text with such
+# sequences (and valid characters, broken leads, LF) planted at the row's start, its end, across the 128- and 256-byte borders and anywhere. ----
+OVL_LENGTHS = [64, 128, 256, 400]
+OVL_ROWS = 160
+OVL_PATTERNS = [("caret", r"^[a-z]+"), ("cfg3", r"[a-z]+\d+"), ("a", r"a+")]
+_OVL = [b"\xc0\x80", b"\xc1\xa1", b"\xc0\xb1", b"\xc1\xa1\xc1\xa2\xc0\xb7", b"\xe0\x80\x80", b"\xe0\x81\xa1", b"\xe0\x80\xb1", b"\xf0\x80\x80\x80", b"\xf0\x80\x81\xa1",
+        b"\xf0\x80\x80\xb1", b"\xc0", b"\xc1", b"\xe0\x80", b"\xf0\x80\x80", b"\xc2\x80", b"\xe0\xa0\x80", "あ".encode(), b"\n", b"\xc0\x8a", b"\xc1\xa1\xe0\x80\xb1"]
+
+
+def _ovl_rows(L, n):
+    per = (L + 255) // 256
+    base = _cfg_rows("cfg3", [777000 + i for i in range(n * per)]).reshape(n, per * 256)[:, :L].copy()
+    for i in range(n):
+        rng = _Rng(0x6F76 + L, i)
+        for _ in range(1 + rng.next(3)):
+            pl = _OVL[rng.next(len(_OVL))]
+            where = rng.next(5)
+            k = [0, L - len(pl), 128 * (1 + rng.next(max(1, (L >> 7) - 1))) - rng.next(len(pl) + 1), rng.next(L - len(pl) + 1), rng.next(L - len(pl) + 1)][where]
+            k = max(0, min(L - len(pl), k))
+            base[i, k:k + len(pl)] = np.frombuffer(pl, dtype=np.uint8)
+            if rng.next(3) == 0 and k + len(pl) + 3 <= L:   # letters and a digit right behind it: a match that starts at the planted character
+                base[i, k + len(pl):k + len(pl) + 3] = np.frombuffer(b"ab7", dtype=np.uint8)
+    return base
+
+
+def ovl_sections():
+    return [("ovl_%s_L%d" % (nm, L), "R", pat, L, OVL_ROWS, lambda L=L: _ovl_rows(L, OVL_ROWS)) for nm, pat in OVL_PATTERNS for L in OVL_LENGTHS]
+
+
 _ROWS_CACHE = {}
 
 
@@ -349,7 +379,7 @@ def all_sections():
         out.append((nm, op, pat, L, len(idx), lambda nm=nm: config_section_rows(nm)))
     for nm, op, pat, L, idx in mutation_sections():
         out.append((nm, op, pat, L, len(idx), lambda nm=nm: mutation_section_rows(nm)))
-    out += tiny_sections() + table_sections() + long_sections() + spec_sections()
+    out += tiny_sections() + table_sections() + long_sections() + spec_sections() + ovl_sections()
     return [(nm, op, pat, L, n, _cached(nm, g)) for nm, op, pat, L, n, g in out]
 
 
