@@ -1286,6 +1286,9 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
          const uint32_t gbase = LONG ? seg * (SEGB / 8u) : 0u;   // 8-byte groups to the left of this segment
          // the chunk loop in two instantiations: every group whole (always, unless LONG and this is a row's short last segment) or
          // with the per-group byte counts
+         // (round 5: the loop records the hit group's number INSIDE the segment -- an inline constant of the select; with `gbase + 2 k` every group
+         //  first moved a scalar into a vector register: 16 v_mov_b32 per 128 bytes of the half-row kernel)
+         uint32_t gloc = 0xFFFFFFFFu;
          auto walk = [&](auto whole_groups) {
             constexpr bool WG = decltype(whole_groups)::value;
             F fa[8], fb[8];
@@ -1318,7 +1321,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                if (nhi != 0u) {
                   const uint32_t entry = state;
                   const uint32_t mx = nhi == 8u ? chain8_back<F, HALF4>(fa, state, TRp) : chain8_back_n(fa, state, TRp, nhi);
-                  gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k + 1) : gsel;
+                  gloc = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gloc;
                   esel = mx >= fp.hit_min ? entry : esel;
                   asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
                }
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                if (nlo != 0u) {
                   const uint32_t entry = state;
                   const uint32_t mx = nlo == 8u ? chain8_back<F, HALF4>(fb, state, TRp) : chain8_back_n(fb, state, TRp, nlo);
-                  gsel = mx >= fp.hit_min ? gbase + (uint32_t)(2 * k) : gsel;
+                  gloc = mx >= fp.hit_min ? (uint32_t)(2 * k) : gloc;
                   esel = mx >= fp.hit_min ? entry : esel;
                   asm volatile("" : "+v"(esel));
                }
@@ -1345,12 +1348,13 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
             if (seg_len == SEGB) walk(std::true_type{});
             else walk(std::false_type{});
          }
+         gsel = gloc != 0xFFFFFFFFu ? gbase + gloc : gsel;   // (a hit in this segment is further left than any recorded so far)
          if constexpr (CAP) {
             // a hit in THIS segment is the leftmost so far: the 40 bytes from its group on go to registers while they are in LDS (its own
             // chunks and, past the segment's right edge, the look-ahead columns)
-            const bool newhit = gsel < gbase + 2u * (uint32_t)CH;   // (segments go right to left: a hit recorded further right has a larger group number; none: 0xFFFFFFFF)
+            const bool newhit = gloc != 0xFFFFFFFFu;   // (a hit in THIS segment)
             if (cap_on && __builtin_amdgcn_ballot_w64(newhit) != 0) {
-               const uint32_t gl = newhit ? gsel - gbase : 0u;
+               const uint32_t gl = newhit ? gloc : 0u;
 #pragma unroll
                for (int q = 0; q < 5; ++q) {
                   const uint32_t p = (gl + (uint32_t)q) << 3;   // local byte position: < 16 * (CH + 2)
