@@ -321,7 +321,10 @@ class Batch:
             rc = L.fxamd_batch_wrap(ctypes.c_void_p(rows.data_ptr()), n, rl, ctypes.byref(h))
             if rc == 0:   # the tensor's producer (torch's current stream on its device) goes before the batch's private stream
                 import torch
-                L.fxamd_batch_after(h, ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream))
+                rc2 = L.fxamd_batch_after(h, ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream))
+                if rc2 != 0:   # (an unordered private stream would be a data race with the producer, not an error anybody sees: ADVICE r05)
+                    L.fxamd_batch_free(h)
+                    raise RuntimeError("fxamd_batch_after failed: %d" % rc2)
         if rc != 0:
             raise RuntimeError("fxamd_batch_upload / _wrap failed: %d" % rc)
         self._h, self.n, self.row_len = h, int(n), int(rl)
@@ -340,7 +343,9 @@ class Batch:
         arr = (ctypes.c_void_p * len(progs))(*[p._h for p in progs])
         if self._keep is not None:   # wrapped tensor: whatever torch's current stream did to it since goes first
             import torch
-            _lib.lib().fxamd_batch_after(self._h, ctypes.c_void_p(torch.cuda.current_stream(self._keep.device).cuda_stream))
+            rc = _lib.lib().fxamd_batch_after(self._h, ctypes.c_void_p(torch.cuda.current_stream(self._keep.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("fxamd_batch_after failed: %d" % rc)
         rc = _lib.lib().fxamd_batch_run(arr, len(progs), self._h, 1 if spans else 0)
         self._spans = bool(spans) and all(p.op == _lib.OP_SEARCH for p in progs)
         if rc != 0:

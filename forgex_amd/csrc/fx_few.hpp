@@ -45,10 +45,11 @@ constexpr uint32_t fx_few_rows_max() {
 
 template <int CH, bool SPANS, class Emit>
 __device__ __forceinline__ void fx_scan_few_rows(const uint4* tile, const uint2* __restrict__ tabR, const uint2* __restrict__ tabA, const FastParams& P,
-                                                 const uint32_t lane, const uint32_t take, const uint32_t* rowq, Emit& emit) {
+                                                 const uint32_t lane, const uint32_t take, const uint32_t* rowq, Emit& emit, const uint32_t r0 = 0u) {
    static_assert(CH >= 2 && CH <= 16, "cells of a row share a wave");
    constexpr uint32_t L = 16u * CH;
-   const uint32_t r = lane / (uint32_t)CH, k = lane % (uint32_t)CH;
+   // rows r0 .. r0 + 64 / CH - 1 of the gathered tile (round 6: a tile of up to three such groups is scanned group by group)
+   const uint32_t r = r0 + lane / (uint32_t)CH, k = lane % (uint32_t)CH;
    const bool on = r < take && lane < fx_few_rows_max<CH>() * (uint32_t)CH;
    const uint4 cell = tile[tile_cell(on ? r : 0u, on ? k : 0u)];
    uint2 f[16];

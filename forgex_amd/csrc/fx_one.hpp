@@ -101,6 +101,10 @@ struct FxScanCtx {
 #ifndef FX_SPEC_RETRY
 #define FX_SPEC_RETRY 16      // ... for this many tiles of the wave
 #endif
+#ifndef FX_SPEC_FEW_GROUPS
+#define FX_SPEC_FEW_GROUPS 3   // gathered tiles of up to this many groups of 64 / CH rows take the in-LDS decode + the chunk-parallel scan of fx_few.hpp (round 5: one group,
+                               // exception rows only); rows the speculative walk could not answer go there directly, without the byte-level scan in between
+#endif
 #ifndef FX_DEFER_DENSE
 #define FX_DEFER_DENSE 12   // tiles with more hit rows than this finish them in place (config 3 / 5: half of the rows match -- queueing those costs
                             // scattered from / to stores and a second read of the rows' bytes: measured slower, profiles/r03_defer_ab.txt)
@@ -146,7 +150,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       if constexpr (TAIL) {
          // right-to-left from the row's LAST byte: the chunk the row ends in over its valid bytes, then the whole chunks; same two
          // lookup buffers as below
-         const FxTail& T = *c.tl;
+         const FxTail T = fx_tail_here(*c.tl);
          F fa[8], fb[8];
          if (T.nb != 0u) {
             const uint4 wp = tile[tile_cell(lane, T.kt)];
@@ -725,7 +729,7 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
    static_assert(!TAIL || !RAGGED, "TAIL: the round-4 ragged scheme (no pad symbol)");
    if constexpr (TAIL) {
       // ragged rows (fx_tile.hpp, "Ragged rows, round 4"): whole chunks in a rolled loop, then the chunk the row ends in over its text bytes
-      const FxTail& T = *c.tl;
+      const FxTail T = fx_tail_here(*c.tl);
       // (rows of 96 bytes and more on the 8-state tables: whole trips of three chunks with three lookup buffers first, as the aligned rows)
       uint32_t k0 = 0;
       if constexpr (FX_MATCH_PIPE3 != 0 && S_ == 0 && CH >= FX_MATCH_P3_MINCH) {
@@ -864,6 +868,37 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 // MARKED: the follow-up of a multi-pass first pass (the half-row kernel of 256-byte rows): only tiles whose rows that pass marked
 // FX_NEEDS_GENERAL are staged and finished here -- with the byte-level tables or the in-LDS decode, and the exception queues --
 // and the launch leaves at once when `gate` says nothing was deferred.  ONE gated launch instead of two.
+// ---- optional phase stamps of fx_search_one (debug builds only: `make stamp-one`, tools/stamp_one.py) --------------------------------------
+// -DFX_STAMP_ONE: every wave accumulates s_memtime deltas per phase in scalar registers and lane 0 adds them to fx_one_stamp_acc[] at its end.
+// The array has internal linkage (one copy per translation unit): the object built with the macro exports fxamd_debug_stamps_one (fx_tile_inst.hip).
+#ifdef FX_STAMP_ONE
+static __device__ unsigned long long fx_one_stamp_acc[20];
+#define ONE_STAMP_DECL unsigned long long _os_t0 = __builtin_amdgcn_s_memtime(), _os_t = _os_t0, _os_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, _os_tiles = 0, _os_gath = 0
+#define ONE_STAMP(i)                                                 \
+   do {                                                              \
+      const unsigned long long _n = __builtin_amdgcn_s_memtime();    \
+      _os_acc[i] += _n - _os_t;                                      \
+      _os_t = _n;                                                    \
+   } while (0)
+#define ONE_STAMP_COUNT(v) ((v) += 1)
+#define ONE_STAMP_FLUSH                                                                                   \
+   do {                                                                                                   \
+      const unsigned long long _life = __builtin_amdgcn_s_memtime() - _os_t0;                             \
+      if (lane == 0) {                                                                                    \
+         for (int _i = 0; _i < 12; ++_i) atomicAdd(&fx_one_stamp_acc[_i], _os_acc[_i]);                   \
+         atomicAdd(&fx_one_stamp_acc[12], _os_tiles);                                                     \
+         atomicAdd(&fx_one_stamp_acc[13], _os_gath);                                                      \
+         atomicAdd(&fx_one_stamp_acc[14], _life);                                                         \
+         atomicMax(&fx_one_stamp_acc[15], _life);                                                         \
+         atomicAdd(&fx_one_stamp_acc[16], 1ull);                                                          \
+      }                                                                                                   \
+   } while (0)
+#else
+#define ONE_STAMP_DECL
+#define ONE_STAMP(i)
+#define ONE_STAMP_COUNT(v)
+#define ONE_STAMP_FLUSH
+#endif
 #ifndef FX_ONE_ROWS_FIRST
 #define FX_ONE_ROWS_FIRST 0   // (1: the first tile's loads before the table reads -- measured SLOWER, see the start-up comment in the kernel)
 #endif
@@ -882,6 +917,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       else if (gate[3] >= 8u && gate[2] * 2u > gate[3]) hintw[0] = FX_ADAPT_CALLS;
    }
    if (MARKED && gate[0] == 0u) return;   // nothing was deferred
+   ONE_STAMP_DECL;
    // out_mode 0: flags u8[n], from / to int32[n].  out_mode 1 / 2 / 4: PACKED results (what a multi-GPU host gathers):
    // `flags` = 1 bit per row (row i = bit i & 63 of the 64-bit word i >> 6: the ballot of the tile's wave, one store per tile),
    // `from` / `to` = arrays of that many bytes per row (uint8 / uint16 / int32).
@@ -1148,6 +1184,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    uint32_t spec_n = 0;        // rows in this wave's queue of rows the speculative pass could not answer (wave-uniform)
    uint64_t spec_mask = 0;     // lanes whose row of the last speculative pass failed and is not yet queued (wave-uniform)
    uint32_t spec_base = 0;     // ... the first row of that tile (wave-uniform: the rows are spec_base + lane)
+   ONE_STAMP(0);   // start-up: header + tables -> LDS, barrier, tile columns
    for (int64_t t = wave_global;;) {
       bool is_tile = false;
       bool spec_gather = false;   // the gathered tile holds rows of the speculative pass's queue: byte-level scan, not the decode
@@ -1197,15 +1234,19 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
          if (process) {
             if constexpr (RAGGED) {
                store_tile_rag<CH>(stage, tile, lane, tl);
+               fx_rag_fix_last(tile, rows, t << 6, n, lane, tl);   // (the batch's last tile: the text dword its exact extent cut off)
                fx_tail_patch(tile, lane, tl);
             } else store_tile<CH>(stage, tile, lane);
          }
+         ONE_STAMP(1);   // wait for the tile's loads, staging registers -> LDS
+         ONE_STAMP_COUNT(_os_tiles);
          // the ONE place the staging registers are reloaded; a tile behind the last one, or one this pass skips, is "loaded" with
          // zero valid bytes
          t += wave_stride;
          if (MARKED) live = tile_marked(t);
          if constexpr (RAGGED) load_tile_rag<CH>(stage, rows, t << 6, n, lane, tl, live);
          else load_tile<CH>(stage, rows, t << 6, n, lane, live);
+         ONE_STAMP(2);   // issue of the next tile's loads
          if (!process) continue;
       } else {
          // gathered tile: lane r loads row queue[r] straight into its own cells (one row per lane: nothing to transpose)
@@ -1239,6 +1280,8 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
          }
          if (spec_gather) spec_n = 0;
          else pool_n = 0;
+         ONE_STAMP(5);   // gather of queued rows: global memory -> LDS (issued; the wait lands in the scan that reads the cells)
+         ONE_STAMP_COUNT(_os_gath);
       }
       if constexpr (MATCH) mgate = match_gate(h, prog, tb, lane, L);   // (on the raw bytes: before any decode rewrites the cells)
       bool except = false;
@@ -1247,11 +1290,12 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       auto row_or = [&]() {
          uint32_t na = 0;
          if constexpr (RAGGED) {   // text bytes only: the NUL / KILL symbols behind the text are not the row's
-            for (uint32_t k = 0; k < tl.kt; ++k) {
+            const FxTail T = fx_tail_here(tl);
+            for (uint32_t k = 0; k < T.kt; ++k) {
                const uint4 c = tile[tile_cell(lane, k)];
                na |= c.x | c.y | c.z | c.w;
             }
-            if (tl.nb != 0u) na |= fx_tail_or(tile[tile_cell(lane, tl.kt)], tl.nb);
+            if (T.nb != 0u) na |= fx_tail_or(tile[tile_cell(lane, T.kt)], T.nb);
          } else {
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
@@ -1277,10 +1321,17 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
             pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
             pend_row = (uint32_t)row;
          }
+         ONE_STAMP(3);   // class-level scan of a pure-ASCII tile (or up to the byte >= 0x80 that gives it back)
       }
       const bool nonascii = !is_tile || hint || redo;   // (gathered rows always take the decode)
+      // A FEW rows the speculative walk could not answer -- the usual end of a wave: config 4 queues five per wave, its rows with a corrupted byte -- skip
+      // the byte-level scan (a 64-lane backward + forward pass for a handful of rows, which then finds the structure error and queues them AGAIN for a
+      // second gather): the in-LDS decode + the chunk-parallel scan of fx_few.hpp answer every row, broken or not, in a fraction of the instructions
+      // (round 6; FX_SPEC_FEW_GROUPS groups of 64 / CH rows)
+      constexpr bool FEW_OK = SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0 && !RAGGED && !GEN;
+      const bool spec_few = FEW_OK && SPEC && spec_gather && take <= (uint32_t)FX_SPEC_FEW_GROUPS * fx_few_rows_max<CH>();
       if constexpr (HAS_B) {
-         if ((is_tile && (ALLB || nonascii)) || spec_gather) {
+         if ((is_tile && (ALLB || nonascii)) || (spec_gather && !spec_few)) {
             bool done = false;
             if constexpr (SPEC) {
                if (is_tile && !spec_on && (fpb.spec & 1u) != 0u && ++spec_wait >= (uint32_t)FX_SPEC_RETRY) spec_on = true;
@@ -1304,12 +1355,15 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
                      spec_on = false;   // too many rows start their match elsewhere (or hold none): the full scan, in place, for all of them
                      spec_wait = 0;
                   }
+                  ONE_STAMP(4);   // speculative forward walk + its results
                }
             }
             if (!done) {
                (void)scan(BCfg{}, row, row_ok, is_tile, except);
                pend_mask = __builtin_amdgcn_ballot_w64(except && row_ok);
                pend_row = (uint32_t)row;
+               if (is_tile) ONE_STAMP(6);   // byte-level backward + forward scan of a tile in place
+               else ONE_STAMP(7);           // ... of a gathered tile (rows the speculative walk could not answer)
             }
          }
       }
@@ -1328,8 +1382,9 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
             }
             emit(row, true, false, res.flag, res.from, res.to);
          }
+         if (!is_tile) ONE_STAMP(10);   // general row procedure over gathered rows
       }
-      if (!GEN && !spec_gather && ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii))) {
+      if (!GEN && (!spec_gather || spec_few) && ((HAS_B && !is_tile) || (!HAS_B && is_tile && nonascii))) {
          // On-device UTF-8 decode, in place in LDS, into fast-path symbol ids (fxrow::translate_cell16); the 4 bytes before / after
          // a cell are taken from the ORIGINAL neighbours.
          if (HAS_B && !is_tile) {
@@ -1386,19 +1441,25 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
             fx_tail_init<CH>(tile, lane, tl);
             fx_tail_patch(tile, lane, tl);
          }
+         ONE_STAMP(8);   // in-LDS UTF-8 decode
          // a gathered tile of a FEW rows -- the usual end of a wave -- on the 8-state tables: the lanes share the rows' cells (fx_few.hpp).
          // (Rows of 192 / 256 bytes only: those kernels run two waves per SIMD whatever their registers; with the 32 registers of a cell's
          //  table rows the kernels of shorter rows would drop from three waves per SIMD to two -- CH 8: 163 -> 191 VGPRs.)
-         if constexpr (SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0 && !RAGGED) {
-            if (!is_tile && take <= fx_few_rows_max<CH>()) {
-               fx_scan_few_rows<CH, SPANS>(tile, permR, permA, fp, lane, take, myq, emit);
+         if constexpr (FEW_OK) {
+            if (!is_tile && take <= (uint32_t)FX_SPEC_FEW_GROUPS * fx_few_rows_max<CH>()) {
+               for (uint32_t r0 = 0; r0 < take; r0 += fx_few_rows_max<CH>())
+                  fx_scan_few_rows<CH, SPANS>(tile, permR, permA, fp, lane, take, spec_gather ? mysq : myq, emit, r0);
+               ONE_STAMP(9);   // scan of the decoded rows (few rows: chunk-parallel)
                continue;
             }
          }
          (void)scan(FxScanCfg<SCH, false, true>{}, row, row_ok, is_tile, except);
+         ONE_STAMP(9);
       }
    }
    flush_fwd();
+   ONE_STAMP(11);   // match-compaction flush (and the loop's last bookkeeping)
+   ONE_STAMP_FLUSH;
 }
 
 // FastParams of the class-level tables (fp) and of the byte-level tables (fpb) are prepared by the host (fxamd.hip)

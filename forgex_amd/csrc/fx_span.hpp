@@ -36,8 +36,11 @@
 #ifndef FX_SPAN_GB
 #define FX_SPAN_GB 1   // compacted finish passes: 8-symbol groups of the forward window whose lookups are issued together (registers)
 #endif
+#ifndef FX_SPAN_WAVES
+#define FX_SPAN_WAVES 4   // waves per SIMD the aligned instantiations are compiled for (experiment hook)
+#endif
 #ifndef FX_SPAN_RAG_WAVES
-#define FX_SPAN_RAG_WAVES 3   // waves per SIMD the ragged instantiations are compiled for (their wave-uniform guards cost ~50 SGPRs: at four waves they spill)
+#define FX_SPAN_RAG_WAVES 4   // waves per SIMD the ragged instantiations are compiled for (round 5: three -- their wave-uniform guards, hoisted out of the tile loop, cost ~50 SGPRs and 8-40 VGPRs; round 6 recomputes them at their use sites, fx_tail_here: 100-122 VGPRs)
 #endif
 #ifndef FX_SPAN_MIN_ROUNDS
 #define FX_SPAN_MIN_ROUNDS 3   // launch grid: at least this many rounds of the 1024 resident blocks (the half-row kernel's rule; 3 M x 64 B: 56.2 -> 53.5 us,
@@ -78,9 +81,10 @@ __device__ __forceinline__ void fx_span_load(uint4 (&v)[8], const uint8_t* __res
 // RAG: tile t = rows [64 K t, 64 K t + 64 K).  Piece q * 64 + lane = lane-span 8 q + lane / 8, cell lane % 8 of it = chunk k = cell % NCH of
 // the span's row j = cell / NCH: the 16 bytes at row byte 16 k of row (8 q + lane / 8) K + j -- unaligned loads at the row stride; cells whose
 // chunk holds no text ask for an address behind the extent and fetch nothing.  The extent: fx_tile.hpp, load_tile_rag (the batch's last
-// tile ends it at the batch's last byte and rebuilds the straddling dword from byte loads).
+// tile ends it at the batch's last byte; the one text dword that cuts off is rebuilt in LDS after the staging store: fx_last_dword).
 template <int RL>
-__device__ __forceinline__ void fx_span_load_rag(uint4 (&v)[8], const uint8_t* __restrict__ rows, const int64_t n, const int64_t t, const uint32_t lane, const FxTail& T) {
+__device__ __forceinline__ void fx_span_load_rag(uint4 (&v)[8], const uint8_t* __restrict__ rows, const int64_t n, const int64_t t, const uint32_t lane, const FxTail& T_) {
+   const FxTail T = fx_tail_here(T_);
    constexpr uint32_t K = (uint32_t)FxSpan<RL>::K, NCH = (uint32_t)FxSpan<RL>::NCH;
    const int64_t row0 = (t << 6) * (int64_t)K;
    const int64_t rows_left = n - row0;
@@ -101,11 +105,6 @@ __device__ __forceinline__ void fx_span_load_rag(uint4 (&v)[8], const uint8_t* _
       const fx_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)q * step, FX_LOAD_AUX);
       v[q] = make_uint4(x.x, x.y, x.z, x.w);
    }
-   if (last_tile && tile_rows != 0u && (T.Lr & 3u) != 0u && k < T.nch) {   // (the batch's last tile only)
-      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) fx_patch_tail_piece(v[q], tb8, voff + (uint32_t)q * step, valid);
-   }
 }
 
 // 8 symbols of the row that starts at chunk c0 of lane R's cells, from row position p (a multiple of 8, any value): text, then the
@@ -124,9 +123,10 @@ __device__ __forceinline__ void fx_span_group(uint32_t& lo, uint32_t& hi, const 
 // holds a hit (0xFFFFFFFF: none), esel = the state entering it, state = the state after the leading NUL.
 template <int RL, int SCH, bool RAG, class TabT>
 __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t lane, const uint32_t c0, const TabT* __restrict__ tabR, const uint8_t* TRp,
-                                             const FastParams& fp, const FxTail& T, uint32_t& na, uint32_t& gsel, uint32_t& esel, uint32_t& state) {
+                                             const FastParams& fp, const FxTail& T_, uint32_t& na, uint32_t& gsel, uint32_t& esel, uint32_t& state) {
    using F = typename FxF<SCH>::type;
    constexpr int NCH = FxSpan<RL>::NCH;
+   const FxTail T = RAG ? fx_tail_here(T_) : T_;   // (what the guards derive from the row length is recomputed here, not kept live across the tile loop: fx_tile.hpp)
    state = fp.R_start;
    gsel = 0xFFFFFFFFu;
    esel = 0;
@@ -354,7 +354,7 @@ __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint
 // n_deferred: this call's group of four counter words (words of consecutive calls alternate; [0] "tiles were deferred", [2] / [3] the
 // sample FX_ADAPT_CALLS describes)
 template <int RL, int SCH, bool PACKED, bool RAG>
-__global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_span(const uint8_t* __restrict__ rows, const int64_t n, const uint8_t* __restrict__ prog, const FastParams fp,
+__global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void fx_search_span(const uint8_t* __restrict__ rows, const int64_t n, const uint8_t* __restrict__ prog, const FastParams fp,
                                                           uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                           uint32_t* __restrict__ n_deferred, uint32_t* __restrict__ clear_next, uint8_t* __restrict__ marks,
                                                           const uint32_t Lr_in) {
@@ -440,7 +440,6 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
                          (reinterpret_cast<uintptr_t>(to) & (uintptr_t)(K >= 4 ? 15 : 4 * K - 1))) == 0;
    for (int64_t t = wave_global; t < n_tiles;) {
       const int64_t t_next = t + wave_stride;
-      const int64_t row_first = ((t << 6) + lane) * K;
       n_seen += 1u;
       bool defer_tile = false;
       {
@@ -450,6 +449,13 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
       }
       if constexpr (RAG) {
          if ((lane & 7u) % (uint32_t)NCH < tl.nch) store_tile<8>(stage, tile, lane);   // (the chunks behind the text keep their KILL symbols)
+         {   // the batch's last tile: the one text dword its exact extent cut off (fx_last_dword, fx_tile.hpp), written into its row's cell
+            FxLastDword d;
+            if (fx_last_dword(d, rows, (t << 6) * (int64_t)K, n, 64u * (uint32_t)K, tl.Lr)) {   // wave-uniform
+               if (lane == 0)
+                  reinterpret_cast<uint32_t*>(tile)[(tile_cell(d.row / (uint32_t)K, (d.row % (uint32_t)K) * (uint32_t)NCH + (d.m >> 2)) << 2) + (d.m & 3u)] = d.word;
+            }
+         }
          fx_span_load_rag<RL>(stage, rows, n, t_next, lane, tl);   // the ONE place the staging registers are reloaded
          if (tl.nb != 0u) {   // what follows the text in the chunk each row ends in: the trailing NUL, then KILL symbols
 #pragma unroll
@@ -467,9 +473,27 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
          store_tile<8>(stage, tile, lane);
          fx_span_load(stage, rows, total, t_next, lane);   // the ONE place the staging registers are reloaded
       }
-      uint32_t res[K];   // flag | from << 8 | to << 16
+      // a row's result: flag | from << 8 | to << 16 -- or, until its slot is finished, the slot number with bit 31 set.  K >= 4 (rows of up
+      // to 32 bytes: from, to <= 32) keeps TWO rows per register, 16 bits each: flag | from << 1 | to << 7, slot number with bit 15 set --
+      // eight result registers were what the K = 8 instantiations spilled at four waves per SIMD
+      constexpr bool RES16 = K >= 4;
+      uint32_t resw[RES16 ? K / 2 : K];
 #pragma unroll
-      for (int i = 0; i < K; ++i) res[i] = 0u;
+      for (int i = 0; i < (RES16 ? K / 2 : K); ++i) resw[i] = 0u;
+      auto res_get = [&](const int i) -> uint32_t {   // (i is a compile-time constant at every call site: the loops are unrolled)
+         if constexpr (RES16) {
+            const uint32_t h = (resw[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+            return (h & 0x8000u) != 0u ? (0x80000000u | (h & 0x7FFFu)) : ((h & 1u) | (((h >> 1) & 63u) << 8) | (((h >> 7) & 63u) << 16));
+         } else return resw[i];
+      };
+      auto res_raw16 = [&](const int i) -> uint32_t { return (resw[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; };   // RES16: the packed half as it is
+      (void)res_raw16;
+      auto res_set = [&](const int i, const uint32_t v) {
+         if constexpr (RES16) {
+            const uint32_t h = (v & 0x80000000u) != 0u ? (0x8000u | (v & 0x7FFFu)) : ((v & 1u) | (((v >> 8) & 63u) << 1) | (((v >> 16) & 63u) << 7));
+            resw[i >> 1] = (i & 1) ? ((resw[i >> 1] & 0x0000FFFFu) | (h << 16)) : ((resw[i >> 1] & 0xFFFF0000u) | h);
+         } else resw[i] = v;
+      };
       uint32_t na = 0;
       bool sink = false;   // this lane has a row that ended in the overlap state of a bordered prefix literal
       if (!defer_tile) {
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
             sink = fp.inv_on != 0u && state == fp.inv;
             const bool want = hit || nul;
             if (__builtin_amdgcn_ballot_w64(want) != 0)
-               res[0] = fx_span_finish<RL, SCH, 2, RAG>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, TRp, TAp, fp, Lr);
+               res_set(0, fx_span_finish<RL, SCH, 2, RAG>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, TRp, TAp, fp, Lr));
          } else {
             // every row's backward pass; the rows that need the finish take a slot: lane | row << 6 | hit group << 9 | nul << 13 | entry state << 14.
             // Until its slot is finished a row's result register holds the slot number (bit 31 set).
@@ -497,14 +521,18 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
 #pragma unroll
             for (int jr = K - 1; jr >= 0; --jr) {
                uint32_t gsel, esel, state;
-               fx_span_back<RL, SCH, RAG>(tile, lane, (uint32_t)(jr * NCH), tabR, TRp, fp, tl, na, gsel, esel, state);
+               // (the row's cell addresses -- (lane ^ chunk) << 4 | base, one per chunk column -- are loop-invariant, and hoisted out of the tile loop they
+               //  are K more live registers, the ones the K = 8 instantiations spilled at four waves per SIMD: computed here, from an opaque copy of the lane)
+               uint32_t lane_here = lane;
+               if constexpr (K >= 4) asm volatile("" : "+v"(lane_here));
+               fx_span_back<RL, SCH, RAG>(tile, lane_here, (uint32_t)(jr * NCH), tabR, TRp, fp, tl, na, gsel, esel, state);
                const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
                sink = sink || (fp.inv_on != 0u && state == fp.inv);
                const bool want = hit || nul;
                const uint64_t wm = __builtin_amdgcn_ballot_w64(want);
                if (want) {
                   const uint32_t slot = cnt + (uint32_t)__builtin_popcountll(wm & ((1ull << lane) - 1ull));
-                  res[jr] = 0x80000000u | slot;
+                  res_set(jr, 0x80000000u | slot);
                   sq[slot % QCAP] = lane | ((uint32_t)jr << 6) | ((hit && !nul ? gsel : 0u) << 9) | ((nul ? 1u : 0u) << 13) | ((SCH == 0 ? (esel & 0xFFu) : esel) << 14);
                }
                cnt += (uint32_t)__builtin_popcountll(wm);
@@ -513,35 +541,45 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
                      finish_slots(done);
                      // owners of the finished slots take their results now: the ring may reuse the slots
 #pragma unroll
-                     for (int j2 = K - 1; j2 >= jr; --j2)
-                        if ((res[j2] & 0x80000000u) != 0u && (res[j2] & 0x7FFFFFFFu) < done + 64u) res[j2] = sq[(res[j2] & 0x7FFFFFFFu) % QCAP];
+                     for (int j2 = K - 1; j2 >= jr; --j2) {
+                        const uint32_t rv = res_get(j2);
+                        if ((rv & 0x80000000u) != 0u && (rv & 0x7FFFFFFFu) < done + 64u) res_set(j2, sq[(rv & 0x7FFFFFFFu) % QCAP]);
+                     }
                      done += 64u;
                   }
                }
             }
             for (uint32_t base = done; base < cnt; base += 64u) finish_slots(base);
 #pragma unroll
-            for (int jr = 0; jr < K; ++jr)
-               if ((res[jr] & 0x80000000u) != 0u) res[jr] = sq[(res[jr] & 0x7FFFFFFFu) % QCAP];
+            for (int jr = 0; jr < K; ++jr) {
+               const uint32_t rv = res_get(jr);
+               if ((rv & 0x80000000u) != 0u) res_set(jr, sq[(rv & 0x7FFFFFFFu) % QCAP]);
+            }
          }
          // bytes >= 0x80, overlap rows: the whole TILE goes to the follow-up (wave-uniform)
          defer_tile = __builtin_amdgcn_ballot_w64((na & 0x80808080u) != 0u || sink) != 0;
       }
-      if (defer_tile) {
-#pragma unroll
-         for (int i = 0; i < K; ++i) res[i] = FX_NEEDS_GENERAL;
+      if (defer_tile) {   // (the stores below write FX_NEEDS_GENERAL flags for it)
          any_deferred = true;
          n_def += 1u;
       }
+      // (the lane's first row, computed HERE through an opaque copy of t: as a value of the loop's top it is two more registers live across the scan)
+      int64_t t_res = t;
+      asm volatile("" : "+s"(t_res));
+      const int64_t row_first = ((t_res << 6) + lane) * K;
       if constexpr (PACKED) {
          // ---- PACKED results: the tile's 64 K rows = K flag words (8 K bytes of bits), one span byte per row; a deferred tile's words and
          //      spans are the follow-up's ----
-         if (lane < (uint32_t)K) marks[t * K + lane] = defer_tile ? 1u : 0u;
+         {   // (scalar base + lane, as for the flag bytes below)
+            uint8_t* mk = marks + t_res * K;
+            asm volatile("" : "+s"(mk));
+            if (lane < (uint32_t)K) mk[lane] = defer_tile ? 1u : 0u;
+         }
          if (!defer_tile) {
             uint32_t bits = 0, f8lo = 0, f8hi = 0, t8lo = 0, t8hi = 0;   // the lane's K flag bits, its K from / to bytes (rows behind the batch's end: zero)
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-               const uint32_t r = row_first + i < n ? res[i] : 0u;
+               const uint32_t r = row_first + i < n ? res_get(i) : 0u;
                bits |= (r & 1u) << i;
                if (i < 4) {
                   f8lo |= ((r >> 8) & 0xFFu) << (8 * i);
@@ -551,9 +589,13 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
                   t8hi |= ((r >> 16) & 0xFFu) << (8 * (i - 4));
                }
             }
-            uint8_t* const wbytes = flags + (t << 3) * K;   // this tile's 8 K bytes of flag bits
+            uint8_t* wbytes = flags + (t_res << 3) * K;   // this tile's 8 K bytes of flag bits
+            asm volatile("" : "+s"(wbytes));             // (a scalar base + the lane: `flags + lane` hoisted out of the tile loop is a 64-bit value per lane, spilled at K = 8)
             const int64_t word_bytes = ((n + 63) >> 6) << 3;   // whole 64-bit words exist for the batch's rows: nothing is written behind them
-            const bool byte_ok = (t << 3) * K + (int64_t)lane < word_bytes;
+            const int64_t bytes_left = word_bytes - (t_res << 3) * K;   // (wave-uniform; compared with the lane as a 32-bit scalar)
+            uint32_t bytes_left32 = bytes_left >= 64 ? 64u : (bytes_left > 0 ? (uint32_t)bytes_left : 0u);
+            asm volatile("" : "+s"(bytes_left32));
+            const bool byte_ok = lane < bytes_left32;
             if constexpr (K == 1) {
                const uint64_t m = __builtin_amdgcn_ballot_w64(bits != 0u);
                if (lane == 0) reinterpret_cast<uint64_t*>(flags)[t] = m;
@@ -597,8 +639,8 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
 #pragma unroll
                for (int i = 0; i < K; ++i)
                   if (row_first + i < n) {
-                     pf[i] = (uint8_t)((res[i] >> 8) & 0xFFu);
-                     pt[i] = (uint8_t)((res[i] >> 16) & 0xFFu);
+                     pf[i] = (uint8_t)((res_get(i) >> 8) & 0xFFu);
+                     pt[i] = (uint8_t)((res_get(i) >> 16) & 0xFFu);
                   }
             }
          }
@@ -606,9 +648,9 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : 4) void fx_search_sp
          continue;
       }
       // ---- results: the lane's K consecutive rows, one store per array when all of them exist ----
-      auto fl = [&](int i) -> uint32_t { return res[i] & 0xFFu; };
-      auto fr = [&](int i) -> int32_t { return (int32_t)((res[i] >> 8) & 0xFFu); };
-      auto tt = [&](int i) -> int32_t { return (int32_t)((res[i] >> 16) & 0xFFu); };
+      auto fl = [&](int i) -> uint32_t { return defer_tile ? (uint32_t)FX_NEEDS_GENERAL : (res_get(i) & 0xFFu); };
+      auto fr = [&](int i) -> int32_t { return (int32_t)((res_get(i) >> 8) & 0xFFu); };
+      auto tt = [&](int i) -> int32_t { return (int32_t)((res_get(i) >> 16) & 0xFFu); };
       if (row_first + K <= n && wide_ok) {
          if constexpr (K == 1) {
             flags[row_first] = (uint8_t)fl(0);

@@ -298,31 +298,67 @@ __device__ __forceinline__ FxTail fx_tail_of(const uint32_t Lr) {
    const uint32_t nch = (Lr + 15u) >> 4;
    return FxTail{Lr, Lr >> 4, Lr & 15u, nch};
 }
+// The same, re-derived HERE from the row length through an opaque scalar move: what a use site computes from it (the tail masks, the
+// wave-uniform chunk guards -- each a 64-bit lane mask --, strides) is loop-invariant, and the compiler otherwise hoists all of it out of the
+// tile loop: ~100 scalars live across the scan bodies, spilled to lanes of 2-3 VGPRs that the ragged instantiations do not have at three
+// waves per SIMD (scratch in the 128-byte ragged kernels).  A few s_ instructions per tile instead.
+__device__ __forceinline__ FxTail fx_tail_here(const FxTail& T) {
+   uint32_t Lr = T.Lr;
+   asm volatile("" : "+s"(Lr));
+   return fx_tail_of(Lr);
+}
 // tile loads: CH (a power of two here: the dispatch rounds a ragged row's chunk count up to one) lanes share a row -- lane = (r0, k) =
 // (lane / CH, lane % CH) reads the 16 bytes at row byte 16k of row q * (64 / CH) + r0 in instruction q: voff = r0 * Lr + 16k per lane,
 // the rows' distance q * (64 / CH) * Lr in the scalar offset (the range check includes it).  Lanes whose chunk holds no text (k >= nch)
 // ask for an address behind the extent and fetch nothing.  The extent is the tile's bytes + 3 (a dword is dropped whole when it
 // straddles the extent, and the last row's last dword does unless Lr % 4 == 0) -- except for the batch's last tile, whose extent is exact
 // and whose straddling dword is rebuilt from byte loads (fx_patch_tail_piece): nothing behind the caller's last byte is read.
-// The batch's LAST tile gets its exact extent -- nothing behind the caller's last byte is read, whatever page it ends on -- and
-// the dword that straddles that extent, dropped whole by the range check, is rebuilt here from byte loads: `po` = this piece's offset in
-// the tile, `valid` = the tile's bytes.
-__device__ __forceinline__ void fx_patch_tail_piece(uint4& v, const uint8_t* __restrict__ tile_base, const uint32_t po, const uint32_t valid) {
-   uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-   for (int i = 0; i < 4; ++i) {
-      const uint32_t o = po + 4u * (uint32_t)i;
-      if (o < valid && o + 4u > valid) {
-         uint32_t r = 0;
-         for (uint32_t j = 0; o + j < valid; ++j) r |= (uint32_t)tile_base[o + j] << (8u * j);
-         w[i] = r;
-      }
-   }
-   v = make_uint4(w[0], w[1], w[2], w[3]);
+// The batch's LAST tile gets its exact extent -- nothing behind the caller's last byte is read, whatever page it ends on.  The range
+// check drops a dword WHOLE when it straddles the extent, and the last row's last dword does unless (Lr + room) % 4 == 0.  Exactly ONE dword of
+// the tile that holds text can be affected: dword m = (Lr + room) >> 2 of the tile's last row (every other row's text dwords end at or before
+// the extent; the last row's dwords behind m hold no text).  fx_last_dword says which one and rebuilds it from byte loads -- `row0` the tile's
+// first row, `rows_in_tile` what a full tile holds; returns false when nothing is to be done (every tile but the batch's last, and that one
+// when the extent falls on a dword border of its last row).  The callers patch the tile IN LDS right after their staging store, behind this
+// wave-uniform test.  (Round 5 patched the staging REGISTERS in the loaders, piece by piece: 10..40 more live VGPRs on the hot path of every
+// ragged instantiation -- 25 of 58 one-launch kernels of 128-byte instantiations spilled at three waves per SIMD)
+// (The tiny-row kernels' tiles are lane SPANS of whole rows, possibly a partial last one: the same in units of span bytes.)
+struct FxLastDword {
+   uint32_t row;    // unit of the tile (a row; the tiny-row kernels: a lane span) the dword lies in
+   uint32_t m;      // dword of that unit (byte offset 4 m in it)
+   uint32_t word;   // its text bytes (zeros behind the text)
+};
+// the tile = up to `cap` bytes from `tb` on, of which `left` exist in the batch; its pieces' dwords sit at multiples of 4 from the start of each
+// `unit` bytes (a row; a lane span of whole rows).  All arguments wave-uniform.
+__device__ __forceinline__ bool fx_last_dword_bytes(FxLastDword& d, const uint8_t* __restrict__ tb, const int64_t left, const uint32_t cap, const uint32_t unit) {
+   if (left <= 0) return false;
+   const int64_t behind = left - (int64_t)cap;   // bytes of the batch behind this tile
+   if (behind >= 3) return false;                // (the extent is the tile's bytes + 3: nothing straddles)
+   const uint32_t tile_bytes = behind >= 0 ? cap : (uint32_t)left;
+   const uint32_t valid = tile_bytes + (behind > 0 ? (uint32_t)behind : 0u);
+   const uint32_t u = (tile_bytes - 1u) / unit;  // the unit the tile's last byte lies in
+   const uint32_t rem = valid - u * unit;        // bytes from that unit's first byte to the extent
+   if ((rem & 3u) == 0u) return false;
+   const uint32_t m = rem >> 2;
+   const uint32_t text_end = tile_bytes - u * unit;   // bytes of the unit that belong to the tile
+   if (4u * m >= text_end) return false;         // (the straddling dword holds no text)
+   const uint8_t* p = tb + (uint64_t)u * unit + 4u * m;
+   uint32_t w = 0;
+   for (uint32_t j = 0; j < 4u && 4u * m + j < text_end; ++j) w |= (uint32_t)p[j] << (8u * j);
+   d.row = u;
+   d.m = m;
+   d.word = w;
+   return true;
+}
+// ... for tiles of whole rows: `row0` the tile's first row, `rows_in_tile` what a full tile holds
+__device__ __forceinline__ bool fx_last_dword(FxLastDword& d, const uint8_t* __restrict__ rows, const int64_t row0, const int64_t n, const uint32_t rows_in_tile,
+                                              const uint32_t Lr) {
+   if (n - row0 <= 0) return false;
+   return fx_last_dword_bytes(d, rows + row0 * (int64_t)Lr, (n - row0) * (int64_t)Lr, rows_in_tile * Lr, Lr);
 }
 template <int CH>
-__device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, const FxTail& T,
+__device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __restrict__ rows, int64_t row0, int64_t n, uint32_t lane, const FxTail& T_,
                                               bool enable = true) {
+   const FxTail T = fx_tail_here(T_);
    static_assert((CH & (CH - 1)) == 0, "ragged rows: the chunk count of the instantiation is a power of two");
    const int64_t rows_left = n - row0;
    // (a tile that is followed by at least 3 more bytes of the batch reads up to 3 of them: the last row's last dword straddles the tile's end
@@ -344,16 +380,18 @@ __device__ __forceinline__ void load_tile_rag(uint4 (&v)[CH], const uint8_t* __r
       const fx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)q * step, FX_LOAD_AUX);
       v[q] = make_uint4(t.x, t.y, t.z, t.w);
    }
-   if (enable && last_tile && tile_bytes != 0u && (T.Lr & 3u) != 0u) {   // (wave-uniform: the batch's last tile only)
-      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
-#pragma unroll
-      for (int q = 0; q < CH; ++q)
-         if (k < T.nch) fx_patch_tail_piece(v[q], tb8, voff + (uint32_t)q * step, valid);
-   }
 }
 template <int CH>
-__device__ __forceinline__ void store_tile_rag(const uint4 (&v)[CH], uint4* tile, uint32_t lane, const FxTail& T) {
+__device__ __forceinline__ void store_tile_rag(const uint4 (&v)[CH], uint4* tile, uint32_t lane, const FxTail& T_) {
+   const FxTail T = fx_tail_here(T_);
    if (lane % CH < T.nch) store_tile<CH>(v, tile, lane);   // (the chunks behind the text keep their KILL symbols)
+}
+// ... and the batch's last tile: the one text dword the range check dropped (fx_last_dword), written into the row's cell (one lane)
+__device__ __forceinline__ void fx_rag_fix_last(uint4* tile, const uint8_t* __restrict__ rows, const int64_t row0, const int64_t n, const uint32_t lane, const FxTail& T_) {
+   const FxTail T = fx_tail_here(T_);
+   FxLastDword d;
+   if (!fx_last_dword(d, rows, row0, n, 64u, T.Lr)) return;   // wave-uniform
+   if (lane == 0) reinterpret_cast<uint32_t*>(tile)[(tile_cell(d.row, d.m >> 2) << 2) + (d.m & 3u)] = d.word;
 }
 // what follows the text in lane r's own cells: the trailing NUL at byte Lr, KILL symbols (0xFE) behind it.  Chunks behind chunk kt are
 // written ONCE per kernel (the loader never touches them); chunk kt -- the text's last bytes, rewritten with every tile -- is patched here.
@@ -363,7 +401,8 @@ __device__ __forceinline__ uint32_t fx_tail_word(const uint32_t w, const uint32_
    const uint32_t sh = 8u * (nb - at);   // 8, 16 or 24: that many low bits are text
    return (w & ~(0xFFFFFFFFu << sh)) | (0xFEFEFE00u << sh);
 }
-__device__ __forceinline__ void fx_tail_patch(uint4* tile, uint32_t lane, const FxTail& T) {
+__device__ __forceinline__ void fx_tail_patch(uint4* tile, uint32_t lane, const FxTail& T_) {
+   const FxTail T = fx_tail_here(T_);
    if (T.nb == 0u) return;
    uint4 c = tile[tile_cell(lane, T.kt)];
    c.x = fx_tail_word(c.x, 0u, T.nb);
@@ -398,7 +437,8 @@ __device__ __forceinline__ uint4 fx_shr128_bytes(const uint4 v, const uint32_t n
    return make_uint4(fxrow::fx_alignbyte(a1, a0, b), fxrow::fx_alignbyte(a2, a1, b), fxrow::fx_alignbyte(a3, a2, b), fxrow::fx_alignbyte(0u, a3, b));
 }
 template <int CH>
-__device__ __forceinline__ void gather_row_rag(uint4* tile, uint32_t lane, const uint8_t* __restrict__ rp, bool on, const FxTail& T) {
+__device__ __forceinline__ void gather_row_rag(uint4* tile, uint32_t lane, const uint8_t* __restrict__ rp, bool on, const FxTail& T_) {
+   const FxTail T = fx_tail_here(T_);
 #pragma unroll 1
    for (uint32_t k = 0; k < T.kt; ++k) {
       uint4 c = make_uint4(0, 0, 0, 0);

@@ -39,3 +39,13 @@ template hipError_t launch_one_marked<FX_INST_CH, 2, true> FX_ONE_MARKED_SIG;
 #endif
 #endif
 #undef FX_Y
+
+#ifdef FX_STAMP_ONE
+// debug builds only (`make stamp-one`): read and clear the phase accumulators of this object's fx_search_one kernels
+extern "C" __attribute__((visibility("default"))) int fxamd_debug_stamps_one(unsigned long long* out) {
+   unsigned long long z[20] = {0};
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_one_stamp_acc), sizeof(z)) != hipSuccess) return 1;
+   if (hipMemcpyToSymbol(HIP_SYMBOL(fx_one_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
+   return 0;
+}
+#endif

@@ -44,17 +44,12 @@ __device__ __forceinline__ void fx_tiny_load(uint4 (&stage)[4], const uint8_t* _
    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)bhi << 32) | blo), 0,
                                                                          __builtin_amdgcn_readfirstlane(valid), 0x00020000);
-   const bool fix = L % 4 != 0 && last_tile && (valid & 3u) != 0u;   // (LS == 64: pieces are dword-aligned in the tile, the extent is not)
-   const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(base);
    if constexpr (T::LS == 64) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
          const fx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + (uint32_t)q * 1024u, 0, FX_LOAD_AUX);
          stage[q] = make_uint4(v.x, v.y, v.z, v.w);
       }
-      if (fix)
-#pragma unroll
-         for (int q = 0; q < 4; ++q) fx_patch_tail_piece(stage[q], tb8, lane * 16u + (uint32_t)q * 1024u, valid);
    } else {
       const uint32_t r0 = lane >> 2, k = lane & 3u;   // four lanes per span, sixteen spans per instruction
       const uint32_t voff = k < (uint32_t)T::NCH ? r0 * (uint32_t)T::LS + 16u * k : 0x7FFFFFF0u;
@@ -63,15 +58,21 @@ __device__ __forceinline__ void fx_tiny_load(uint4 (&stage)[4], const uint8_t* _
          const fx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)(q * 16 * T::LS), FX_LOAD_AUX);
          stage[q] = make_uint4(v.x, v.y, v.z, v.w);
       }
-      if (L % 4 != 0 && last_tile && tile_bytes != 0u && k < (uint32_t)T::NCH)
-#pragma unroll
-         for (int q = 0; q < 4; ++q) fx_patch_tail_piece(stage[q], tb8, voff + (uint32_t)(q * 16 * T::LS), valid);
    }
 }
+// ... into LDS; `t`: the trip the registers hold.  The batch's last tile: the one text dword its exact extent cut off is rebuilt in LDS (fx_last_dword_bytes,
+// fx_tile.hpp; round 5 patched the staging registers in the loader) -- units are the lane spans of LS bytes: span u = cells of row u, chunk m / 4
 template <int L>
-__device__ __forceinline__ void fx_tiny_store(const uint4 (&stage)[4], uint4* tile, const uint32_t lane) {
+__device__ __forceinline__ void fx_tiny_store(const uint4 (&stage)[4], uint4* tile, const uint32_t lane, const uint8_t* __restrict__ rows, const int64_t total, const int64_t t) {
    using T = FxTiny<L>;
    if (T::LS == 64 || (lane & 3u) < (uint32_t)T::NCH) store_tile<4>(stage, tile, lane);
+   if constexpr (L % 4 != 0) {
+      const int64_t off0 = t * (int64_t)(64 * T::LS);
+      FxLastDword d;
+      if (fx_last_dword_bytes(d, rows + off0, total - off0, 64u * (uint32_t)T::LS, (uint32_t)T::LS)) {   // wave-uniform
+         if (lane == 0) reinterpret_cast<uint32_t*>(tile)[(tile_cell(d.row, d.m >> 2) << 2) + (d.m & 3u)] = d.word;
+      }
+   }
 }
 // the lane's span as 16 dwords (+ one of slack for the byte shifts), and row j of it as NW dwords (bytes behind the row in the last one are
 // whatever follows: the walks look at the row's L bytes only)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void fx_match_tiny(const uint8_t* __restrict__
    uint4 stage[4];
    fx_tiny_load<L>(stage, rows, total, wave_global, lane);
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
-      fx_tiny_store<L>(stage, tile, lane);
+      fx_tiny_store<L>(stage, tile, lane, rows, total, t);
       fx_tiny_load<L>(stage, rows, total, t + wave_stride, lane);   // the ONE reload site of the staging registers
       uint32_t d[17];
       fx_tiny_span<L>(d, tile, lane);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void fx_search_tiny(const uint8_t* __restrict_
    fx_tiny_load<L>(stage, rows, total, wave_global, lane);
    const F fz = tabR[0];   // the leading NUL
    for (int64_t t = wave_global; t < n_tiles; t += wave_stride) {
-      fx_tiny_store<L>(stage, tile, lane);
+      fx_tiny_store<L>(stage, tile, lane, rows, total, t);
       fx_tiny_load<L>(stage, rows, total, t + wave_stride, lane);
       uint32_t d[17];
       fx_tiny_span<L>(d, tile, lane);

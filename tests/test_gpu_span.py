@@ -110,9 +110,9 @@ def _span_path(prog, L):
     return 18 if 2 <= L <= 128 else None
 
 
-def _check(fx, pat, rows_np, dev_rows, want_path, label):
+def _check(fx, pat, rows_np, dev_rows, want_path, label, ref=None):
     import torch
-    of, oa, ob = oracle_lib.batch(2, pat.encode(), rows_np, NT)
+    of, oa, ob = ref if ref is not None else oracle_lib.batch(2, pat.encode(), rows_np, NT)
     prog = fx.Program(pat, fx.OP_SEARCH)
     f, a, b = prog.match_device(dev_rows)
     torch.cuda.synchronize()
@@ -142,10 +142,11 @@ def test_span_kernel_vs_oracle(fx, L, hi_frac, monkeypatch):
         gen = pat in PATS_GEN
         # (candidate-list driver programs take the span kernel at 128-byte rows only by default: FXAMD_SPAN_LENS=63 sends them there at every length)
         monkeypatch.setenv("FXAMD_SPAN_LENS", "63") if gen else monkeypatch.delenv("FXAMD_SPAN_LENS", raising=False)
+        ref = oracle_lib.batch(2, pat.encode(), rows, NT)   # (one oracle pass per pattern: both grids answer the same rows)
         for blocks in ("", "2"):
             monkeypatch.setenv("FXAMD_ONE_BLOCKS", blocks) if blocks else monkeypatch.delenv("FXAMD_ONE_BLOCKS", raising=False)
             monkeypatch.delenv("FXAMD_NO_SPAN", raising=False)
-            prog, f, a, b = _check(fx, pat, rows, dev_rows, None, ("span", L, hi_frac, blocks))
+            prog, f, a, b = _check(fx, pat, rows, dev_rows, None, ("span", L, hi_frac, blocks), ref)
             n_span += 1 if prog.last_path() == 18 else 0
             # flags-only calls are not the span kernel's: they must agree all the same
             ff, _, _ = prog.match_device(dev_rows, spans=False)
