@@ -300,6 +300,159 @@ def dryrun(args, rank, world, emit):
     return 0
 
 
+def single_process(args, emit):
+    """--single-process: ONE process drives the N GPUs of the node, and every shard's packed results land in the ROOT GPU's buffer while the shard is
+    scanned -- the collective-free delivery SURVEY.md section 5 names ("7 peer writes into the root's buffer").  Peer access is enabled from every
+    device to device 0; the root's buffer holds one packed image per shard (forgex_amd.dist.peer_direct_layout); shard i's match call gets its slice
+    of that buffer as `d_packed` (the C ABI takes any device pointer), so GPU i's kernels store their flag words and narrow spans over xGMI as they
+    go.  There is no gather step: the step's time already contains the delivery.  One host thread per GPU enqueues that GPU's launches (a 1.25 M-row
+    shard is a ~66 us step: one thread enqueueing for eight devices would be the bottleneck), each on its own program handle (handles from blobs are
+    never shared: no common mutex).  Same timing contract as the multi-rank path: W untimed steps, then K timed ones between two barriers of all
+    threads with every device synchronised, the slowest device's time counts.
+    FXAMD_BENCH_DRYRUN=1: the same plumbing on the CPU (threads, shard bounds, image offsets, unpack of the root's buffer) without a GPU."""
+    import threading
+    import numpy as np
+    import torch
+    from forgex_amd import synth
+    from forgex_amd import dist as fxdist
+    N = args.gpus
+    cfg = args.config
+    n_cfg, row_len = synth.SHAPES[cfg]
+    spans = not args.flags_only
+    scaling = args.scaling or ("strong" if cfg == "cfg3" and not args.rows else "weak")
+    if scaling == "strong" and not args.rows:
+        bounds = [fxdist.shard_bounds(n_cfg, r, N) for r in range(N)]
+    else:
+        per = args.rows or (n_cfg if cfg != "cfg5" else n_cfg // 8)
+        bounds = [(r * per, (r + 1) * per) for r in range(N)]
+    if DRYRUN:
+        bounds = [(a, a + min(b - a, args.rows or 4096)) for a, b in bounds]
+    sizes = [b - a for a, b in bounds]
+    offs, total = fxdist.peer_direct_layout(sizes, row_len, spans)
+    pattern = synth.PATTERNS[cfg]
+    root_dev = torch.device("cpu") if DRYRUN else torch.device("cuda", 0)
+    root = torch.zeros(max(total, 16), dtype=torch.uint8, device=root_dev)
+    peer = []
+    if not DRYRUN:
+        import forgex_amd
+        assert torch.cuda.is_available() and torch.cuda.device_count() >= N, "--single-process --gpus %d: %d devices visible" % (N, torch.cuda.device_count())
+        hip = ctypes.CDLL("libamdhip64.so")
+        for d in range(1, N):   # device d may write device 0's memory (error 704 = already enabled)
+            assert hip.hipSetDevice(d) == 0
+            rc = hip.hipDeviceEnablePeerAccess(0, 0)
+            peer.append({"device": d, "to": 0, "torch_can_access": bool(torch.cuda.can_device_access_peer(d, 0)), "hipDeviceEnablePeerAccess": int(rc)})
+            assert rc in (0, 704), "no peer access from device %d to device 0 (hip error %d): peer-direct delivery needs xGMI / PCIe peer access" % (d, rc)
+        hip.hipSetDevice(0)
+        base = forgex_amd.Program(pattern, forgex_amd.OP_SEARCH)
+        assert base.status == 0
+        blob = base.blob()
+    bar = threading.Barrier(N + 1)
+    state = {"dt": [0.0] * N, "dt_settled": [0.0] * N, "err": [None] * N, "path": [None] * N, "init_ms": [0.0] * N}
+    rows_keep = [None] * N
+
+    def worker(d):
+        try:
+            a, b = bounds[d]
+            m = b - a
+            image = root[offs[d]:offs[d] + max(fxdist._packed_total(m, row_len, spans), 16)]
+            if DRYRUN:
+                idx = torch.arange(a, b)
+                f = (idx % 3 == 0).to(torch.uint8)
+                fr = ((idx % row_len) + 1).to(torch.int32) * f
+                to = torch.full_like(fr, row_len) * f
+
+                def step():
+                    image.copy_(fxdist.pack_image(f, fr, to, row_len, spans))
+                sync = lambda: None
+            else:
+                dev = torch.device("cuda", d)
+                torch.cuda.set_device(dev)
+                prog = forgex_amd.Program.from_blob(blob, forgex_amd.OP_SEARCH)   # (its own handle: no mutex shared with the other devices' threads)
+                t_i = time.perf_counter()
+                init_rows = synth.batch(cfg, a, 64, dev)
+                prog.match_device_packed(init_rows, spans=spans)
+                assert forgex_amd.lib().fxamd_program_reserve(prog._h, m, torch.cuda.current_stream(dev).cuda_stream) == 0
+                torch.cuda.synchronize(dev)
+                state["init_ms"][d] = (time.perf_counter() - t_i) * 1e3
+                rows = synth.batch(cfg, a, m, dev)
+                rows_keep[d] = rows
+
+                def step():
+                    prog.match_device_packed(rows, spans=spans, out=image)
+                sync = lambda: torch.cuda.synchronize(dev)
+            for _ in range(args.warmup):
+                step()
+            for key in ("dt", "dt_settled"):
+                sync()
+                bar.wait()            # every device idle, every thread here: the timed region starts
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                sync()
+                state[key][d] = time.perf_counter() - t0
+                bar.wait()            # ... and ends when the slowest device has finished
+                if key == "dt":
+                    for _ in range(SETTLE if not DRYRUN else 0):
+                        step()
+            if not DRYRUN:
+                state["path"][d] = prog.last_path()
+        except Exception as e:   # a failed thread must not leave the others in a barrier
+            state["err"][d] = repr(e)
+            bar.abort()
+
+    threads = [threading.Thread(target=worker, args=(d,)) for d in range(N)]
+    for t in threads:
+        t.start()
+    wall = {}
+    try:
+        for key in ("dt", "dt_settled"):
+            bar.wait()
+            t0 = time.perf_counter()
+            bar.wait()
+            wall[key] = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        pass
+    for t in threads:
+        t.join()
+    assert not any(state["err"]), state["err"]
+    rows_all = sum(sizes)
+    dt = wall["dt"]
+    # ---- what arrived in the root's buffer: every shard's image unpacked ON THE ROOT and compared (generator truth in the dry run; the host table
+    #      walker over the regenerated rows on GPUs) -- the peer writes are inside what is checked ----
+    shards = []
+    for d in range(N):
+        a, b = bounds[d]
+        m = b - a
+        image = root[offs[d]:offs[d] + max(fxdist._packed_total(m, row_len, spans), 16)]
+        if DRYRUN:
+            f, fr, to = fxdist.unpack_image(image, m, row_len, spans)
+            idx = torch.arange(a, b)
+            ef = (idx % 3 == 0).to(torch.uint8)
+            ok = bool(torch.equal(f, ef) and (not spans or torch.equal(fr, ((idx % row_len) + 1).to(torch.int32) * ef)))
+            shards.append({"device": d, "rows": m, "mismatches": 0 if ok else 1})
+        elif not args.no_parity:
+            f, fr, to = forgex_amd.unpack_results(image, m, row_len, spans)   # (on device 0: the root's copy)
+            torch.cuda.synchronize()
+            res = full_parity(pattern, rows_keep[d], f, fr, to, os.cpu_count() or 1)
+            shards.append({"device": d, "rows": m, "mismatches": res["mismatches"], "matches": int(f.sum().item())})
+    devices = [("cpu-thread-%d" % d) if DRYRUN else fxdist.device_identity(torch.device("cuda", d)) for d in range(N)]
+    per_image = [max(fxdist._packed_total(m, row_len, spans), 16) for m in sizes]
+    emit({"metric": "input GB/s scanned (.in. over 10M strings)", "value": None if DRYRUN else rows_all * row_len * args.steps / dt / 1e9, "unit": "GB/s", "n_gpus": N,
+          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8",
+          "data": "synthetic", "dryrun": DRYRUN or None, "single_process": True,
+          "settled": {"value": None if DRYRUN else rows_all * row_len * args.steps / wall["dt_settled"] / 1e9, "ms_per_step": wall["dt_settled"] / args.steps * 1e3},
+          "per_device_ms_per_step": [x / args.steps * 1e3 for x in state["dt"]], "per_device_ms_per_step_settled": [x / args.steps * 1e3 for x in state["dt_settled"]],
+          "devices": devices, "devices_distinct": len({repr(x) for x in devices}) == N, "peer_access": peer, "init_ms": state["init_ms"], "kernel_path": state["path"],
+          "delivery": {"mode": "peer-direct: every shard's kernels write their packed image into the root GPU's buffer (device 0) while they scan; no collective, no gather step",
+                       "bytes_per_row": per_image[0] / max(sizes[0], 1), "bytes_into_root_over_links_per_step": int(sum(per_image[1:])), "image_offsets": offs, "root_buffer_bytes": total},
+          "parity": {"root_buffer_shards": shards, "mismatches": sum(x["mismatches"] or 0 for x in shards) if shards else None,
+                     "checker": "generator truth" if DRYRUN else "product tables walked on the host over every shard's regenerated rows vs the root's unpacked images"},
+          "config": {"workload": ("dry run of the single-process plumbing on CPU threads; no GPU work" if DRYRUN else
+                                  "BASELINE %s: `%s` .in. over %d x %d B rows in %d contiguous shards, one process, packed results delivered peer-direct" % (cfg, pattern, rows_all, row_len, N)),
+                     "parallelism": "shard%d" % N, "rows_per_gpu": sizes, "results": "packed (1 bit + 2 narrow spans per row)" if spans else "packed flag bits"}})
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,7 +468,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the whole-batch host check (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region and the roofline leg (profiling runs)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process drives all --gpus N devices; every shard's packed results are written peer-direct into device 0's buffer (no collective)")
     args = ap.parse_args()
+    if args.single_process:
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)   # (libraries' banners go to stderr; the one JSON line to the real stdout)
+
+        def emit1(obj):
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+        sys.exit(single_process(args, emit1))
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -446,7 +609,7 @@ def main():
                  torch.empty(n_cfg, dtype=torch.int32, device=dev) if spans else None)
         main_step = step
 
-        def step():   # noqa: F811 (timed() calls the module-level name)
+        def step():   # noqa: F811 (timed() is a closure of main() too: it calls whatever `step` is bound to in this scope)
             prog.match_device(rows_w, spans=spans, out=out_w)
         for _ in range(SETTLE):
             step()

@@ -119,6 +119,8 @@ struct FxFwdQueue {
    uint32_t n;         // entries (wave-uniform)
    uint32_t family;    // table family of the queued entries: 0 class-level, 1 byte-level (wave-uniform)
    uint2* w;           // LDS (FX_DEFER_STASH): 3 x 64 8-byte groups -- group k of slot s at w[64 k + s]: the flush's re-walk + first window read no global memory
+   const uint8_t* rows = nullptr;   // FX_DEFER_PREFETCH: the batch (rows of L bytes) ...
+   uint32_t pre[6] = {0, 0, 0, 0, 0, 0};   // ... and, per LANE, the three 8-byte groups of the row in the slot this lane will finish (registers)
 };
 struct FxNoFlush {
    __device__ __forceinline__ void operator()() const {}
@@ -284,6 +286,17 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                   uint32_t lo, hi;
                   group_words<false, false>(lo, hi, tb, lane, p0 + 8u * (uint32_t)q, L);
                   if (queued) fq->w[64u * (uint32_t)q + slot] = make_uint2(lo, hi);
+               }
+            }
+            if constexpr (FX_DEFER_PREFETCH != 0 && FX_DEFER_STASH == 0 && CH <= 4) {
+               // the lanes that will FINISH the new slots load those rows' three groups now (fx_finish_from_global's own loads, issued one to three tiles early)
+               const uint32_t n_old = fq->n;
+               if (lane >= n_old && lane < n_old + cnt) {
+                  const uint32_t qrow = fq->q[lane], ge = fq->q[64u + lane];
+                  const uint8_t* rp = fq->rows + (int64_t)qrow * (int64_t)L;
+                  const uint32_t b0 = (ge & 0xFFFFu) * 8u;
+#pragma unroll
+                  for (int q = 0; q < 3; ++q) group_words<false, true>(fq->pre[2 * q], fq->pre[2 * q + 1], rp, lane, b0 + 8u * (uint32_t)q, L, nullptr, true);
                }
             }
             fq->n += cnt;
@@ -872,31 +885,42 @@ __device__ __forceinline__ bool fx_match_tile(const FxScanCtx& c, const TabT* __
 // -DFX_STAMP_ONE: every wave accumulates s_memtime deltas per phase in scalar registers and lane 0 adds them to fx_one_stamp_acc[] at its end.
 // The array has internal linkage (one copy per translation unit): the object built with the macro exports fxamd_debug_stamps_one (fx_tile_inst.hip).
 #ifdef FX_STAMP_ONE
-static __device__ unsigned long long fx_one_stamp_acc[20];
-#define ONE_STAMP_DECL unsigned long long _os_t0 = __builtin_amdgcn_s_memtime(), _os_t = _os_t0, _os_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, _os_tiles = 0, _os_gath = 0
-#define ONE_STAMP(i)                                                 \
-   do {                                                              \
-      const unsigned long long _n = __builtin_amdgcn_s_memtime();    \
-      _os_acc[i] += _n - _os_t;                                      \
-      _os_t = _n;                                                    \
+#define FX_STAMP_MAX_WAVES 16384
+#define FX_STAMP_SLOTS 20
+static __device__ unsigned long long fx_one_stamp_buf[FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS];   // per wave: slots 0..11 and 14..17 phase ticks, 12 tiles, 13 gathered passes, 18 lifetime, 19 launches seen
+// (the per-phase sums live in LDS, 16 slots per wave, added to by lane 0 with ds_add_u64, and every wave ADDS its slots to its own row of the global buffer
+//  with plain stores at its end -- no atomics.  A first version kept twelve 64-bit accumulators in scalar registers: the kernel then ran at one wave per
+//  SIMD and took 242 us instead of 51; a second one added every wave's sums to ONE set of global words: 35 k same-address atomics at ~12 ns each made the
+//  launch 346 us and delayed the last waves' own memory operations)
+#define ONE_STAMP_DECL                                                                   \
+   __shared__ unsigned long long _os_lds[4 * FX_STAMP_SLOTS];                            \
+   if (threadIdx.x < 4 * FX_STAMP_SLOTS) _os_lds[threadIdx.x] = 0ull;                    \
+   const unsigned long long _os_t0 = __builtin_amdgcn_s_memtime();                       \
+   unsigned long long _os_t = _os_t0
+#define ONE_STAMP(i)                                                                                                                         \
+   do {                                                                                                                                      \
+      const unsigned long long _n = __builtin_amdgcn_s_memtime();                                                                            \
+      if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&_os_lds[(threadIdx.x >> 6) * FX_STAMP_SLOTS + (i)], _n - _os_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      _os_t = _n;                                                                                                                            \
    } while (0)
-#define ONE_STAMP_COUNT(v) ((v) += 1)
+#define ONE_STAMP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define ONE_STAMP_COUNT(slot)                                                                                                                \
+   do {                                                                                                                                      \
+      if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(&_os_lds[(threadIdx.x >> 6) * FX_STAMP_SLOTS + (slot)], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+   } while (0)
 #define ONE_STAMP_FLUSH                                                                                   \
    do {                                                                                                   \
       const unsigned long long _life = __builtin_amdgcn_s_memtime() - _os_t0;                             \
-      if (lane == 0) {                                                                                    \
-         for (int _i = 0; _i < 12; ++_i) atomicAdd(&fx_one_stamp_acc[_i], _os_acc[_i]);                   \
-         atomicAdd(&fx_one_stamp_acc[12], _os_tiles);                                                     \
-         atomicAdd(&fx_one_stamp_acc[13], _os_gath);                                                      \
-         atomicAdd(&fx_one_stamp_acc[14], _life);                                                         \
-         atomicMax(&fx_one_stamp_acc[15], _life);                                                         \
-         atomicAdd(&fx_one_stamp_acc[16], 1ull);                                                          \
+      if (lane < (uint32_t)FX_STAMP_SLOTS && wave_global < FX_STAMP_MAX_WAVES) {                          \
+         unsigned long long* _row = fx_one_stamp_buf + wave_global * FX_STAMP_SLOTS;                      \
+         _row[lane] += lane == 18u ? _life : (lane == 19u ? 1ull : _os_lds[wave * FX_STAMP_SLOTS + lane]); \
       }                                                                                                   \
    } while (0)
 #else
 #define ONE_STAMP_DECL
 #define ONE_STAMP(i)
-#define ONE_STAMP_COUNT(v)
+#define ONE_STAMP_WAIT_VM()
+#define ONE_STAMP_COUNT(slot)
 #define ONE_STAMP_FLUSH
 #endif
 #ifndef FX_ONE_ROWS_FIRST
@@ -1106,7 +1130,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       }
    };
    // ---- match compaction: this wave's queue and its flush (every lane finishes one queued row from global memory) ----------------
-   FxFwdQueue fwdq{fwd_q + (DEFERQ ? wave * 128u : 0u), 0u, 0u, fwd_w + ((DEFERQ && FX_DEFER_STASH != 0) ? wave * 192u : 0u)};
+   FxFwdQueue fwdq{fwd_q + (DEFERQ ? wave * 128u : 0u), 0u, 0u, fwd_w + ((DEFERQ && FX_DEFER_STASH != 0) ? wave * 192u : 0u), rows};
    auto flush_fwd = [&]() {
       if constexpr (DEFERQ) {
          if (fwdq.n == 0u) return;
@@ -1120,7 +1144,8 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
             constexpr int S_ = decltype(cfg)::sch;
             with_tables(cfg, [&](auto tabR, auto tabA, const uint8_t* TRp, const uint8_t* TAp, const FastParams& P) {
                const uint32_t e = S_ == 0 ? (ge >> 16) * 0x01010101u : (ge >> 16);
-               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2, decltype(cfg)::sch_a, (FX_DEFER_STASH != 0)>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm, fwdq.w);
+               fx_finish_from_global<S_, (CH <= 4 ? 2 : 4), 2, decltype(cfg)::sch_a, (FX_DEFER_STASH != 0)>(tabR, tabA, TRp, TAp, P, rp, L, lane, on, ge & 0xFFFFu, e, s, mm, fwdq.w,
+                                                                                                            (FX_DEFER_PREFETCH != 0 && FX_DEFER_STASH == 0 && CH <= 4) ? fwdq.pre : nullptr);
                return 0;
             });
          };
@@ -1231,6 +1256,8 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
             const uint32_t smp = RAGGED ? (stage[0].x | stage[0].y | stage[0].w) : (stage[0].x | stage[0].w | stage[CH / 2].y | stage[CH - 1].z);
             hint = __builtin_amdgcn_ballot_w64((smp & 0x80808080u) != 0) != 0;
          }
+         ONE_STAMP_WAIT_VM();
+         ONE_STAMP(1);   // wait for the tile's loads (issued one tile of work ago)
          if (process) {
             if constexpr (RAGGED) {
                store_tile_rag<CH>(stage, tile, lane, tl);
@@ -1238,8 +1265,8 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
                fx_tail_patch(tile, lane, tl);
             } else store_tile<CH>(stage, tile, lane);
          }
-         ONE_STAMP(1);   // wait for the tile's loads, staging registers -> LDS
-         ONE_STAMP_COUNT(_os_tiles);
+         ONE_STAMP(14);   // staging registers -> LDS (the stamp waits for the LDS stores' completion: queued behind the other waves' lookups)
+         ONE_STAMP_COUNT(12);
          // the ONE place the staging registers are reloaded; a tile behind the last one, or one this pass skips, is "loaded" with
          // zero valid bytes
          t += wave_stride;
@@ -1281,7 +1308,7 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
          if (spec_gather) spec_n = 0;
          else pool_n = 0;
          ONE_STAMP(5);   // gather of queued rows: global memory -> LDS (issued; the wait lands in the scan that reads the cells)
-         ONE_STAMP_COUNT(_os_gath);
+         ONE_STAMP_COUNT(13);
       }
       if constexpr (MATCH) mgate = match_gate(h, prog, tb, lane, L);   // (on the raw bytes: before any decode rewrites the cells)
       bool except = false;

@@ -44,6 +44,11 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FX_PREFETCH_DEPTH
 #define FX_PREFETCH_DEPTH 1   // tiles of global loads in flight per wave in the first pass
 #endif
+#ifndef FX_DEFER_PREFETCH
+#define FX_DEFER_PREFETCH 1   // match compaction: the lane that owns a queue slot loads the slot's three 8-byte groups from global memory WHEN the row is queued (they are in
+                              // L2: the tile has just been loaded) and keeps them in six registers -- the flush at the wave's end then waits for no memory (config 2: the flush
+                              // was 2 us of a wave's 17, `profiles/r06_cfg2_phases.md`, most of it one round trip with nothing to overlap)
+#endif
 #ifndef FX_DEFER_FWD
 #define FX_DEFER_FWD 1   // match compaction in fx_search_one (fx_one.hpp): rows of SPARSE tiles that need the exact start + the forward
                          // pass are queued per wave and finished 64 at a time
@@ -699,11 +704,13 @@ __device__ __forceinline__ void fx_stage_chain(uint16_t* __restrict__ dst, const
 // round while any lane is alive).  Returns the wrapped start index s (>= 2) and max_match mm (0 = none; lit_len != 0: s + lit_len, no
 // walk).  The same arithmetic as the in-tile path (fx_scan_tile / fx_search_fast), with the row read through group_words<.., LONG>.
 // (PRE: the window's NW + 1 groups were copied into LDS when the row was queued -- `pre`[64 k + lane] = group k of this lane's row; only a
-//  match longer than the window still reads the row)
+//  match longer than the window still reads the row.  `prr` (round 6): the same three groups in this lane's REGISTERS, loaded from global memory
+//  when the row took its slot -- fx_scan_tile, FX_DEFER_PREFETCH: the flush then waits for nothing.)
 template <int S_, int NW, int GB, int S_A = S_, bool PRE = false, class TabT, class TabTA>
 __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ tabR, const TabTA* __restrict__ tabA, const uint8_t* TRp, const uint8_t* TAp,
                                                       const FastParams& P, const uint8_t* rp, const uint32_t L, const uint32_t lane, const bool on,
-                                                      const uint32_t g, const uint32_t e, uint32_t& s_out, uint32_t& mm_out, const uint2* pre = nullptr) {
+                                                      const uint32_t g, const uint32_t e, uint32_t& s_out, uint32_t& mm_out, const uint2* pre = nullptr,
+                                                      const uint32_t* prr = nullptr) {
    using F = typename FxF<S_>::type;
    using FA = typename FxF<S_A>::type;
    static_assert(NW % GB == 0, "window groups: a multiple of the lookup batch");
@@ -719,6 +726,9 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
          d[2 * q] = r.x;
          d[2 * q + 1] = r.y;
       }
+   } else if (NW == 2 && prr != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 2 * NW + 2; ++k) d[k] = prr[k];
    } else {
       const uint32_t base0 = on ? g * 8u : 0u;
 #pragma unroll
@@ -2069,17 +2079,23 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
       else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
       return hipGetLastError();
    } else {
-      const void* fn = ragged ? (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, true>)
-                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, true>))
-                              : (spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, false>)
-                                       : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, false>));
+      // (ragged rows run on the power-of-two instantiations, as in the one-launch kernel -- fxamd.hip, chunks_of: round 6 retired the ragged variants of 3, 6
+      //  and 12 chunks, 100-odd kernels that answered rows of 33..47 / 65..95 / 129..191 bytes 2-5 % faster than the next power of two does)
+      constexpr bool RAG_OK = (CH & (CH - 1)) == 0;
+      if (ragged && !RAG_OK) return hipErrorInvalidValue;
+      const void* fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, false>) : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, false>);
+      if constexpr (RAG_OK) {
+         if (ragged) fn = spans ? reinterpret_cast<const void*>(&fx_search_fast<CH, true, MODE, SCH, true>) : reinterpret_cast<const void*>(&fx_search_fast<CH, false, MODE, SCH, true>);
+      }
       if (lds > 64 * 1024) {   // beyond the default dynamic-LDS window: raise the kernel's limit (idempotent)
          hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e != hipSuccess) return e;
       }
       if (ragged) {
-         if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
-         else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         if constexpr (RAG_OK) {
+            if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+            else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+         }
       } else {
          if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
          else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
@@ -2143,14 +2159,19 @@ hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, F
       hipLaunchKernelGGL((fx_match_fast<CH, MODE, CHN, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
       return hipGetLastError();
    } else {
+      constexpr bool RAG_OK = (CH & (CH - 1)) == 0;   // (ragged rows: the power-of-two instantiations only, see launch_fast)
+      if (ragged && !RAG_OK) return hipErrorInvalidValue;
+      const void* fn = reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, false>);
+      if constexpr (RAG_OK) {
+         if (ragged) fn = reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, true>);
+      }
       if (lds > 64 * 1024) {
-         hipError_t e = hipFuncSetAttribute(ragged ? reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, true>)
-                                                   : reinterpret_cast<const void*>(&fx_match_fast<CH, MODE, SCH, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
          if (e != hipSuccess) return e;
       }
-      if (ragged) hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
-      else hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      if (ragged) {
+         if constexpr (RAG_OK) hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
+      } else hipLaunchKernelGGL((fx_match_fast<CH, MODE, SCH, false>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, n_deferred, map_lds, Lr, clear_next, worklist);
       return hipGetLastError();
    }
 }

@@ -41,11 +41,13 @@ template hipError_t launch_one_marked<FX_INST_CH, 2, true> FX_ONE_MARKED_SIG;
 #undef FX_Y
 
 #ifdef FX_STAMP_ONE
-// debug builds only (`make stamp-one`): read and clear the phase accumulators of this object's fx_search_one kernels
-extern "C" __attribute__((visibility("default"))) int fxamd_debug_stamps_one(unsigned long long* out) {
-   unsigned long long z[20] = {0};
-   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_one_stamp_acc), sizeof(z)) != hipSuccess) return 1;
-   if (hipMemcpyToSymbol(HIP_SYMBOL(fx_one_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
+// debug builds only (`make stamp-one`): read and clear the per-wave phase sums of this object's fx_search_one kernels (FX_STAMP_MAX_WAVES x FX_STAMP_SLOTS words)
+extern "C" __attribute__((visibility("default"))) int fxamd_debug_stamps_one(unsigned long long* out, long long max_words) {
+   const size_t bytes = sizeof(unsigned long long) * (size_t)(max_words < (long long)(FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS) ? max_words : FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS);
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_one_stamp_buf), bytes) != hipSuccess) return 1;
+   void* p = nullptr;
+   if (hipGetSymbolAddress(&p, HIP_SYMBOL(fx_one_stamp_buf)) != hipSuccess) return 1;
+   if (hipMemset(p, 0, sizeof(unsigned long long) * FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS) != hipSuccess) return 1;
    return 0;
 }
 #endif

@@ -547,9 +547,12 @@ static int one_chunks(int64_t row_len) {
 }
 // long rows (any length): walked in 256-byte segments by the CH = 16 instantiations
 static bool long_row(int64_t row_len) { return row_len > 256 && row_len <= 65536; }
-static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : tile_chunks(row_len); }
+// (the multi-pass kernels take ragged rows on the power-of-two instantiations too: round 6 -- launch_fast / launch_match, fx_tile.hpp)
+static int chunks_of(int64_t row_len) { return long_row(row_len) ? 16 : one_chunks(row_len); }
 // ... and the larger of the two instantiations a row length may meet (LDS budgets of table schemes that must hold for both pipelines)
 static int chunks_max(int64_t row_len) { return long_row(row_len) ? 16 : std::max(tile_chunks(row_len), one_chunks(row_len)); }
+// ... and the tile columns that instantiation allocates per row (the LDS budgets of fast_scheme / bytes_ok are coupled to the allocation: ADVICE r05)
+static size_t tile_cols_max(int64_t row_len) { return long_row(row_len) ? (size_t)fx_tile_cols<16, true, true>() : (size_t)chunks_max(row_len) + 1; }
 // what a pass needs to know beyond the tables: deferral policy of a first pass, gate word of a marked-tile pass
 struct PassOpts {
    uint32_t defer_tiles = 0, gate_word = 0;
@@ -631,7 +634,8 @@ static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
    if (h.flags & FXP_F_FAST_OK) return 0;
    if ((h.flags & FXP_F_W16_OK) && !fx_env().no_w16) return 2;
    if (h.flags & FXP_F_CHAIN_OK) {
-      const size_t need = (size_t)4 * 64 * 16 * (chunks_max(row_len) + 1) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
+      // (tile columns: chunks + the end-of-row column; the long-row walkers with spans have one more -- fx_tile_cols<16, true, true>, the window capture)
+      const size_t need = (size_t)4 * 64 * 16 * tile_cols_max(row_len) + 512 + h.chain_TR_bytes + h.chain_TA_bytes + 16 + (1024u + h.n_pages * 64u) * 2u;
       if (need <= 150 * 1024) return 1;
    }
    return -1;
@@ -644,7 +648,7 @@ static int bytes_scheme(const FxpHeader& h) { return ((h.flags & FXP_F_BYTE_W16)
 static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len, bool ragged_too = false) {
    if (fx_env().no_byte_dfa) return false;   // test hook: exercise the decode pass instead
    if (!(h.flags & FXP_F_BYTE_DFA) || !row_len_ok(h, d_rows, row_len) || (!long_row(row_len) && !ragged_too && row_len != 16 * tile_chunks(row_len))) return false;
-   return (size_t)4 * 64 * 16 * (chunks_max(row_len) + 1) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
+   return (size_t)4 * 64 * 16 * tile_cols_max(row_len) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
 
 template <int MODE, int SCH>
@@ -888,37 +892,37 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // `.match.` over tiny rows (2 to 32 bytes) on the class-level v_perm / nibble tables: a lane takes a span of 64 / L whole
       // rows (fx_tiny.hpp); a first pass of the multi-pass kind: rows with bytes >= 0x80 are listed for the row-level fix-up
       // ... and the `.in.` VERDICT (no spans asked for) over the same rows: fx_search_tiny
+      // (a stream that is being captured into a hipGraph keeps the one-launch kernel wherever another pipeline would hold host-side state between
+      //  launches -- the counter groups alternate on the host.  Asked ONCE per call, and only when a rule below can need it: ADVICE r05.)
+      bool capturing_known = false, capturing_val = false;
+      auto capturing = [&]() -> bool {
+         if (!capturing_known) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+            else capturing_val = cap != hipStreamCaptureStatusNone;
+            capturing_known = true;
+         }
+         return capturing_val;
+      };
       bool tiny = first_pass == FX_FP_OWN && (is_match || (h.mode == FXP_MODE_SEARCH_ENGINE && d_from == nullptr && !(h.flags & FXP_F_RAW_BYTES))) && out_mode == 0u &&
                   row_len >= 2 && row_len <= 32 && (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
-      if (tiny) {   // (a stream that is being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches)
-         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-         else if (cap != hipStreamCaptureStatusNone) tiny = false;
-      }
+      if (tiny && capturing()) tiny = false;
       // Where round 4 moved rows off the one-launch kernel -- 256-byte rows on the chain / nibble tables (half rows) -- a stream that is
       // being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches (the counter groups of
       // the multi-pass pipelines alternate on the host).
       // (Rows of 129..255 bytes on the chain tables walked like long rows, in 128-byte segments, were tried too: the 17-state pattern over
       //  200-byte rows 1.283 -> 1.349 ms -- a 128-byte and a 72-byte segment pay two segments' fixed work; gpurun call r04_c34.)
       bool half = is_match ? match_half_rows(h, scheme, row_len) : half_rows(h, scheme, row_len);
-      if (half && (scheme != 0 || is_match)) {
-         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-         else if (cap != hipStreamCaptureStatusNone) half = false;
-      }
+      if (half && (scheme != 0 || is_match) && capturing()) half = false;
       const bool as_long = long_row(row_len);
-      // Rows of 128 / 64 bytes with spans on the 8-state tables (round 5, fx_span.hpp; BASELINE configs 5 and 2): a lane owns a 256-byte span
-      // of two / four whole rows -- the half-row kernel's memory path and four waves per SIMD.  Programs whose tables decode UTF-8: first pass
-      // + ONE gated follow-up over the tiles it marked (last_path 18; the counter groups alternate on the host, so a stream under hipGraph
-      // capture keeps the one-launch kernel); candidate-list driver programs: the general row procedure for the rows the tables cannot answer
-      // inside the same launch (GEN, last_path 19: no host-side state).  FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook).
+      // Rows of 2..128 bytes with spans on the 8-state tables (round 5, fx_span.hpp; BASELINE config 5): a lane owns a 128-byte span of
+      // 128 / RL whole rows -- the half-row kernel's memory path and four waves per SIMD -- first pass + ONE gated follow-up over the tiles it
+      // marked (last_path 18; the counter groups alternate on the host, so a stream under hipGraph capture keeps the one-launch kernel); for
+      // candidate-list driver programs the follow-up is the GEN instantiation (the general row procedure for the rows the tables cannot answer;
+      // still 18).  FXAMD_NO_SPAN=1: the one-launch kernel (test / A-B hook).
       bool span = first_pass == FX_FP_OWN && (out_mode == 0u || (out_mode == 1u && !fx_env().no_pack_first)) && !half && !tiny &&
                   span_kind(h, scheme, row_len, d_from != nullptr && d_to != nullptr);
-      if (span) {   // (a stream under hipGraph capture keeps the one-launch kernel: the counter groups alternate on the host)
-         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-         else if (cap != hipStreamCaptureStatusNone) span = false;
-      }
+      if (span && capturing()) span = false;   // (a stream under hipGraph capture keeps the one-launch kernel: the counter groups alternate on the host)
       // ... and as the FIRST PASS of the multi-pass pipeline for automata of 9..16 states (round 5): aligned rows of 128 / 64 / 32 / 16 bytes on
       // the nibble tables; the tiles it marks go to the passes that pipeline has (byte-level tables over marked tiles / the decode pass), so it
       // needs one of the two.  last_path 20.  Measured (gpurun calls r05_c14 / c15, FXAMD_NO_SPAN=1 as the other arm): 16-byte rows 0.862 -> 0.575 ms,
@@ -928,9 +932,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
           !(h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) && !fx_env().multipass && !fx_env().no_span && (fx_env().span_lens & 64) &&
           scheme == 2 && (row_len == 128 || row_len == 64 || row_len == 32 || row_len == 16) &&
           (scheme_decodes_utf8(h, scheme) || bytes_ok(h, d_rows, row_len))) {
-         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-         if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-         span_first = cap == hipStreamCaptureStatusNone;
+         span_first = !capturing();
       }
       const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !span_first && !fx_env().multipass;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
@@ -2114,8 +2116,14 @@ void fxamd_batch_free(fxamd_batch* b) {
 int fxamd_batch_after(fxamd_batch* b, void* producer_hip_stream) {
    if (!b) return FXAMD_E_ARG;
    std::lock_guard<std::mutex> g(b->mu);
-   FX_HIP(hipEventRecord(b->ev, (hipStream_t)producer_hip_stream));
-   FX_HIP(hipStreamWaitEvent(b->st, b->ev, 0));
+   // (on the batch's device: a null producer stream then means the rows' device, whatever the caller's current device is -- ADVICE r05)
+   int cur = -1;
+   if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+   if (cur != b->dev) FX_HIP(hipSetDevice(b->dev));
+   hipError_t e = hipEventRecord(b->ev, (hipStream_t)producer_hip_stream);
+   if (e == hipSuccess) e = hipStreamWaitEvent(b->st, b->ev, 0);
+   if (cur >= 0 && cur != b->dev) (void)hipSetDevice(cur);
+   FX_HIP(e);
    return FXAMD_OK;
 }
 int fxamd_batch_info(const fxamd_batch* b, int64_t* n, int64_t* row_len) {

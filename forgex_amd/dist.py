@@ -183,3 +183,41 @@ def gather_floats(x, device):
     got = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(got, t)
     return [float(g.item()) for g in got]
+
+
+# ---- collective-free delivery ("7 peer writes into the root's buffer"; round 6) -------------------------------------------
+# ONE process drives every GPU of the node (peer access enabled): the root's result buffer holds one packed image per shard, and each shard's
+# match call is given ITS slice of that buffer as `d_packed` -- the C ABI takes any device pointer -- so the kernels of GPU i write their flag
+# words and narrow spans straight into the root GPU's HBM over xGMI while they run.  No gather step, no collective, nothing to wait for after
+# the scan but the stores themselves.  bench.py --single-process times it; the RCCL gather above stays the path of one-process-per-GPU hosts.
+def peer_direct_layout(sizes, row_len, spans=True):
+    """Offsets of the shards' packed images in the root's buffer (16-byte aligned, the C ABI's fxamd_packed_layout sizes) -> (offsets, total)."""
+    offs, o = [], 0
+    for m in sizes:
+        offs.append(o)
+        o += max(_packed_total(m, row_len, spans), 16)
+    return offs, o
+
+
+def pack_image(flags, frm, to, row_len, spans=True):
+    """One shard's packed image as a uint8 tensor -- the layout the kernels write, with torch ops (CPU dry runs and cross-checks)."""
+    n = flags.shape[0]
+    bits, f8, t8 = pack_results(flags, frm if spans else flags.new_zeros(n, dtype=torch.int32), to if spans else flags.new_zeros(n, dtype=torch.int32), row_len)
+    img = torch.zeros(max(_packed_total(n, row_len, spans), 16), dtype=torch.uint8, device=flags.device)
+    img[:bits.numel()] = bits
+    if spans:
+        off_f, off_t, _ = packed_layout(n, row_len)
+        fb, tb = f8.view(torch.uint8), t8.view(torch.uint8)
+        img[off_f:off_f + fb.numel()] = fb
+        img[off_t:off_t + tb.numel()] = tb
+    return img
+
+
+def unpack_image(img, n, row_len, spans=True):
+    """Inverse of pack_image (torch ops): -> (flags uint8[n], from int32[n] or None, to int32[n] or None)."""
+    if not spans:
+        f, _, _ = unpack_results(img[:(n + 7) // 8], img.new_zeros(0), img.new_zeros(0), n)
+        return f, None, None
+    w, dt = span_bytes(row_len), span_dtype(row_len)
+    off_f, off_t, _ = packed_layout(n, row_len)
+    return unpack_results(img[:(n + 7) // 8], img[off_f:off_f + n * w].view(dt), img[off_t:off_t + n * w].view(dt), n)

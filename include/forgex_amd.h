@@ -188,10 +188,20 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * 15 = first pass shared with other patterns (fx_search_multi).  16 = 256-byte rows: half-row first pass + ONE gated follow-up of the
  * one-launch kernel over the tiles that pass left.  17 = `.match.` and the `.in.` verdict (no spans) over rows of 2 to 32 bytes:
  * fx_match_tiny / fx_search_tiny (a lane takes a span of 64 / L whole rows) + the gated row-level fix-up of rows with bytes >= 0x80
- * (a stream under hipGraph capture keeps path 9-14).  256-byte rows of programs with more than 8 states (chain and nibble tables) report 5 / 6 / 8 as well: the same pipeline with a half-row first pass at four waves per SIMD (one-launch
+ * (a stream under hipGraph capture keeps path 9-14).
+ * 18 = searches WITH SPANS over rows of 2 to 128 bytes on the 8-state tables: fx_search_span (a lane owns a 128-byte span of 128 / RL whole
+ * rows, RL = the row length rounded up to 16 / 32 / 64 / 128; plain or packed results) + ONE gated follow-up of the one-launch kernel over
+ * the tiles it marked (a byte >= 0x80, a row in the overlap state of a bordered prefix); for candidate-list driver programs that follow-up
+ * runs the general row procedure on queued rows (still 18).  20 = the same kernel on the NIBBLE tables as the first pass of the multi-pass
+ * pipeline (9..16-state programs, rows of exactly 16 / 32 / 64 / 128 bytes, plain results), followed by that pipeline's gated passes.
+ * Both keep the one-launch kernel on a stream under hipGraph capture.  256-byte rows of programs with more than 8 states (chain and nibble tables) report 5 / 6 / 8 as well: the same pipeline with a half-row first pass at four waves per SIMD (one-launch
  * kernel on a stream under hipGraph capture); rows longer than 256 bytes on the chain tables: 7 or 5 / 6, walked in 128-byte segments.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
  * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_NO_TINY, FXAMD_NO_ADAPT, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,
+ * FXAMD_NO_SPAN (paths 18 / 20 off: the one-launch kernel), FXAMD_SPAN_LENS (bit mask, default 111: bits 0..3 = rows that get 128 / 64 / 32 / 16
+ * bytes of LDS take path 18; bit 4 = candidate-list driver programs too at rows of up to 64 bytes; bit 5 = ragged rows, any length 2..127 that
+ * is not one of the four; bit 6 = path 20),
+ * FXAMD_NO_PACK_FIRST (packed results through fx_pack instead of straight from the first passes),
  * FXAMD_HALF_SCH (bit s: table scheme s -- 0 v_perm, 1 chain, 2 nibble -- takes half rows; bit 3: 128-byte segments of long chain rows;
  * bit 4: 128-byte rows on the chain tables in 64-byte halves);
  * grid experiments: FXAMD_ONE_GRID, FXAMD_ONE_ROUND_MB, FXAMD_ONE_BLOCKS, FXAMD_HALF_ROUNDS.  They are read once

@@ -159,3 +159,44 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, FXAMD_BENCH_DRYRUN="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], env=env, capture_output=True, timeout=120, cwd=ROOT)
     assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_single_process_peer_direct_dry_run():
+    """`python bench.py --gpus N --single-process`: ONE process, one host thread per device, every shard's packed image written into ITS slice of the root
+    device's buffer (forgex_amd.dist.peer_direct_layout) -- no process group, no collective (peer writes into the root's buffer).  CPU dry run of
+    that plumbing (no gloo, no GPU): shard bounds, image offsets, the two-barrier timing contract, and the root's buffer unpacked and checked per shard."""
+    from forgex_amd import dist as fxdist
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "4", "--single-process", "--steps", "3", "--warmup", "1", "--rows", "1001"])
+    assert line["single_process"] is True and line["n_gpus"] == 4 and line["dryrun"] is True
+    assert line["config"]["parallelism"] == "shard4" and line["config"]["rows_per_gpu"] == [1001] * 4
+    assert len(line["per_device_ms_per_step"]) == 4 and line["devices_distinct"] is True and len(line["devices"]) == 4
+    assert line["parity"]["mismatches"] == 0 and [x["rows"] for x in line["parity"]["root_buffer_shards"]] == [1001] * 4
+    offs, total = fxdist.peer_direct_layout([1001] * 4, 256, True)
+    assert line["delivery"]["image_offsets"] == offs and line["delivery"]["root_buffer_bytes"] == total
+    assert all(o % 16 == 0 for o in offs) and line["delivery"]["bytes_into_root_over_links_per_step"] == total - offs[1]
+    # the driver's own form: config 3's rows split four ways (strong scaling), flags only as well
+    line = _bench_dryrun([sys.executable, "bench.py", "--gpus", "3", "--single-process", "--steps", "2", "--warmup", "1", "--flags-only"])
+    assert line["scaling"] == "strong" and sum(line["config"]["rows_per_gpu"]) <= 3 * 4096 and line["parity"]["mismatches"] == 0
+
+
+def test_peer_direct_images_are_the_c_abis_layout():
+    """pack_image / unpack_image (torch ops) against the C ABI's fxamd_packed_layout sizes, and the images of uneven shards side by side in one buffer."""
+    import forgex_amd
+    from forgex_amd import dist as fxdist
+    for L in (8, 128, 255, 256, 1000):
+        sizes = [1, 63, 64, 1003]
+        offs, total = fxdist.peer_direct_layout(sizes, L, True)
+        root = torch.zeros(total, dtype=torch.uint8)
+        want = []
+        for m, o in zip(sizes, offs):
+            assert max(forgex_amd.packed_layout(m, L, True)[2], 16) == max(fxdist._packed_total(m, L, True), 16)
+            idx = torch.arange(m)
+            f = (idx % 2 == 0).to(torch.uint8)
+            a = ((idx % L) + 1).to(torch.int32) * f
+            b = torch.full((m,), L, dtype=torch.int32) * f
+            img = fxdist.pack_image(f, a, b, L)
+            root[o:o + img.numel()] = img
+            want.append((f, a, b))
+        for (m, o), (f, a, b) in zip(zip(sizes, offs), want):
+            f2, a2, b2 = fxdist.unpack_image(root[o:o + max(fxdist._packed_total(m, L, True), 16)], m, L)
+            assert torch.equal(f, f2) and torch.equal(a, a2) and torch.equal(b, b2), (L, m)

@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""Per-phase cycle shares of fx_search_one (debug build `make -C forgex_amd/csrc stamp-one [STAMP_OBJ=12_2]`; run on the GPU box).
+"""Per-phase cycle shares of fx_search_one (debug build `make -C forgex_amd/csrc stamp-one [STAMP_OBJ=12_2]`: the object <chunks>_<part> the
+config's kernel lives in -- config 4: 12_2, config 2: 4_3; run on the GPU box).
 
-    FXAMD_LIB=forgex_amd/libforgex_amd_stamp_one.so python tools/stamp_one.py [cfg4] [--flags-only] [--md]
+    FXAMD_LIB=forgex_amd/libforgex_amd_stamp_one_12_2.so python tools/stamp_one.py [cfg4] [--flags-only] [--md]
 
-Every wave accumulates s_memtime deltas per phase (scalar registers); lane 0 adds them to a device array at the wave's end.  Printed: each
-phase's share of the waves' summed lifetimes, cycles per tile, and what the kernel's wall time (HIP events) is made of -- the average
-and the longest wave lifetime against the launch's duration.  The stamps themselves cost a few percent (s_memtime + s_waitcnt per
-stamp); the un-stamped library's time for the same call is printed next to it when FXAMD_REF_LIB names it.
+Every wave accumulates s_memtime deltas per phase (LDS slots, lane 0) and adds them to its own row of a device buffer at its end (plain stores).
+Printed: each phase's ticks per wave (average over waves and launches), its share of the waves' lifetime, the spread of the waves' lifetimes, and
+the launch's duration by HIP events next to it.  s_memtime counts shader-clock ticks; the tick length is taken from the longest wave's lifetime
+against the launch's duration (one round of resident blocks: the longest wave spans the launch but for its dispatch).  The stamps cost a few percent
+(s_memtime + a wait for outstanding LDS operations per stamp, one explicit wait for the tile's loads); `FXAMD_REF_US` prints the product's time.
 """
 import ctypes
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FXAMD_LIB", os.path.join(ROOT, "forgex_amd", "libforgex_amd_stamp_one.so"))
+os.environ.setdefault("FXAMD_LIB", os.path.join(ROOT, "forgex_amd", "libforgex_amd_stamp_one_12_2.so"))
 import torch
 import forgex_amd
 from forgex_amd import synth
 
+MAX_WAVES, SLOTS = 16384, 20
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 cfg = args[0] if args else "cfg4"
 spans = "--flags-only" not in sys.argv
@@ -29,15 +34,21 @@ dev = torch.device("cuda", 0)
 rows = synth.batch(cfg, 0, n, dev)
 prog = forgex_amd.Program(synth.PATTERNS[cfg], forgex_amd.OP_SEARCH)
 lib = forgex_amd.lib()
-lib.fxamd_debug_stamps_one.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-buf = (ctypes.c_ulonglong * 20)()
+lib.fxamd_debug_stamps_one.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+buf = np.zeros(MAX_WAVES * SLOTS, dtype=np.uint64)
+
+
+def read():
+    assert lib.fxamd_debug_stamps_one(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
+    return buf.reshape(MAX_WAVES, SLOTS).astype(np.float64)
+
 
 prog.match_device(rows, spans=spans)
 torch.cuda.synchronize()
 for _ in range(60):   # (the clocks settle over the first back-to-back launches)
     prog.match_device(rows, spans=spans)
 torch.cuda.synchronize()
-assert lib.fxamd_debug_stamps_one(buf) == 0
+read()
 REPS = 40
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -45,32 +56,33 @@ for _ in range(REPS):
     prog.match_device(rows, spans=spans)
 e1.record()
 torch.cuda.synchronize()
-assert lib.fxamd_debug_stamps_one(buf) == 0
 us = e0.elapsed_time(e1) * 1000.0 / REPS
-v = [float(x) for x in buf]
-names = ["start-up (header, tables -> LDS, barrier)", "wait for the tile's loads + LDS store", "issue of the next tile's loads", "class-level scan (ASCII tile)",
-         "speculative forward walk + results", "gather of queued rows (issue)", "byte-level scan in place", "byte-level scan of gathered rows", "in-LDS decode",
-         "scan of decoded rows", "general row procedure", "end (compaction flush, loop exit)"]
-tiles, gath, life_sum, life_max, waves = v[12] / REPS, v[13] / REPS, v[14], v[15], v[16] / REPS
-tot = sum(v[:12]) or 1.0
-# s_memtime counts at 100 MHz on gfx9 (the constant "REFCLK"); convert with the measured wall time of the longest wave when that is plausible
-print("%s %s: path %d, %.2f us per launch (HIP events over %d launches), %d waves, %.1f tiles and %.2f gathered passes per wave" %
-      (cfg, "spans" if spans else "flags only", prog.last_path(), us, REPS, waves, tiles / waves, gath / waves))
-avg_life = life_sum / (REPS * waves)
-print("wave lifetime: average %.0f ticks, longest %.0f ticks; launch = %.2f us -> 1 tick = %.4f us if the longest wave spans the launch" %
-      (avg_life, life_max, us, us / life_max))
-tick_us = us / life_max
+v = read()
+live = v[:, 19] > 0
+w = v[live] / v[live][:, 19:20]            # per wave, per launch
+waves = int(live.sum())
+names = {0: "start-up (header, tables -> LDS, barrier)", 1: "wait for the tile's loads", 14: "staging registers -> LDS", 2: "issue of the next tile's loads",
+         3: "class-level scan (ASCII tile)", 4: "speculative forward walk + results", 5: "gather of queued rows (global -> LDS)", 6: "byte-level scan in place",
+         7: "byte-level scan of gathered rows", 8: "in-LDS decode", 9: "scan of decoded rows", 10: "general row procedure", 11: "end (compaction flush, loop exit)"}
+order = [0, 1, 14, 2, 3, 4, 6, 5, 7, 8, 9, 10, 11]
+life = w[:, 18]
+tiles, gath = w[:, 12].mean(), w[:, 13].mean()
+tick_us = us / life.max()
+print("%s %s: path %d, %.2f us per launch (HIP events over %d launches; the product's kernel: %s us), %d waves, %.1f tiles and %.2f gathered passes per wave" %
+      (cfg, "spans" if spans else "flags only", prog.last_path(), us, REPS, os.environ.get("FXAMD_REF_US", "?"), waves, tiles, gath))
+print("wave lifetime in ticks: mean %.0f, median %.0f, 5 %% %.0f, 95 %% %.0f, longest %.0f -> 1 tick = %.5f us if the longest wave spans the launch (%.2f GHz)" %
+      (life.mean(), np.median(life), np.percentile(life, 5), np.percentile(life, 95), life.max(), tick_us, 1e-3 / tick_us))
+tot = sum(w[:, i].mean() for i in order)
 if md:
-    print("\n| phase | share of the waves' lifetime | ticks per wave | us per wave (at %.4f us per tick) |" % tick_us)
-    print("|---|---|---|---|")
-for nm, x in zip(names, v[:12]):
-    per_wave = x / (REPS * waves)
+    print("\n| phase | share of a wave's lifetime | ticks per wave | us per wave | per tile, us |")
+    print("|---|---|---|---|---|")
+for i in order:
+    x = w[:, i].mean()
+    if x == 0:
+        continue
     if md:
-        print("| %s | %.1f %% | %.0f | %.2f |" % (nm, 100.0 * x / tot, per_wave, per_wave * tick_us))
+        print("| %s | %.1f %% | %.0f | %.2f | %.3f |" % (names[i], 100.0 * x / tot, x, x * tick_us, x * tick_us / max(tiles, 1.0)))
     else:
-        print("  %-44s %6.2f %%   %8.0f ticks per wave  %7.2f us" % (nm, 100.0 * x / tot, per_wave, per_wave * tick_us))
-print("average wave lifetime %.2f us of the launch's %.2f us (%.0f %%): the rest is waves that start late or end early (ramp-up, drain, the longest tail)" %
-      (avg_life * tick_us, us, 100.0 * avg_life * tick_us / us))
-ref = os.environ.get("FXAMD_REF_US")
-if ref:
-    print("un-stamped library, same call: %s us" % ref)
+        print("  %-44s %6.2f %%   %8.0f ticks per wave  %7.2f us  %6.3f us per tile" % (names[i], 100.0 * x / tot, x, x * tick_us, x * tick_us / max(tiles, 1.0)))
+print("sum of the phases %.2f us; mean wave lifetime %.2f us = %.0f %% of the launch's %.2f us (the rest: dispatch of the blocks, waves that end before the longest one)" %
+      (tot * tick_us, life.mean() * tick_us, 100.0 * life.mean() * tick_us / us, us))
