@@ -1567,7 +1567,7 @@ hipError_t launch_one(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fas
    constexpr bool RAG_OK = (CH & (CH - 1)) == 0;   // ragged rows run on the power-of-two instantiations (fxamd.hip: one_chunks)
    if (ragged && !RAG_OK) return hipErrorInvalidValue;
    if (is_match) {   // `.match.`: one verdict per row, no span
-      if constexpr (BSCH == 3) return hipErrorInvalidValue;   // (never dispatched: FXP_F_BYTE_A8 is a search program's table)
+      if constexpr (BSCH == 3 || GEN) return hipErrorInvalidValue;   // (never dispatched: FXP_F_BYTE_A8 is a search program's table; `.match.` programs that cannot decode take the multi-pass pipeline)
       else {
          if constexpr (RAG_OK)
             if (ragged) return go(&fx_search_one<CH, false, SCH, BSCH, true, GEN, false, true>);
@@ -1622,5 +1622,5 @@ hipError_t launch_one_marked(const uint8_t* rows, int64_t n, const uint8_t* d_bl
 #define FX_ONE_COMBOS_G(X, CH, G) X(CH, 0, 0, G) X(CH, 1, 0, G) X(CH, 2, 0, G) X(CH, 0, 1, G) X(CH, 0, 2, G) X(CH, 0, 3, G) X(CH, 1, 1, G) X(CH, 1, 2, G) X(CH, 2, 1, G) X(CH, 2, 2, G)
 #define FX_ONE_COMBOS(X, CH) FX_ONE_COMBOS_G(X, CH, false) FX_ONE_COMBOS_G(X, CH, true)
 #define FX_ONE_ALL(X) \
-   FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 3) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 6) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)
+   FX_ONE_COMBOS(X, 1) FX_ONE_COMBOS(X, 2) FX_ONE_COMBOS(X, 4) FX_ONE_COMBOS(X, 8) FX_ONE_COMBOS(X, 12) FX_ONE_COMBOS(X, 16)
 #define FX_ONE_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t, bool)

@@ -45,9 +45,11 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 #define FX_PREFETCH_DEPTH 1   // tiles of global loads in flight per wave in the first pass
 #endif
 #ifndef FX_DEFER_PREFETCH
-#define FX_DEFER_PREFETCH 1   // match compaction: the lane that owns a queue slot loads the slot's three 8-byte groups from global memory WHEN the row is queued (they are in
-                              // L2: the tile has just been loaded) and keeps them in six registers -- the flush at the wave's end then waits for no memory (config 2: the flush
-                              // was 2 us of a wave's 17, `profiles/r06_cfg2_phases.md`, most of it one round trip with nothing to overlap)
+#define FX_DEFER_PREFETCH 0   // (1: match compaction with the lane that owns a queue slot loading the slot's three 8-byte groups from global memory WHEN the row is queued --
+                              //  they are in L2: the tile has just been loaded -- into six registers, so that the flush at the wave's end waits for no memory: the flush is 2 us
+                              //  of a wave's 17 on config 2, profiles/r06_cfg2_stamps.md.  Measured and NOT kept: 18.2-18.5 -> 19.1-19.3 us per step, four interleaved pairs,
+                              //  gpurun call r06_c5 -- the kernel is VALU-bound at four waves per SIMD, and the loads' row-end handling executed once per tile instead of once
+                              //  per wave costs more issue time than the one round trip it hides)
 #endif
 #ifndef FX_DEFER_FWD
 #define FX_DEFER_FWD 1   // match compaction in fx_search_one (fx_one.hpp): rows of SPARSE tiles that need the exact start + the forward
@@ -2181,7 +2183,7 @@ hipError_t launch_match(const uint8_t* rows, int64_t n, const uint8_t* d_blob, F
 #define FX_TILE_COMBOS(X, CH) \
    X(CH, 0, 0) X(CH, 0, 1) X(CH, 0, 2) X(CH, 1, 0) X(CH, 1, 1) X(CH, 1, 2) X(CH, 4, 0) X(CH, 4, 1) X(CH, 4, 2) X(CH, 2, 1) X(CH, 2, 2) X(CH, 3, 1) X(CH, 3, 2)
 #define FX_TILE_ALL(X) \
-   FX_TILE_COMBOS(X, 1) FX_TILE_COMBOS(X, 2) FX_TILE_COMBOS(X, 3) FX_TILE_COMBOS(X, 4) FX_TILE_COMBOS(X, 6) FX_TILE_COMBOS(X, 8) FX_TILE_COMBOS(X, 12) FX_TILE_COMBOS(X, 16)
+   FX_TILE_COMBOS(X, 1) FX_TILE_COMBOS(X, 2) FX_TILE_COMBOS(X, 4) FX_TILE_COMBOS(X, 8) FX_TILE_COMBOS(X, 12) FX_TILE_COMBOS(X, 16)
 #define FX_TILE_SIG_FAST \
    (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t*, int64_t)
 #define FX_TILE_SIG_MATCH (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, uint32_t*, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t*, int64_t)

@@ -1,5 +1,5 @@
 // Explicit instantiation of the tile-kernel launchers (and with them the kernels) for ONE chunk count: compiled per
-// -DFX_INST_CH=<1|2|3|4|6|8|12|16> and, so that the few hundred variants build in parallel on all cores, per -DFX_INST_PART=<1|2|3>:
+// -DFX_INST_CH=<1|2|4|8|12|16> and, so that the few hundred variants build in parallel on all cores, per -DFX_INST_PART=<1|2|3>:
 // 1 = the multi-pass kernels (fx_search_fast / fx_match_fast), 2 = the one-launch kernel for programs whose tables decode, 3 = the
 // one-launch kernel with the general row procedure for queued rows (GEN), the many-pattern kernel and the gated follow-up
 // (forgex_amd/csrc/Makefile).

@@ -531,7 +531,7 @@ static int grow_worklist(DevScratch* s, int64_t rows) {
 
 // chunk count the tile kernels are instantiated for that covers row_len (0 = none)
 static int tile_chunks(int64_t row_len) {
-   static const int inst[] = {1, 2, 3, 4, 6, 8, 12, 16};
+   static const int inst[] = {1, 2, 4, 8, 12, 16};   // (round 6: 3 and 6 retired -- rows of 48 / 96 bytes run as ragged rows of the 4- / 8-chunk kernels; 12 stays: config 4)
    for (int c : inst)
       if (row_len <= 16 * c) return c;
    return 0;
@@ -607,9 +607,7 @@ static hipError_t launch_match_any(const FxpHeader& h, const uint8_t* d_blob, co
    switch (((po.half && SCH == 1 && MODE == 0) || long8) ? 8 : chunks_of(row_len)) {
       case 1: return launch_match<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_match<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 3: return launch_match<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 4: return launch_match<4, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 6: return launch_match<6, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 8: return launch_match<8, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 12: return launch_match<12, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       default: return launch_match<16, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -687,9 +685,7 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
    switch ((po.half || long8) ? (row_len == 128 ? 4 : 8) : chunks_of(row_len)) {
       case 1: return launch_fast<1, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 2: return launch_fast<2, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 3: return launch_fast<3, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 4: return launch_fast<4, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
-      case 6: return launch_fast<6, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 8: return launch_fast<8, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       case 12: return launch_fast<12, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
       default: return launch_fast<16, MODE, SCH>(d_rows, n, d_blob, fp, d_flags, d_from, d_to, n_deferred, class_map_bytes, chain_bytes, (uint32_t)row_len, st, po.worklist, po.grid_tiles);
@@ -746,9 +742,7 @@ static hipError_t launch_one_ch(const FxpHeader& h, const uint8_t* d_blob, const
    switch (one_chunks(row_len)) {
       case 1: return launch_one<1, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       case 2: return launch_one<2, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
-      case 3: return launch_one<3, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       case 4: return launch_one<4, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
-      case 6: return launch_one<6, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       case 8: return launch_one<8, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       case 12: return launch_one<12, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
       default: return launch_one<16, SCH, BSCH, GEN>(d_rows, n, d_blob, fp, fpb, d_flags, d_from, d_to, class_map_bytes, table_bytes, Lr, st, out_mode, is_match);
@@ -848,8 +842,8 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       const bool half0 = sc0 == 0 && h.mode == FXP_MODE_SEARCH_ENGINE && spans_p && row_len == 256 && half_rows(h, sc0, row_len) && scheme_decodes_utf8(h, sc0) &&
                          first_pass == FX_FP_OWN && !fx_env().no_pack_first;
       const bool one = sc0 >= 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_MATCH_ENGINE) && !(h.flags & FXP_F_RAW_BYTES) && !long_row(row_len) &&
-                       (h.mode == FXP_MODE_MATCH_ENGINE ? !match_half_rows(h, sc0, row_len) : (!half_rows(h, sc0, row_len) || half0)) &&
-                       !fx_env().multipass;
+                       (h.mode == FXP_MODE_MATCH_ENGINE ? (!match_half_rows(h, sc0, row_len) && scheme_decodes_utf8(h, sc0)) : (!half_rows(h, sc0, row_len) || half0)) &&
+                       !fx_env().multipass;   // (`.match.` programs that cannot decode: the multi-pass pipeline, see gen_match below)
       if (!one) return FX_NOT_PACKED;
       // (FXAMD_NO_PACK_FIRST=1, test / A-B hook: 256-byte rows unpacked + fx_pack, the span kernel's rows packed by the one-launch kernel -- as before round 5)
    }
@@ -934,7 +928,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
           (scheme_decodes_utf8(h, scheme) || bytes_ok(h, d_rows, row_len))) {
          span_first = !capturing();
       }
-      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !span_first && !fx_env().multipass;
+      // (`.match.` programs whose class-level tables cannot decode UTF-8 -- more than 126 symbol classes -- take the multi-pass pipeline: first pass + the general row
+      //  procedure over a worklist; their one-launch instantiations, GEN x MATCH, were 117 kernels nobody's tables asked for: retired in round 6)
+      const bool gen_match = is_match && !scheme_decodes_utf8(h, scheme);
+      const bool one_launch = first_pass == FX_FP_OWN && !tiny && !(h.flags & FXP_F_RAW_BYTES) && !as_long && !half && !span && !span_first && !fx_env().multipass && !gen_match;
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
@@ -1799,9 +1796,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       switch (ch) {
          case 1: e = launch_multi<1>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          case 2: e = launch_multi<2>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
-         case 3: e = launch_multi<3>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          case 4: e = launch_multi<4>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
-         case 6: e = launch_multi<6>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          case 8: e = launch_multi<8>(d_rows, n, a, d_flags, d_from, d_to, (uint32_t)row_len, st); break;
          default: e = hipErrorInvalidValue; break;   // (never dispatched: the shared pass takes rows of up to 128 bytes)
       }

@@ -1165,7 +1165,8 @@ def test_long_rows_last_bytes_of_a_tile(fx):
 
 
 @pytest.mark.parametrize("hook", ["", "FXAMD_MULTIPASS", "FXAMD_NO_A8", "FXAMD_NO_BYTE_DFA", "FXAMD_NO_W16", "FXAMD_NO_HALF", "FXAMD_FORCE_GENERAL",
-                                  "FXAMD_NO_TINY", "FXAMD_NO_SPEC", "FXAMD_HALF_SCH=1", "FXAMD_HALF_SCH=7", "FXAMD_NO_ADAPT", "FXAMD_NO_SPAN", "FXAMD_SPAN_LENS=31"])
+                                  "FXAMD_NO_TINY", "FXAMD_NO_SPEC", "FXAMD_HALF_SCH=1", "FXAMD_HALF_SCH=7", "FXAMD_NO_ADAPT", "FXAMD_NO_SPAN", "FXAMD_SPAN_LENS=31",
+                                  "PACKED", "PACKED+FXAMD_NO_PACK_FIRST", "PACKED+FXAMD_NO_SPAN"])
 def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
     """tests/golden/config_rows.tsv: the REAL reference's flag / from / to (recorded in the container by
     tests/golden/make_config_goldens.py through oracle/_ref/ref_driver) on 2000-6144 rows of each BASELINE config (first and last
@@ -1183,15 +1184,34 @@ def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
     #  default set, the adaptive first pass off, the span kernel off / also for programs with byte-level tables -- and the fixture's
     #  round-5 sections: rows of 2..32 bytes, chain / nibble tables over 256- and 128-byte rows, a chain program over 400- and 1024-byte
     #  rows, speculative-pass rows)
+    # (round 6, VERDICT r05: the PACKED entry -- fxamd_match_batch_device_packed, what a multi-GPU host gathers or has written peer-direct -- against the
+    #  real reference's answers too: images straight from the first passes, through fx_pack, and from the one-launch kernel; unpacked on the device)
+    packed = hook.startswith("PACKED")
+    if packed:
+        hook = hook[7:] if "+" in hook else ""
     if hook:
         monkeypatch.setenv(hook.split("=")[0], hook.split("=")[1] if "=" in hook else "1")
     fix, crcs = cr.load_fixture(os.path.join(golden.GOLDEN, "config_rows.tsv"))
     n_rows = 0
     paths = {}
+
+    def run(pat, op_, rows, spans):
+        if not packed:
+            return _device_run(fx, pat, op_, rows, spans=spans)
+        import torch
+        prog = fx.Program(pat, op_)
+        d = torch.from_numpy(np.ascontiguousarray(rows)).cuda()
+        sp = spans and op_ == fx.OP_SEARCH
+        img = prog.match_device_packed(d, spans=sp)
+        f, a, b = fx.unpack_results(img, rows.shape[0], rows.shape[1], sp)
+        torch.cuda.synchronize()
+        z = np.zeros(rows.shape[0], dtype=np.int32)
+        return prog, f.cpu().numpy(), (a.cpu().numpy() if sp else z), (b.cpu().numpy() if sp else z)
+
     for name, op, pat, L, n, getter in cr.all_sections():
         rows = getter()
         assert cr.crc_of(rows) == crcs[name], name
-        prog, f, a, b = _device_run(fx, pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH, rows, spans=True)
+        prog, f, a, b = run(pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH, rows, True)
         paths[name] = prog.last_path()   # (now: the flags-only call below runs on the same cached handle)
         want = fix[name]
         bad = np.flatnonzero(f.astype(np.int64) != want[:, 0])
@@ -1200,11 +1220,14 @@ def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
             bad = np.flatnonzero((a.astype(np.int64) != want[:, 1]) | (b.astype(np.int64) != want[:, 2]))
             assert bad.size == 0, (name, int(bad[0]), int(a[bad[0]]), int(b[bad[0]]), want[bad[0]].tolist(), bytes(rows[bad[0]]))
             # flags-only entry: the same verdicts
-            _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+            _, f2, _, _ = run(pat, fx.OP_SEARCH, rows, False)
             assert np.array_equal(f2.astype(np.int64), want[:, 0]), name
         n_rows += n
     # the BASELINE configs run on the tile kernels (one-launch kernel / half-row pipeline), not on the general kernel
-    if not hook:
+    if packed:
+        if not hook:
+            assert paths["cfg3"] == 16 and paths["cfg5"] == 18, paths   # (packed results straight from the first passes)
+    elif not hook:
         assert paths["cfg3"] == 16 and paths["cfg2"] in (9, 10, 11, 12, 13, 14) and paths["cfg4"] in (10, 11) and paths["cfg5"] == 18, paths
         assert paths["tiny_M0_L8"] == 17 and paths["tab_p0_L256"] in (5, 6, 8) and paths["long_chain_L1024"] == 7, paths
     elif hook == "FXAMD_FORCE_GENERAL":
@@ -1219,7 +1242,7 @@ def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
         groups.setdefault((pat, op, len(row)), []).append(i)
     for (pat, op, L), idx in groups.items():
         rows = np.frombuffer(b"".join(cases[i][2] for i in idx), dtype=np.uint8).reshape(len(idx), L)
-        _, f, a, b = _device_run(fx, pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH, rows, spans=True)
+        _, f, a, b = run(pat, fx.OP_MATCH if op == "M" else fx.OP_SEARCH, rows, True)
         want = fix["probes"][idx]
         assert np.array_equal(f.astype(np.int64), want[:, 0]), (pat, op, L, f.tolist(), want[:, 0].tolist())
         if op == "R":

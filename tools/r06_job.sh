@@ -49,6 +49,17 @@ print('gathered_shards', d['parity'].get('gathered_shards'), 'rccl_ranks', d['rc
         python bench.py --config $cfg --no-cpu-baseline --no-extras > $OUT/abc_${cfg}_new_$rep.json 2> $OUT/abc_${cfg}_new_$rep.err; line $OUT/abc_${cfg}_new_$rep.json "$cfg default library   $rep"
         env FXAMD_LIB=$libp python bench.py --config $cfg --no-cpu-baseline --no-extras > $OUT/abc_${cfg}_old_$rep.json 2> $OUT/abc_${cfg}_old_$rep.err; line $OUT/abc_${cfg}_old_$rep.json "$cfg $libp $rep"
       done ;;
+    rounds:*) IFS=: read -r _ cfg nrows list <<< "$step"   # rounds:<cfg>:<rows>:<r1,r2,...>  grid rounds (FXAMD_HALF_ROUNDS; 0 = the built-in rule) at a given batch size, twice each, interleaved
+      for rep in 1 2; do for r in $(echo $list | tr ',' ' '); do
+        if [ $r = 0 ]; then python bench.py --config $cfg --rows $nrows --no-cpu-baseline --no-extras --no-parity > $OUT/rounds_${cfg}_${nrows}_${r}_$rep.json 2> $OUT/rounds_${cfg}_${nrows}_${r}_$rep.err
+        else env FXAMD_HALF_ROUNDS=$r python bench.py --config $cfg --rows $nrows --no-cpu-baseline --no-extras --no-parity > $OUT/rounds_${cfg}_${nrows}_${r}_$rep.json 2> $OUT/rounds_${cfg}_${nrows}_${r}_$rep.err; fi
+        line $OUT/rounds_${cfg}_${nrows}_${r}_$rep.json "$cfg rows $nrows rounds $r rep $rep"
+      done; done ;;
+    abe:*) IFS=: read -r _ cfg envv reps <<< "$step"; reps=${reps:-3}; case $envv in *=*) ;; *) envv="$envv=1" ;; esac   # bench.py config with / without an environment setting, interleaved
+      for rep in $(seq 1 $reps); do
+        python bench.py --config $cfg --no-cpu-baseline --no-extras --no-parity > $OUT/abe_${cfg}_on_$rep.json 2> $OUT/abe_${cfg}_on_$rep.err; line $OUT/abe_${cfg}_on_$rep.json "$cfg default      $rep"
+        env $envv python bench.py --config $cfg --no-cpu-baseline --no-extras --no-parity > $OUT/abe_${cfg}_off_$rep.json 2> $OUT/abe_${cfg}_off_$rep.err; line $OUT/abe_${cfg}_off_$rep.json "$cfg $envv $rep"
+      done ;;
     abs:*) IFS=: read -r _ sh envv reps <<< "$step"; reps=${reps:-2}; case $envv in *=*) ;; *) envv="$envv=1" ;; esac
       for rep in $(seq 1 $reps); do
         for arm in on off; do
