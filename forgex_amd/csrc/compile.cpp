@@ -1224,7 +1224,22 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       prefix_necessary = ok;
    }
    if (prefix_necessary) h.flags |= FXP_F_PREFIX_NECESSARY;
-   if (brute_equiv && prefilter) brute_equiv = prefix_necessary && (border_free(lit.prefix) || overlap_sink);
+   // Round 6 (0.6 % of generated patterns on the general kernel, a 20-30 x cliff): where that proof fails -- the prefix is not a necessary
+   // beginning (`(}[abc]){2}\d*c{2,}`), or it has a border and no overlap state (`(\t{3}[a-z]){2}`) -- the tile tables still run, and the KERNEL decides per row
+   // whether brute force and the candidate list agree.  The reference tries the candidates -- the non-overlapping occurrences of the prefix
+   // (utility_m.f90:94-116) -- in order and takes the first with a non-empty match (api_internal_m.F90:108-164); brute force takes the leftmost start s of
+   // ANY match.  No candidate before s matches (s is the leftmost start of all), so when s itself is a candidate the two agree: same start, same longest end.
+   // s is a candidate when the prefix stands at s and no earlier occurrence overlaps it (a selected one would have swallowed it; an unselected one only
+   // makes the test conservative).  Every other row with a hit -- s at the leading NUL, no prefix at s, an overlapping occurrence before s -- goes to the
+   // general row procedure inside the same launch, which follows the driver to the letter (it also knows the fallback to brute force when the prefix occurs
+   // nowhere).  A row without a hit has no match for the reference either: whatever it finds is a match brute force would have found.  (Suffix literal: only
+   // with the suffix proof above -- `brute_equiv` is already false otherwise.)
+   bool prefix_check = false;
+   if (brute_equiv && prefilter && !(prefix_necessary && (border_free(lit.prefix) || overlap_sink))) {
+      prefix_check = lit.prefix.find('\0') == std::string::npos && lit.prefix.size() <= 32;
+      brute_equiv = prefix_check;
+   }
+   if (prefix_check) h.flags |= FXP_F_PREFIX_CHECK;
    if (overlap_sink) {
       h.flags |= FXP_F_OVERLAP_SINK;
       h.R_inv = static_cast<uint32_t>(R_inv_state);
@@ -1384,7 +1399,8 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    // engine, which follows the candidate-list driver to the letter).
    {
       std::vector<uint16_t> bcm(256, 0), btr, bta;
-      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || (brute_equiv && !overlap_sink));
+      // (FXP_F_PREFIX_CHECK programs: no byte-level tables -- the per-row check compares raw bytes of pure-ASCII rows; rows with a byte >= 0x80 go to the general procedure)
+      const bool want = (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK)) != 0 && (is_match || (brute_equiv && !overlap_sink && !prefix_check));
       std::vector<uint8_t> bwa, bwr, b8a;
       if (want) {
          Sig full;
@@ -1627,7 +1643,8 @@ int validate_blob(const uint8_t* b, size_t size) {
    auto u16 = [&](uint32_t off, uint64_t i) { uint16_t v; std::memcpy(&v, b + off + 2 * i, 2); return v; };
    const uint32_t known = FXP_F_INIT_ACCEPTING | FXP_F_PREFILTER | FXP_F_HAS_SUFFIX | FXP_F_FAST_OK | FXP_F_HAS_R | FXP_F_MATCH_LITERAL |
                           FXP_F_FAST_UTF8 | FXP_F_NFA_SIM | FXP_F_CHAIN_OK | FXP_F_CHAIN_UTF8 | FXP_F_RAW_BYTES | FXP_F_RAGGED_OK | FXP_F_BYTE_DFA |
-                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8 | FXP_F_SPEC_FWD | FXP_F_NEEDS_NONASCII;
+                          FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8 | FXP_F_SPEC_FWD | FXP_F_NEEDS_NONASCII |
+                          FXP_F_PREFIX_CHECK;
    if (h.flags & ~known) return 5;
    // chain-format table: rows of (ncls + 3) uint16, entries = row offsets of the same table; the 256-entry map holds 2 * column
    auto chain_ok = [&](uint32_t off_cls, uint32_t off_T, uint32_t T_bytes, uint32_t ncls, uint32_t row_bytes, bool final_col) {
@@ -1702,6 +1719,8 @@ int validate_blob(const uint8_t* b, size_t size) {
    } else if (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK | FXP_F_BYTE_DFA | FXP_F_OVERLAP_SINK)) {
       if (h.mode != FXP_MODE_MATCH_ENGINE) return 46;   // the tile kernels' search needs R
    }
+   if ((h.flags & FXP_F_PREFIX_CHECK) && (!(h.flags & FXP_F_PREFILTER) || h.mode != FXP_MODE_SEARCH_ENGINE || h.len_prefix < 1u || h.len_prefix > 32u ||
+                                          (h.flags & (FXP_F_BYTE_DFA | FXP_F_FAST_UTF8 | FXP_F_CHAIN_UTF8 | FXP_F_W16_UTF8)))) return 78;
    if ((h.flags & FXP_F_FAST_OK) && (!inside(h.off_fastA, 2048) || !inside(h.off_fastR, 2048))) return 50;
    if ((h.flags & FXP_F_FAST_UTF8) && (!(h.flags & FXP_F_FAST_OK) || nc > 126)) return 51;
    if (h.flags & FXP_F_CHAIN_OK) {

@@ -63,6 +63,8 @@ struct FxScanCtx {
    bool whole, raw;
    uint32_t pre_na;
    const FxTail* tl = nullptr;   // TAIL scans (ragged rows of fx_search_one, fx_tile.hpp "Ragged rows, round 4"): L = Lr, the cells are walked as 16*CH bytes
+   const uint8_t* pfx = nullptr;   // FXP_F_PREFIX_CHECK programs (round 6): the prefix literal (global memory, wave-uniform reads) ...
+   uint32_t pfx_len = 0;           // ... and its length; 0 = no per-row check (fxrow::prefix_start_ok, row_engine.hpp)
 };
 // Match compaction (DEFERQ): the exact start and the forward pass are per-ROW work that only rows with a hit need, but a
 // wave pays for them per TILE -- at full price when a few lanes in 64 have a hit (config 2: one row in ten matches).  Unless the tile
@@ -265,7 +267,7 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       // ---- match compaction: rows with a start inside the text go to the wave's queue unless the tile is dense in them ----
       bool queued = false;
       if constexpr (DEFERQ && SPANS && !DECODED) {
-         const bool want = hit && !s_nul && !except && row_ok && P.lit_len == 0 && L >= 16u;
+         const bool want = hit && !s_nul && !except && row_ok && P.lit_len == 0 && L >= 16u && c.pfx_len == 0u;   // (prefix-check programs: the exact start decides whether the row is the tables' at all)
          const uint64_t qm = __builtin_amdgcn_ballot_w64(want);
          const uint32_t cnt = (uint32_t)__builtin_popcountll(qm);
          if (cnt != 0u && cnt <= (uint32_t)FX_DEFER_DENSE) {
@@ -306,7 +308,8 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
       uint32_t s = hit ? 2u : 0u;          // wrapped start index (1 = leading NUL, j+2 for text byte j), 0 = none; 2 stands for "inside the text"
       // exact byte of the leftmost hit: re-walk the selected group -- only spans need it (a verdict is "some start"), and only rows
       // that were not queued
-      if (SPANS && __builtin_amdgcn_ballot_w64(hit && !queued && !s_nul && !except) != 0) {
+      const bool pfx_on = ROW_EXC && !BYTES && !DECODED && c.pfx_len != 0u;   // (wave-uniform)
+      if ((SPANS || pfx_on) && __builtin_amdgcn_ballot_w64(hit && !queued && !s_nul && !except) != 0) {
          const uint32_t g = hit ? gsel : 0u;
          const uint2 rw = *reinterpret_cast<const uint2*>(tb + (tile_cell(lane, g >> 1) << 4) + ((g & 1u) << 3));
          F f[8];
@@ -327,6 +330,20 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          s = hit ? g * 8u + 2u + loc : 0u;
       }
       s = s_nul ? 1u : s;
+      if constexpr (ROW_EXC && !BYTES && !DECODED) {
+         // FXP_F_PREFIX_CHECK (compile.cpp): the tables searched by brute force; the reference searches its candidate list.  The two agree on this row when the
+         // start found is a candidate -- the prefix literal stands there, no earlier occurrence overlaps it; any other row with a hit is the general row
+         // procedure's (queued like a row in the overlap state).  Rare programs (0.6 % of generated patterns), byte reads from the tile: not a hot path.
+         if (pfx_on) {
+            bool ok = true;
+            if (s != 0u && !except && row_ok) {
+               const FxTileRow tr{tb, lane};
+               const uint8_t* const pp = c.pfx;
+               ok = fxrow::prefix_start_ok([&](int k) -> uint32_t { return pp[k]; }, (int)c.pfx_len, tr, (int)L, (int)s);
+            }
+            except = except || !ok;
+         }
+      }
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
       uint32_t cur = (s != 0 && !queued && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
       uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
@@ -1109,7 +1126,8 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
    };
 
    // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
-   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u, &tl};
+   const bool pfx_chk = GEN && !MATCH && (h->flags & FXP_F_PREFIX_CHECK) != 0u;
+   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u, &tl, pfx_chk ? prog + h->off_prefix : nullptr, pfx_chk ? h->len_prefix : 0u};
    // tables of one family (class-level / byte-level) in the scheme `S_`, handed to `fn(tabR, tabA, TRp, TAp, P)`
    auto with_tables = [&](auto cfg, auto&& fn) {
       using C = decltype(cfg);

@@ -86,6 +86,13 @@ typedef uint32_t fx_u32x4 __attribute__((ext_vector_type(4)));
 // pure-ASCII tiles included (with the class-level tables); only the cost does, until the count-down ends and a first pass looks again.
 #define FX_ADAPT_CALLS 8u
 #endif
+#ifndef FX_LONG_NT_LAST
+#define FX_LONG_NT_LAST 1   // (round 6) a long row's FIRST segment -- the last one its backward pass loads -- takes the `nt` policy whatever the row length: its lines are not
+                            // needed again (the lines it shares with the segment to its right were fetched by that segment's pass), so they should not push the
+                            // still-to-be-shared lines of other waves out of L2.  Interleaved against a build without it (gpurun call r06_c7): 1024-byte rows
+                            // 0.5020 / 0.5013 -> 0.4884 / 0.4896 ms; 400-byte rows unchanged (0.688-0.704 both ways: two segments, and what bounds them is not the
+                            // allocation policy of the second one)
+#endif
 #ifndef FX_LONG_NT_MIN
 // Rows longer than 256 bytes, search kernels: the segment loads take the nt policy only from this row length on.  Below it the lines stay
 // in L2 for the re-walk and the forward pass (which read the row from global memory once its segments have left the tile) and for the
@@ -835,20 +842,30 @@ __device__ __forceinline__ void fx_finish_from_global(const TabT* __restrict__ t
 }
 
 // ---- optional phase stamps (debug builds only: make stamp) --------------------------------------------------------------
-// -DFX_STAMP: lane 0 of every wave accumulates s_memtime deltas per phase of fx_search_fast and adds them to fx_stamp_acc[].
+// -DFX_STAMP (`make stamp-fast STAMP_OBJ=<chunks>_1`, tools/stamp_one.py --fast): every wave accumulates s_memtime deltas per phase of fx_search_fast and ADDS them to
+// its own row of fx_stamp_buf at its end (plain stores: per-wave atomics to one set of words measured themselves -- fx_one.hpp, ONE_STAMP).
 #ifdef FX_STAMP
-__device__ unsigned long long fx_stamp_acc[16];
-#define STAMP_DECL unsigned long long _st_t = __builtin_amdgcn_s_memtime(), _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FX_STAMP_MAX_WAVES 65536
+#define FX_STAMP_SLOTS 12
+static __device__ unsigned long long fx_stamp_buf[FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS];   // per wave: 0..7 phase ticks, 8 tiles, 9 -, 10 lifetime, 11 launches seen
+#define STAMP_DECL const unsigned long long _st_t0 = __builtin_amdgcn_s_memtime(); unsigned long long _st_t = _st_t0, _st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(i)                                                     \
    do {                                                              \
       const unsigned long long _n = __builtin_amdgcn_s_memtime();    \
       _st_acc[i] += _n - _st_t;                                      \
       _st_t = _n;                                                    \
    } while (0)
-#define STAMP_FLUSH                                                                      \
-   do {                                                                                  \
-      if (lane == 0)                                                                     \
-         for (int _i = 0; _i < 8; ++_i) atomicAdd(&fx_stamp_acc[_i], _st_acc[_i]);       \
+#define STAMP_FLUSH                                                                                                   \
+   do {                                                                                                               \
+      const unsigned long long _life = __builtin_amdgcn_s_memtime() - _st_t0;                                         \
+      const int64_t _wg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);                                               \
+      if (lane == 0 && _wg < FX_STAMP_MAX_WAVES) {                                                                    \
+         unsigned long long* _row = fx_stamp_buf + _wg * FX_STAMP_SLOTS;                                              \
+         for (int _i = 0; _i < 8; ++_i) _row[_i] += _st_acc[_i];                                                      \
+         _row[8] += n_seen;                                                                                           \
+         _row[10] += _life;                                                                                           \
+         _row[11] += 1ull;                                                                                            \
+      }                                                                                                               \
    } while (0)
 #else
 #define STAMP_DECL
@@ -880,7 +897,7 @@ __device__ unsigned long long fx_stamp_acc[16];
 // segment sg of a long row: bytes [SEGB sg, SEGB sg + SEGB) of every row (SEGB = 16*CH); the LAST segment is shorter when Lr % SEGB != 0 and sits
 // left-aligned in the tile: its chunks behind the row end repeat the last one (loaded, never walked)
 #define PREFETCH_SEG(st, tn, sg, en) \
-   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH == 8 || (CH == 16 && Lr >= FX_LONG_NT_MIN))
+   load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH == 8 || (CH == 16 && (Lr >= FX_LONG_NT_MIN || (FX_LONG_NT_LAST != 0 && (sg) == 0u))))
 #define PREFETCH_SEG_FWD(st, tn, sg, en) \
    load_tile_seg<CH, (CH == 16 || NOHALF)>(st, rows, (tn) << 6, n, lane, Lr, (sg) * SEGB, 0u, (((sg) + 1u) * SEGB > Lr) ? (((Lr % SEGB) + 15u) >> 4) - 1u : (uint32_t)CH - 1u, (en), (((sg) + 1u) * SEGB > Lr), CH != 4)
 

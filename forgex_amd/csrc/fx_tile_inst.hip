@@ -51,3 +51,15 @@ extern "C" __attribute__((visibility("default"))) int fxamd_debug_stamps_one(uns
    return 0;
 }
 #endif
+
+#if defined(FX_STAMP) && FX_INST_PART == 1
+// debug builds only (`make stamp-fast`): read and clear the per-wave phase sums of this object's fx_search_fast kernels
+extern "C" __attribute__((visibility("default"))) int fxamd_debug_stamps_fast(unsigned long long* out, long long max_words) {
+   const size_t bytes = sizeof(unsigned long long) * (size_t)(max_words < (long long)(FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS) ? max_words : FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS);
+   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_stamp_buf), bytes) != hipSuccess) return 1;
+   void* p = nullptr;
+   if (hipGetSymbolAddress(&p, HIP_SYMBOL(fx_stamp_buf)) != hipSuccess) return 1;
+   if (hipMemset(p, 0, sizeof(unsigned long long) * FX_STAMP_MAX_WAVES * FX_STAMP_SLOTS) != hipSuccess) return 1;
+   return 0;
+}
+#endif

@@ -570,7 +570,7 @@ struct PassOpts {
 //  default cache policy on the loads so that the second half meets its line in L2: 0.45 ms against 0.366 ms, gpurun call r04_c26)
 static bool half_rows(const FxpHeader& h, int scheme, int64_t row_len) {
    // (FXAMD_NO_HALF: test / experiment hook -- these rows on the one-launch kernel; FXAMD_HALF_SCH: bit s = table scheme s takes half rows)
-   if (fx_env().no_half) return false;
+   if (fx_env().no_half || (h.flags & FXP_F_PREFIX_CHECK)) return false;
    // 128-byte rows on the chain tables: 64-byte halves (bit 4 of the hook).  The chain scheme's dependent LDS read per byte is latency-bound:
    // four waves per SIMD on a 4 KB tile against the one-launch kernel's three (and class-level tables on pure-ASCII tiles instead of
    // byte-level ones everywhere): the 17-state pattern over config 5's shard 0.743 -> 0.496 ms (gpurun call r04_c47).  With the v_perm
@@ -629,6 +629,9 @@ static bool row_len_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_le
 static int fast_scheme(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len) {
    if (fx_env().force_general) return -1;   // test hook: the general kernel (one lane per row) for everything
    if ((h.mode != FXP_MODE_SEARCH_ENGINE && h.mode != FXP_MODE_MATCH_ENGINE && h.mode != FXP_MODE_SEARCH_LITERAL) || !row_len_ok(h, d_rows, row_len)) return -1;
+   // FXP_F_PREFIX_CHECK (round 6): the per-row check of the start lives in the one-launch kernel's scan (fx_scan_tile, GEN instantiations): rows of up to 256 bytes
+   // there; longer rows and the multi-pass test hook keep the general kernel
+   if ((h.flags & FXP_F_PREFIX_CHECK) && (long_row(row_len) || fx_env().multipass)) return -1;
    if (h.flags & FXP_F_FAST_OK) return 0;
    if ((h.flags & FXP_F_W16_OK) && !fx_env().no_w16) return 2;
    if (h.flags & FXP_F_CHAIN_OK) {
@@ -804,7 +807,7 @@ static bool scheme_decodes_utf8(const FxpHeader& h, int sch) {   // the class-le
 // rows, any length 2..127 that is not one of the four; +64: first pass of the multi-pass pipeline on the nibble tables; experiment hook).
 static int span_cell(int64_t row_len) { return row_len <= 16 ? 16 : (row_len <= 32 ? 32 : (row_len <= 64 ? 64 : 128)); }   // bytes of LDS a row gets (fx_span.hpp: RL)
 static bool span_kind(const FxpHeader& h, int scheme, int64_t row_len, bool spans) {
-   if (!spans || scheme != 0 || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) || fx_env().multipass || fx_env().no_span)
+   if (!spans || scheme != 0 || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII | FXP_F_PREFIX_CHECK)) || fx_env().multipass || fx_env().no_span)
       return false;
    if (row_len < 2 || row_len > 128) return false;
    const int lens = fx_env().span_lens;
@@ -830,9 +833,38 @@ struct SharedFirstPass {
    bool bytes_in_shared = false;   // the shared pass scans tiles with bytes >= 0x80 with this pattern's byte-level tables: no pass over deferred tiles
    bool exc_in_shared = false;     // ... and finishes the exception rows of those scans itself (class-level tables that decode): no follow-up at all
 };
+static int enqueue_batch_body(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                              uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode, int first_pass, SharedFirstPass* shared,
+                              const bool capturing_now);
+// (a kernel node, not a memset node: a 16-byte hipMemsetAsync captured into a graph aborted the process at the first replay on this ROCm -- gpurun call r06_c9)
+__global__ __launch_bounds__(64) void fx_zero_words(uint32_t* __restrict__ p, uint32_t n) {
+   if (threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+// A stream that is being captured into a hipGraph (round 6): the multi-pass pipelines keep their "tiles were deferred / rows are listed" words in two
+// groups that alternate between calls on the HOST, each first pass zeroing the other group for the call after it -- a replayed graph alternates nothing.
+// Under capture the call therefore zeroes ITS group with a one-block kernel node before its first pass and both groups behind its last pass: every replay starts
+// and ends with clean words, whatever ran on the stream in between, and eager calls after it find the group they expect to be zero.  Pipelines of
+// several launches (rows longer than 256 bytes, which have no one-launch kernel) are thereby replay-safe; rows of up to 256 bytes still take the
+// one-launch kernel under capture (one node instead of two or three).
 static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
                          uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode = 0u, int first_pass = FX_FP_OWN,
                          SharedFirstPass* shared = nullptr) {
+   bool cap_now = false;
+   {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+      else cap_now = cap != hipStreamCaptureStatusNone;
+   }
+   const int rc = enqueue_batch_body(p, d_blob, sc, d_rows, n, row_len, d_flags, d_from, d_to, st, out_mode, first_pass, shared, cap_now);
+   if (cap_now && rc == FXAMD_OK && first_pass != FX_FP_PREPARE && sc->d_counter) {
+      hipLaunchKernelGGL(fx_zero_words, dim3(1), dim3(64), 0, st, sc->d_counter, 8u);
+      FX_HIP(hipGetLastError());
+   }
+   return rc;
+}
+static int enqueue_batch_body(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc, const uint8_t* d_rows, int64_t n, int64_t row_len,
+                              uint8_t* d_flags, int32_t* d_from, int32_t* d_to, hipStream_t st, uint32_t out_mode, int first_pass, SharedFirstPass* shared,
+                              const bool capturing_now) {
    const FxpHeader& h = p->prog.hdr();
    if (out_mode != 0u) {
       // who writes packed results itself: the one-launch kernel; round 5: the half-row first pass of 256-byte rows (8-state tables, spans) and
@@ -888,18 +920,9 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // ... and the `.in.` VERDICT (no spans asked for) over the same rows: fx_search_tiny
       // (a stream that is being captured into a hipGraph keeps the one-launch kernel wherever another pipeline would hold host-side state between
       //  launches -- the counter groups alternate on the host.  Asked ONCE per call, and only when a rule below can need it: ADVICE r05.)
-      bool capturing_known = false, capturing_val = false;
-      auto capturing = [&]() -> bool {
-         if (!capturing_known) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
-            else capturing_val = cap != hipStreamCaptureStatusNone;
-            capturing_known = true;
-         }
-         return capturing_val;
-      };
+      auto capturing = [&]() -> bool { return capturing_now; };   // (asked once per call, by enqueue_batch)
       bool tiny = first_pass == FX_FP_OWN && (is_match || (h.mode == FXP_MODE_SEARCH_ENGINE && d_from == nullptr && !(h.flags & FXP_F_RAW_BYTES))) && out_mode == 0u &&
-                  row_len >= 2 && row_len <= 32 && (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny;
+                  row_len >= 2 && row_len <= 32 && (scheme == 0 || scheme == 2) && !fx_env().multipass && !fx_env().no_tiny && !(h.flags & FXP_F_PREFIX_CHECK);
       if (tiny && capturing()) tiny = false;
       // Where round 4 moved rows off the one-launch kernel -- 256-byte rows on the chain / nibble tables (half rows) -- a stream that is
       // being captured into a hipGraph keeps the one-launch kernel: it holds no host-side state between launches (the counter groups of
@@ -923,7 +946,7 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       // 128-byte rows 0.3225 -> 0.3177 ms.  (The chain tables at 128-byte rows: 0.504 against 0.494 ms on round 4's 64-byte halves -- not built.)
       bool span_first = false;
       if (first_pass == FX_FP_OWN && out_mode == 0u && !is_match && !tiny && !span && h.mode == FXP_MODE_SEARCH_ENGINE && d_from != nullptr && d_to != nullptr &&
-          !(h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII)) && !fx_env().multipass && !fx_env().no_span && (fx_env().span_lens & 64) &&
+          !(h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII | FXP_F_PREFIX_CHECK)) && !fx_env().multipass && !fx_env().no_span && (fx_env().span_lens & 64) &&
           scheme == 2 && (row_len == 128 || row_len == 64 || row_len == 32 || row_len == 16) &&
           (scheme_decodes_utf8(h, scheme) || bytes_ok(h, d_rows, row_len))) {
          span_first = !capturing();
@@ -935,6 +958,10 @@ static int enqueue_batch(fxamd_program* p, const uint8_t* d_blob, DevScratch* sc
       if (first_pass != FX_FP_DONE && !one_launch) sc->parity ^= 1u;
       uint32_t* ctr = sc->d_counter + 4u * sc->parity;   // this call's words: [0] tiles deferred, [1] exception rows left
       if (first_pass == FX_FP_DONE && shared && shared->ctr) ctr = shared->ctr;   // (what PREPARE chose and the shared kernel used)
+      if (capturing_now && !one_launch && first_pass == FX_FP_OWN) {   // (a replay cannot rely on the call before it: see enqueue_batch)
+         hipLaunchKernelGGL(fx_zero_words, dim3(1), dim3(64), 0, st, ctr, 4u);
+         FX_HIP(hipGetLastError());
+      }
       // (long rows have no in-LDS decode pass: their non-ASCII / exception rows go to the row-level fix-up)
       const bool utf8_tables = scheme_decodes_utf8(h, scheme) && !as_long;
       const bool bytes = !(h.flags & FXP_F_RAW_BYTES) && bytes_ok(h, d_rows, row_len);
@@ -1696,7 +1723,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       for (int32_t i = 0; i < m; ++i) {
          const FxpHeader& h = progs[i]->prog.hdr();
          if (first_of[(size_t)i] == i && progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&
-             fast_scheme(h, d_rows, row_len) == 0)
+             fast_scheme(h, d_rows, row_len) == 0 && !(h.flags & FXP_F_PREFIX_CHECK))   // (prefix-check programs: the one-launch kernel only, see fast_scheme)
             fused.push_back(i);
       }
    // The shared pass pays where a tile is small enough for full occupancy next to m patterns' tables -- rows of up to 128 bytes: 6 patterns
@@ -2279,14 +2306,5 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
    if (rc) *rc = r;
 }
 
-#ifdef FX_STAMP
-// debug builds only: read and clear the phase accumulators
-int fxamd_debug_stamps(unsigned long long* out) {
-   unsigned long long z[16] = {0};
-   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_stamp_acc), sizeof(z)) != hipSuccess) return 1;
-   if (hipMemcpyToSymbol(HIP_SYMBOL(fx_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
-   return 0;
-}
-#endif
 }   // extern "C"
 #pragma GCC visibility pop

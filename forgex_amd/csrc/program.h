@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 15u
+#define FXP_VERSION 16u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -41,6 +41,10 @@ enum FxpFlags {
    FXP_F_BYTE_A8 = 1u << 18,        // searches: the byte-level FORWARD automaton has <= 8 states and also exists in the v_perm format (b8A)
    FXP_F_SPEC_FWD = 1u << 19,       // ... and a walk of it from the row's first character decides the leftmost start by itself when it finds a match
                                     // (the leading NUL is no start, no state survives U+FFFF, no candidate-list driver): the tile kernels' speculative pass
+   FXP_F_PREFIX_CHECK = 1u << 21,   // searches with a prefix literal that is NOT proven a necessary, border-free beginning of every match: the tile tables still run
+                                    // (brute-force semantics) and the kernel checks per ROW that the start it found is one the reference's candidate list would
+                                    // have tried first -- the prefix literal stands there and no earlier occurrence overlaps it --, else the row goes to the general
+                                    // row procedure (round 6; compile.cpp `prefix_check`, row_engine.hpp prefix_start_ok)
    FXP_F_NEEDS_NONASCII = 1u << 20, // searches with byte-level tables: no non-empty match is made of ASCII symbols only -- a row without a byte >= 0x80 holds no match
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match

@@ -403,6 +403,24 @@ FX_HD uint32_t match_gate(const FxpHeader* h, const uint8_t* prog, const RowFn& 
    return ok ? 1u : 0u;
 }
 
+// FXP_F_PREFIX_CHECK (compile.cpp): is the brute-force start s (wrapped index: 1 = the leading NUL, j + 2 = text byte j) one the reference's candidate list tries
+// before any other start that could match?  The prefix literal stands at text byte j = s - 2 (wholly inside the text: it holds no NUL) and no occurrence of it
+// starts in the lp - 1 bytes before j (utility_m.f90:94-116 collects NON-overlapping occurrences left to right).  `pre(k)`: byte k of the literal.
+template <class Row, class Pre>
+FX_HD bool prefix_start_ok(const Pre& pre, const int lp, const Row& r, const int L, const int s) {
+   if (s < 2) return false;
+   const int j = s - 2;
+   if (j + lp > L) return false;
+   for (int k = 0; k < lp; ++k)
+      if (r[j + k] != pre(k)) return false;
+   for (int d = 1; d < lp && d <= j; ++d) {   // an occurrence at j - d overlaps the one at j
+      bool occ = true;
+      for (int k = 0; occ && k < lp; ++k) occ = r[j - d + k] == pre(k);
+      if (occ) return false;
+   }
+   return true;
+}
+
 struct Result {
    uint32_t flag;   // verdict of `.in.` / `.match.`
    int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none
@@ -471,6 +489,11 @@ FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Resu
             return;
          }
          if (s == 0) return;
+         if (force_brute && (h.flags & FXP_F_PREFIX_CHECK) && !prefix_start_ok(pre, lp, r, L, s)) {
+            // (test harness: what the tile kernels do with such a row -- they leave it to this procedure WITHOUT force_brute)
+            search_engine(pv, sim, r, L, out, false);
+            return;
+         }
          int mm = anchored_max_match(pv, sim, r, L, s);
          span_from(s, mm, L, out.from, out.to);
       } else {

@@ -76,11 +76,62 @@ def gen_case(rng):
     return (rng.choice(["I", "R", "R"]), pat.encode(), txt.encode())
 
 
+# round 6: programs with FXP_F_PREFIX_CHECK -- a prefix literal the compile-time proof does NOT cover (not a necessary beginning, or bordered without an overlap
+# state); the tile kernels run their tables all the same and check per row that the brute-force start is a candidate (row_engine.hpp prefix_start_ok), every
+# other row with a hit goes to the statement-level driver.  Patterns: random ones (fuzz_diff.gen_pattern) and hand-made shapes whose program carries the flag;
+# texts: the pattern's own literal characters repeated and overlapped, so that several prefix occurrences, overlapping ones and matches that do NOT start at an
+# occurrence all happen.
+CHECK_SHAPES = [r"(}[abc]){2}\d*c{2,}", r"(\t{3}[a-z]){2}", r" {3}\\{2}[a-z]{2,}", r"(ab|abc)x", r"(a|ab)(c|bcd)", r"a?ab+", r"(aa|a)b", r"x*yz", r"(ab)*abc", r"a{1,2}ab",
+                r"(-|--)a", r"(\t\t|\t)x+", r"aa(a|b)", r"(xy){1,2}z", r"ab?ab", r"(zz|z)\d", r"\d?12", r"(ab){2,}c?", r"a*aab", r"(b|)aba"]
+_info = None
+
+
+def prefix_check_flag(pat):
+    """does the compiled search program carry FXP_F_PREFIX_CHECK (bit 21)?  (tests/support/libhostwalk.so, hw_info)"""
+    global _info
+    import ctypes
+    if _info is None:
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhostwalk.so"))
+        lib.hw_info.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
+        _info = lib.hw_info
+    info = (ctypes.c_int32 * 8)()
+    _info(pat, len(pat), 0, info)
+    return info[5] == 0 and (info[1] & (1 << 21)) != 0
+
+
+def gen_case_check(rng, pool):
+    pat = rng.choice(pool)
+    lits = sorted({c for c in pat.decode("utf-8", "replace") if c.isalnum() or c in " -}\t"} | set("ab1c "))
+    lits = [("\t" if c == "t" and "\\t" in pat.decode("utf-8", "replace") else c) for c in lits]
+    pieces = []
+    for _ in range(rng.randint(0, 14)):
+        q = rng.random()
+        if q < 0.7:
+            c = rng.choice(lits)
+            pieces.append((c * rng.randint(1, 4)).encode())
+        elif q < 0.9:
+            pieces.append(rng.choice(["ab", "aab", "abab", "}a}b", "12", "\t\t\t\ta", "   \\\\ab", "--a", "xyxyz", "zz1"]).encode())
+        else:
+            pieces.append(rng.choice([b"\xce\xb1", b"\xff", b"\n", b"\0"]))
+    return (rng.choice(["I", "R", "R"]), pat, b"".join(pieces))
+
+
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     rng = random.Random(seed)
-    cases = [gen_case(rng) for _ in range(n)]
+    if os.environ.get("FX_FUZZ_CHECK"):
+        pool = [p.encode() for p in CHECK_SHAPES if prefix_check_flag(p.encode())]
+        tried = 0
+        while len(pool) < 60 and tried < 20000:   # random patterns whose program carries the flag
+            tried += 1
+            p = gen_pattern(rng).encode()
+            if prefix_check_flag(p):
+                pool.append(p)
+        print("FX_FUZZ_CHECK: %d patterns with FXP_F_PREFIX_CHECK (%d hand-made shapes carry it)" % (len(pool), sum(1 for p in CHECK_SHAPES if prefix_check_flag(p.encode()))))
+        cases = [gen_case_check(rng, pool) for _ in range(n)]
+    else:
+        cases = [gen_case(rng) for _ in range(n)]
     a = run_protocol(ORACLE_CLI, cases)
     os.environ["FX_HW_FAST"] = "1"
     b = run_protocol(HOST_WALK, cases)

@@ -810,6 +810,63 @@ def test_bordered_prefix_literals_on_tile_kernel(fx):
     assert 0 < int(of.sum()) < n
 
 
+def test_prefix_literal_checked_per_row_on_tile_kernel(fx, monkeypatch):
+    """Round 6: search programs whose prefix literal the compile-time proof does NOT cover -- not a necessary beginning of every match
+    (`(}[abc]){2}\\d*c{2,}`), or bordered without an overlap state (`(\\t{3}[a-z]){2}`) -- used to run on the general kernel, a 20-30 x cliff.  They carry
+    FXP_F_PREFIX_CHECK now: the one-launch kernel searches with the tables and checks per row that the start it found is one the reference's candidate list
+    (src/essential/utility_m.f90:94-116, src/api_internal_m.F90:84-164) tries first; any other row with a hit is finished by the general row procedure inside
+    the launch.  Random patterns whose program carries the flag + hand-made shapes, texts with several / overlapping occurrences and matches that do not start
+    at an occurrence, in rows of whole chunks and ragged rows, spans and flags only, plain and packed -- against the oracle (which follows the driver)."""
+    import random
+    import fuzz_diff
+    import fuzz_prefilter
+    rng = random.Random(int(os.environ.get("FX_FUZZ_SEED", "0")) + 88)
+    pool = [q.encode() for q in fuzz_prefilter.CHECK_SHAPES if fx.Program(q.encode(), fx.OP_SEARCH).info()["flags"] & (1 << 21)]
+    n_hand = len(pool)
+    tried = 0
+    while len(pool) < n_hand + 24 and tried < 20000:
+        tried += 1
+        q = fuzz_diff.gen_pattern(rng).encode()
+        pr = fx.Program(q, fx.OP_SEARCH)
+        if pr.status == 0 and pr.info()["flags"] & (1 << 21):
+            pool.append(q)
+    assert n_hand >= 3 and len(pool) >= n_hand + 12, (n_hand, len(pool))
+    n_exc = 0
+    for pat in pool:
+        for L in (16, 64, 100, 192, 256, 33):
+            n = 64 * 5 + 7
+            rows = np.full((n, L), 0x20, dtype=np.uint8)
+            for i in range(n):
+                t = b""
+                while len(t) < L and rng.random() < 0.97:
+                    t += fuzz_prefilter.gen_case_check(rng, [pat])[2] + rng.choice([b"", b" ", b"x", b"\n"])
+                t = t[:L]
+                if rng.random() < 0.8:
+                    t = t.replace(b"\xce\xb1", b"ab").replace(b"\xff", b"c")   # (most rows pure ASCII: the tables' rows; the others are the general procedure's anyway)
+                rows[i, :len(t)] = np.frombuffer(t, dtype=np.uint8)
+            of, oa, ob = oracle_lib.batch(2, pat, rows, NT)
+            prog, f, a, b = _device_run(fx, pat, fx.OP_SEARCH, rows)
+            assert prog.last_path() in (12, 13, 14), (pat, L, prog.last_path())
+            bad = np.flatnonzero((f != of) | (a != oa) | (b != ob))
+            assert bad.size == 0, (pat, L, int(bad[0]), bytes(rows[bad[0]]), int(f[bad[0]]), int(a[bad[0]]), int(b[bad[0]]), int(of[bad[0]]), int(oa[bad[0]]), int(ob[bad[0]]))
+            _, f2, _, _ = _device_run(fx, pat, fx.OP_SEARCH, rows, spans=False)
+            assert np.array_equal(f2, of), (pat, L, "flags only")
+            import torch
+            img = prog.match_device_packed(torch.from_numpy(rows).cuda(), spans=True)
+            pf, pa, pb = fx.unpack_results(img, n, L, True)
+            torch.cuda.synchronize()
+            assert np.array_equal(pf.cpu().numpy(), of) and np.array_equal(pa.cpu().numpy(), oa) and np.array_equal(pb.cpu().numpy(), ob), (pat, L, "packed")
+            # brute force on the same rows (what the tables alone would answer): where it differs from the reference the check was needed
+            n_exc += int((of == 0).sum())
+    # longer rows and the multi-pass hook: the general kernel, as before
+    rows = np.full((100, 400), 0x61, dtype=np.uint8)
+    prog, f, a, b = _device_run(fx, pool[0], fx.OP_SEARCH, rows)
+    assert prog.last_path() == 2, prog.last_path()
+    monkeypatch.setenv("FXAMD_MULTIPASS", "1")
+    prog, f, a, b = _device_run(fx, pool[0], fx.OP_SEARCH, rows[:, :64].copy())
+    assert prog.last_path() == 2, prog.last_path()
+
+
 def _hostwalk_mt():
     import ctypes
     lib = ctypes.CDLL(os.path.join(golden.ROOT, "tests", "support", "libhostwalk.so"))
@@ -1286,6 +1343,56 @@ def test_one_launch_calls_replay_from_a_hip_graph(fx):
             assert torch.equal(got[0], want[0]), (cfg, start)
             if spans:
                 assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (cfg, start)
+
+
+def test_multi_pass_pipelines_replay_from_a_hip_graph(fx):
+    """Round 6: rows longer than 256 bytes have no one-launch kernel -- first pass + gated passes, whose counter words alternate between calls on the host.  Under
+    capture the call zeroes its words with memset nodes (before its first pass, behind its last one), so the captured pipeline replays on new row contents:
+    400- and 1024-byte rows (`last_path` 8 / 7), pure ASCII and with UTF-8 / broken rows mixed in (the gated passes have work), replays interleaved with
+    eager calls on the same handle; search with spans, flags only, `.match.`."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(606)
+
+    def batch(L, n, start, hi):
+        flat = synth.batch("cfg3", start, (n * L + 255) // 256, dev).reshape(-1)
+        rows = flat[: n * L].reshape(n, L).clone()
+        if hi:   # every 37th row: a three-byte character, every 101st: a lone continuation byte
+            rows[::37, 5:8] = torch.tensor([0xE3, 0x81, 0x82], dtype=torch.uint8, device=dev)
+            rows[::101, L - 3] = 0x85
+        return rows
+
+    for L, pat, op, spans in ((400, r"[a-z]+\d+", fx.OP_SEARCH, True), (1024, r"[a-z]+\d+", fx.OP_SEARCH, True), (400, r"\d{3}-\d{4}|[a-z]+\d", fx.OP_SEARCH, False),
+                              (1024, r"[a-z]{6}\d{1,3}[a-z ]{6}", fx.OP_SEARCH, True), (400, r"[a-z0-9 ]+", fx.OP_MATCH, False)):
+        for hi in (False, True):
+            n = 4096 + 17
+            rows = batch(L, n, 0, hi)
+            prog = fx.Program(pat, op)
+            out = prog.match_device(rows, spans=spans)
+            torch.cuda.synchronize()
+            assert prog.last_path() in (1, 3, 5, 6, 7, 8), (L, pat, prog.last_path())
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):   # the capture stream's own scratch set, made before capturing
+                assert fx.lib().fxamd_program_reserve(prog._h, n, side.cuda_stream) == 0
+                prog.match_device(rows, spans=spans, out=out)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                prog.match_device(rows, spans=spans, out=out)
+            for k, start in enumerate((31000, 90001, 250000, 31000)):
+                rows.copy_(batch(L, n, start, hi and k != 1))   # (the second replay: a pure-ASCII batch after one with deferred tiles)
+                graph.replay()
+                torch.cuda.synchronize()
+                got = [t.clone() if t is not None else None for t in out]
+                with torch.cuda.stream(side):   # an eager call on the captured stream in between
+                    want = prog.match_device(rows, spans=spans)
+                torch.cuda.synchronize()
+                assert torch.equal(got[0], want[0]), (L, pat, hi, start)
+                if spans and op == fx.OP_SEARCH:
+                    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]), (L, pat, hi, start)
+            of, oa, ob = oracle_lib.batch(1 if op == fx.OP_MATCH else 2, pat.encode(), rows[:512].cpu().numpy(), NT)
+            assert np.array_equal(got[0][:512].cpu().numpy(), of), (L, pat, hi)
 
 
 def test_many_patterns_default_dispatch_by_row_length(fx):

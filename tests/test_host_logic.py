@@ -481,7 +481,7 @@ def test_default_path_kernels_use_no_scratch_memory():
     csrc = os.path.join(golden.ROOT, "forgex_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip", ".h", ".cpp"))]
     txts = [os.path.join(ru_dir, f) for f in os.listdir(ru_dir) if f.endswith(".txt")] if os.path.isdir(ru_dir) else []
-    if len(txts) >= 26 and min(os.path.getmtime(t) for t in txts) >= max(os.path.getmtime(f) for f in srcs):   # (the remarks of THESE sources, every object)
+    if len(txts) >= 20 and min(os.path.getmtime(t) for t in txts) >= max(os.path.getmtime(f) for f in srcs):   # (the remarks of THESE sources, every object)
         sys.path.insert(0, os.path.join(golden.ROOT, "tools"))
         import summarize_ru
         rows = [r for r in summarize_ru.load(ru_dir) if "scratch" in r]
@@ -499,7 +499,7 @@ def test_c_abi_host_side_under_thread_sanitizer(built, tmp_path):
     csrc = os.path.join(golden.ROOT, "forgex_amd", "csrc")
     objs_dir = os.path.join(csrc, "build")
     tiles = sorted(os.path.join(objs_dir, f) for f in os.listdir(objs_dir) if f.startswith("tile_") and f.endswith(".o")) if os.path.isdir(objs_dir) else []
-    if not os.path.exists(hipcc) or len(tiles) < 24 or not os.path.exists(os.path.join(objs_dir, "span.o")):
+    if not os.path.exists(hipcc) or len(tiles) < 18 or not os.path.exists(os.path.join(objs_dir, "span.o")):
         pytest.skip("needs hipcc and the product's objects (forgex_amd/csrc/build)")
     common = ["-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=thread", "-fno-omit-frame-pointer"]
     jobs = [[hipcc, "--offload-arch=gfx950", "--cuda-host-only"] + common + ["-c", os.path.join(csrc, "fxamd.hip"), "-o", str(tmp_path / "fxamd.o")],

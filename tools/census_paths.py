@@ -39,6 +39,8 @@ def classify(pat, op):
     if fl & (F["FAST_OK"] | F["W16_OK"] | F["CHAIN_OK"]):
         tab = "8-state v_perm" if fl & F["FAST_OK"] else ("nibble" if fl & F["W16_OK"] else "chain")
         ragged = "" if fl & F["RAGGED_OK"] else " (ragged rows -> general)"
+        if fl & (1 << 21):   # FXP_F_PREFIX_CHECK (round 6): rows of up to 256 bytes on the one-launch kernel, the start checked per row; longer rows: general kernel
+            tab += " + per-row prefix check (rows > 256 B: general kernel)"
         return "tile", tab + ragged
     # general kernel: why?
     why = []

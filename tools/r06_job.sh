@@ -20,6 +20,8 @@ for step in "$@"; do
   case $step in
     spec_tests) timeout 1500 python -m pytest tests -m gpu -x -q -k "speculative or config_rows_vs_oracle or exception_queues or few_exception or utf8_rows" > $OUT/spec_tests.log 2>&1; echo "spec_tests rc $?"; tail -5 $OUT/spec_tests.log ;;
     suite) timeout 3000 python -m pytest tests -m gpu -x -q --durations=25 > $OUT/pytest.log 2>&1; echo "suite rc $?"; grep -A27 "slowest" $OUT/pytest.log | head -30; tail -3 $OUT/pytest.log ;;
+    stampf:*) IFS=: read -r _ shp obj <<< "$step"   # stampf:<bench_shapes name>:<ch>_1  phases of fx_search_fast (make -C forgex_amd/csrc stamp-fast STAMP_FAST_OBJ=<ch>_1)
+      FXAMD_LIB=forgex_amd/libforgex_amd_stamp_fast_$obj.so python tools/stamp_one.py shape:$shp --fast --md > $OUT/stampf_${shp}.md 2> $OUT/stampf_${shp}.err; echo "stampf $shp rc $?"; cat $OUT/stampf_${shp}.md; tail -2 $OUT/stampf_${shp}.err ;;
     stamp:*) IFS=: read -r _ cfg obj extra <<< "$step"   # stamp:<cfg>:<ch>_<part>[:--flags-only] per-phase s_memtime shares of fx_search_one (make -C forgex_amd/csrc stamp-one STAMP_OBJ=<ch>_<part>)
       FXAMD_LIB=forgex_amd/libforgex_amd_stamp_one_$obj.so python tools/stamp_one.py $cfg $extra --md > $OUT/stamp_${cfg}${extra}.md 2> $OUT/stamp_${cfg}${extra}.err; echo "stamp $cfg rc $?"; cat $OUT/stamp_${cfg}${extra}.md; tail -2 $OUT/stamp_${cfg}${extra}.err ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc $?"; tail -3 $OUT/smoke.log ;;
