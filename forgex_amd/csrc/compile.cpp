@@ -1190,6 +1190,7 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    // Candidate-list search == brute-force search on pure-ASCII rows iff the prefix is a NECESSARY, non-self-overlapping
    // beginning of every non-empty match; the suffix is only consulted by the candidate-list driver.
    bool brute_equiv = op == OP_SEARCH && R.ok;   // (a suffix literal without a prefix literal is never consulted: api_internal_m.F90:76-82)
+   bool suffix_unproven = false;
    if (brute_equiv && prefilter && has_suffix) {
       // With a suffix literal the driver also (a) gives up when the suffix does not occur, (b) stops at candidates behind its
       // last occurrence (api_internal_m.F90:99-116; one index is a text index, the other a wrapped one).  Neither changes a
@@ -1197,7 +1198,8 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
       // suffix of the match found starts at least one byte behind the match start, which is all the off-by-one needs).
       // Necessity is checked on the NFA walked BACKWARDS from the exit: at each of the last ls positions only the suffix's own
       // symbol -- a singleton class -- leads anywhere, and the entry state (a complete, shorter match) is not met on the way.
-      brute_equiv = suffix_is_necessary_ending();
+      // (round 6: where that proof fails, the kernel checks per row that the match it found ends with the suffix, behind its start: `suffix_check` below)
+      suffix_unproven = !suffix_is_necessary_ending();
    }
    // the prefix literal is a NECESSARY beginning of every non-empty match (walking A along it, each state is non-accepting and only
    // the next prefix symbol -- a singleton class -- is live): with it the general engine may skip the reference's brute-force
@@ -1234,12 +1236,19 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    // general row procedure inside the same launch, which follows the driver to the letter (it also knows the fallback to brute force when the prefix occurs
    // nowhere).  A row without a hit has no match for the reference either: whatever it finds is a match brute force would have found.  (Suffix literal: only
    // with the suffix proof above -- `brute_equiv` is already false otherwise.)
-   bool prefix_check = false;
-   if (brute_equiv && prefilter && !(prefix_necessary && (border_free(lit.prefix) || overlap_sink))) {
-      prefix_check = lit.prefix.find('\0') == std::string::npos && lit.prefix.size() <= 32;
+   // With a suffix literal the driver also gives up when the suffix does not occur in the text and stops at candidates behind its last occurrence
+   // (api_internal_m.F90:99-116; the list builder stops collecting behind it as well, utility_m.f90:85-114).  None of that changes the result of a row on which
+   // the match found at the candidate s ENDS with the suffix literal at least one byte behind s: the suffix then occurs behind s, so the text index of its last
+   // occurrence is >= the wrapped index of s, no candidate up to s is cut off, and every listed occurrence before s ends before the suffix does.  Where the
+   // compile-time suffix proof fails the kernel checks exactly that (FXP_F_SUFFIX_CHECK), after the forward pass; rows that fail go to the general procedure.
+   bool prefix_check = false, suffix_check = false;
+   if (brute_equiv && prefilter && (suffix_unproven || !(prefix_necessary && (border_free(lit.prefix) || overlap_sink)))) {
+      suffix_check = suffix_unproven;
+      prefix_check = lit.prefix.find('\0') == std::string::npos && lit.prefix.size() <= 32 &&
+                     (!suffix_check || (lit.suffix.find('\0') == std::string::npos && lit.suffix.size() <= 32));
       brute_equiv = prefix_check;
    }
-   if (prefix_check) h.flags |= FXP_F_PREFIX_CHECK;
+   if (prefix_check) h.flags |= FXP_F_PREFIX_CHECK | (suffix_check ? FXP_F_SUFFIX_CHECK : 0u);
    if (overlap_sink) {
       h.flags |= FXP_F_OVERLAP_SINK;
       h.R_inv = static_cast<uint32_t>(R_inv_state);
@@ -1644,7 +1653,7 @@ int validate_blob(const uint8_t* b, size_t size) {
    const uint32_t known = FXP_F_INIT_ACCEPTING | FXP_F_PREFILTER | FXP_F_HAS_SUFFIX | FXP_F_FAST_OK | FXP_F_HAS_R | FXP_F_MATCH_LITERAL |
                           FXP_F_FAST_UTF8 | FXP_F_NFA_SIM | FXP_F_CHAIN_OK | FXP_F_CHAIN_UTF8 | FXP_F_RAW_BYTES | FXP_F_RAGGED_OK | FXP_F_BYTE_DFA |
                           FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8 | FXP_F_SPEC_FWD | FXP_F_NEEDS_NONASCII |
-                          FXP_F_PREFIX_CHECK;
+                          FXP_F_PREFIX_CHECK | FXP_F_SUFFIX_CHECK;
    if (h.flags & ~known) return 5;
    // chain-format table: rows of (ncls + 3) uint16, entries = row offsets of the same table; the 256-entry map holds 2 * column
    auto chain_ok = [&](uint32_t off_cls, uint32_t off_T, uint32_t T_bytes, uint32_t ncls, uint32_t row_bytes, bool final_col) {
@@ -1719,6 +1728,7 @@ int validate_blob(const uint8_t* b, size_t size) {
    } else if (h.flags & (FXP_F_FAST_OK | FXP_F_CHAIN_OK | FXP_F_W16_OK | FXP_F_BYTE_DFA | FXP_F_OVERLAP_SINK)) {
       if (h.mode != FXP_MODE_MATCH_ENGINE) return 46;   // the tile kernels' search needs R
    }
+   if ((h.flags & FXP_F_SUFFIX_CHECK) && (!(h.flags & FXP_F_PREFIX_CHECK) || !(h.flags & FXP_F_HAS_SUFFIX) || h.len_suffix < 1u || h.len_suffix > 32u)) return 79;
    if ((h.flags & FXP_F_PREFIX_CHECK) && (!(h.flags & FXP_F_PREFILTER) || h.mode != FXP_MODE_SEARCH_ENGINE || h.len_prefix < 1u || h.len_prefix > 32u ||
                                           (h.flags & (FXP_F_BYTE_DFA | FXP_F_FAST_UTF8 | FXP_F_CHAIN_UTF8 | FXP_F_W16_UTF8)))) return 78;
    if ((h.flags & FXP_F_FAST_OK) && (!inside(h.off_fastA, 2048) || !inside(h.off_fastR, 2048))) return 50;

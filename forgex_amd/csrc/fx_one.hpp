@@ -65,6 +65,8 @@ struct FxScanCtx {
    const FxTail* tl = nullptr;   // TAIL scans (ragged rows of fx_search_one, fx_tile.hpp "Ragged rows, round 4"): L = Lr, the cells are walked as 16*CH bytes
    const uint8_t* pfx = nullptr;   // FXP_F_PREFIX_CHECK programs (round 6): the prefix literal (global memory, wave-uniform reads) ...
    uint32_t pfx_len = 0;           // ... and its length; 0 = no per-row check (fxrow::prefix_start_ok, row_engine.hpp)
+   const uint8_t* sfx = nullptr;   // FXP_F_SUFFIX_CHECK: the suffix literal ...
+   uint32_t sfx_len = 0;           // ... and its length; 0 = no check of the match's end (fxrow::suffix_end_ok)
 };
 // Match compaction (DEFERQ): the exact start and the forward pass are per-ROW work that only rows with a hit need, but a
 // wave pays for them per TILE -- at full price when a few lanes in 64 have a hit (config 2: one row in ten matches).  Unless the tile
@@ -330,6 +332,8 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
          s = hit ? g * 8u + 2u + loc : 0u;
       }
       s = s_nul ? 1u : s;
+      bool pfx_nowhere = false;   // (per lane)
+      (void)pfx_nowhere;
       if constexpr (ROW_EXC && !BYTES && !DECODED) {
          // FXP_F_PREFIX_CHECK (compile.cpp): the tables searched by brute force; the reference searches its candidate list.  The two agree on this row when the
          // start found is a candidate -- the prefix literal stands there, no earlier occurrence overlaps it; any other row with a hit is the general row
@@ -339,13 +343,19 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
             if (s != 0u && !except && row_ok) {
                const FxTileRow tr{tb, lane};
                const uint8_t* const pp = c.pfx;
-               ok = fxrow::prefix_start_ok([&](int k) -> uint32_t { return pp[k]; }, (int)c.pfx_len, tr, (int)L, (int)s);
+               auto pre = [&](int k) -> uint32_t { return pp[k]; };
+               ok = fxrow::prefix_start_ok(pre, (int)c.pfx_len, tr, (int)L, (int)s);
+               if (!ok && !fxrow::prefix_occurs(pre, (int)c.pfx_len, tr, (int)L)) {   // the prefix occurs nowhere: the reference searches by brute force itself, suffix not consulted
+                  ok = true;
+                  pfx_nowhere = true;
+               }
             }
             except = except || !ok;
          }
       }
       // ---- left-to-right pass from the leftmost start: anchored DFA, longest accept (api_internal_m.F90:119-148) ----
-      uint32_t cur = (s != 0 && !queued && !except && (SPANS || s == 1) && P.lit_len == 0) ? P.A_init : 0u;
+      const bool sfx_on = pfx_on && c.sfx_len != 0u;   // (wave-uniform: the match's end is needed whatever the caller asked for)
+      uint32_t cur = (s != 0 && !queued && !except && (SPANS || s == 1 || sfx_on) && P.lit_len == 0) ? P.A_init : 0u;
       uint32_t mm = (P.lit_len != 0 && s != 0) ? s + P.lit_len : 0u;   // max_match (wrapped index of the byte after the match)
       uint32_t j = s >= 2 ? s - 2 : 0;      // 0-based text index of the next byte to consume
       if (s == 1) {
@@ -636,6 +646,17 @@ __device__ __forceinline__ bool fx_scan_tile(const FxScanCtx& c, const TabT* __r
                }
                mm = jl != 0xFFFFFFFFu ? jl + loc + 3u : mm;
             }
+         }
+      }
+      if constexpr (ROW_EXC && !BYTES && !DECODED) {
+         if (sfx_on) {   // FXP_F_SUFFIX_CHECK: the match found ends with the suffix literal, behind its start -- else the row is the general procedure's
+            bool ok = true;
+            if (s != 0u && !except && row_ok && !pfx_nowhere) {
+               const FxTileRow tr{tb, lane};
+               const uint8_t* const sp = c.sfx;
+               ok = fxrow::suffix_end_ok([&](int k) -> uint32_t { return sp[k]; }, (int)c.sfx_len, tr, (int)L, (int)s, (int)mm);
+            }
+            except = except || !ok;
          }
       }
       uint32_t flag = 0;
@@ -1127,7 +1148,9 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
 
    // ---- one scan of the tile in LDS (fx_scan_tile) with the tables of one family ----------------------------------------------
    const bool pfx_chk = GEN && !MATCH && (h->flags & FXP_F_PREFIX_CHECK) != 0u;
-   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u, &tl, pfx_chk ? prog + h->off_prefix : nullptr, pfx_chk ? h->len_prefix : 0u};
+   const bool sfx_chk = pfx_chk && (h->flags & FXP_F_SUFFIX_CHECK) != 0u;
+   const FxScanCtx sctx{tile, tb, lane, L, Lr, whole, raw, 0u, &tl, pfx_chk ? prog + h->off_prefix : nullptr, pfx_chk ? h->len_prefix : 0u,
+                        sfx_chk ? prog + h->off_suffix : nullptr, sfx_chk ? h->len_suffix : 0u};
    // tables of one family (class-level / byte-level) in the scheme `S_`, handed to `fn(tabR, tabA, TRp, TAp, P)`
    auto with_tables = [&](auto cfg, auto&& fn) {
       using C = decltype(cfg);

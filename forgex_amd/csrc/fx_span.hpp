@@ -724,9 +724,10 @@ hipError_t launch_span(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    if (!from || !to) return hipErrorInvalidValue;   // (searches with spans only: fxamd.hip, span_kind)
    const bool rag = Lr != (uint32_t)RL;
 #define FX_SPAN_GO(P, R) hipLaunchKernelGGL((fx_search_span<RL, SCH, P, R>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks, Lr)
-   if constexpr (SCH != 0) {   // nibble tables: aligned rows, plain results (fxamd.hip, span_first)
-      if (rag || fp.out_mode != 0u) return hipErrorInvalidValue;
-      FX_SPAN_GO(false, false);
+   if constexpr (SCH != 0) {   // nibble tables: plain results (fxamd.hip, span_first); round 6: ragged rows too (101-124 VGPRs at four waves per SIMD, no scratch)
+      if (fp.out_mode != 0u) return hipErrorInvalidValue;
+      if (rag) FX_SPAN_GO(false, true);
+      else FX_SPAN_GO(false, false);
    } else if (fp.out_mode != 0u) {
       if (rag) FX_SPAN_GO(true, true);
       else FX_SPAN_GO(true, false);

@@ -1,5 +1,5 @@
 // Explicit instantiation of the span-kernel launchers (fx_span.hpp): rows of up to 128 / 64 / 32 / 16 bytes on the 8-state v_perm tables
-// (aligned and ragged, plain and packed results); aligned rows on the nibble tables (all four lengths, plain results).
+// (aligned and ragged, plain and packed results); aligned and ragged rows on the nibble tables (all four lengths, plain results).
 #include "fx_span.hpp"
 
 template hipError_t launch_span<128, 0> FX_SPAN_SIG;

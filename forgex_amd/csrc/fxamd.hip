@@ -947,8 +947,11 @@ static int enqueue_batch_body(fxamd_program* p, const uint8_t* d_blob, DevScratc
       bool span_first = false;
       if (first_pass == FX_FP_OWN && out_mode == 0u && !is_match && !tiny && !span && h.mode == FXP_MODE_SEARCH_ENGINE && d_from != nullptr && d_to != nullptr &&
           !(h.flags & (FXP_F_RAW_BYTES | FXP_F_NEEDS_NONASCII | FXP_F_PREFIX_CHECK)) && !fx_env().multipass && !fx_env().no_span && (fx_env().span_lens & 64) &&
-          scheme == 2 && (row_len == 128 || row_len == 64 || row_len == 32 || row_len == 16) &&
-          (scheme_decodes_utf8(h, scheme) || bytes_ok(h, d_rows, row_len))) {
+          scheme == 2 && row_len >= 2 && row_len <= 128 &&
+          // (round 6: ragged rows too -- character(20), (80), (100) with a 9..16-state pattern used to stay on the one-launch kernel's RAGGED instantiations; the
+          //  tiles the first pass marks then need the decode pass: byte-level tables do not run on the multi-pass kernels' padded ragged rows)
+          ((row_len == span_cell(row_len) && (scheme_decodes_utf8(h, scheme) || bytes_ok(h, d_rows, row_len))) ||
+           (row_len != span_cell(row_len) && (fx_env().span_lens & 32) && scheme_decodes_utf8(h, scheme)))) {
          span_first = !capturing();
       }
       // (`.match.` programs whose class-level tables cannot decode UTF-8 -- more than 126 symbol classes -- take the multi-pass pipeline: first pass + the general row
@@ -1140,10 +1143,11 @@ static int enqueue_batch_body(fxamd_program* p, const uint8_t* d_blob, DevScratc
       else if (span_first) {
          FastParams fps = params_of(h, scheme, false);
          fps.defer_tiles = 1u;
-         if (row_len == 128) FX_HIP((launch_span<128, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 128u)));
-         else if (row_len == 64) FX_HIP((launch_span<64, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 64u)));
-         else if (row_len == 32) FX_HIP((launch_span<32, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 32u)));
-         else FX_HIP((launch_span<16, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, 16u)));
+         const int rl = span_cell(row_len);   // (the LDS bytes a row gets: its length rounded up to 16 / 32 / 64 / 128)
+         if (rl == 128) FX_HIP((launch_span<128, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, (uint32_t)row_len)));
+         else if (rl == 64) FX_HIP((launch_span<64, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, (uint32_t)row_len)));
+         else if (rl == 32) FX_HIP((launch_span<32, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, (uint32_t)row_len)));
+         else FX_HIP((launch_span<16, 2>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, st, nullptr, (uint32_t)row_len)));
       } else FX_HIP(fast_by<0>(scheme, h, d_blob, d_rows, n, row_len, d_flags, d_from, d_to, ctr, st, first));
       if (bytes) {
          // deferred tiles (bytes >= 0x80): byte-level tables on the raw bytes; structurally invalid rows go on to the decode pass

@@ -45,6 +45,9 @@ enum FxpFlags {
                                     // (brute-force semantics) and the kernel checks per ROW that the start it found is one the reference's candidate list would
                                     // have tried first -- the prefix literal stands there and no earlier occurrence overlaps it --, else the row goes to the general
                                     // row procedure (round 6; compile.cpp `prefix_check`, row_engine.hpp prefix_start_ok)
+   FXP_F_SUFFIX_CHECK = 1u << 22,   // ... and (with FXP_F_PREFIX_CHECK) a suffix literal that is not proven a necessary ending: the kernel also checks that the match it found
+                                    // ends with the suffix literal, at least one byte behind the match's start -- what makes the driver's give-up / cut-off rules
+                                    // (api_internal_m.F90:99-116) moot for this row (row_engine.hpp suffix_end_ok)
    FXP_F_NEEDS_NONASCII = 1u << 20, // searches with byte-level tables: no non-empty match is made of ASCII symbols only -- a row without a byte >= 0x80 holds no match
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match

@@ -421,6 +421,32 @@ FX_HD bool prefix_start_ok(const Pre& pre, const int lp, const Row& r, const int
    return true;
 }
 
+// ... and when the start is NOT such a candidate: does the prefix literal occur in the row at all?  If it occurs nowhere the reference itself searches by brute
+// force, suffix literal ignored (api_internal_m.F90:76-81: INDEX of the prefix = 0) -- the tables' answer stands.  This is the common case for the "prefix"
+// literals the reference derives from patterns like `(}[abc]){2}\d*c{2,}` (`}}`) or `(\t{3}[a-z]){2}` (six tabs): no match ever contains them.
+template <class Row, class Pre>
+FX_HD bool prefix_occurs(const Pre& pre, const int lp, const Row& r, const int L) {
+   const uint32_t p0 = pre(0);
+   for (int i = 0; i + lp <= L; ++i) {
+      if (r[i] != p0) continue;
+      int k = 1;
+      while (k < lp && r[i + k] == pre(k)) ++k;
+      if (k == lp) return true;
+   }
+   return false;
+}
+// FXP_F_SUFFIX_CHECK: the match from the start s (wrapped index >= 2) with max_match mm (wrapped index of the symbol behind it; >= L + 2: it ran to the row's end)
+// ends with the suffix literal, and that occurrence starts at least one byte behind the match's start.
+template <class Row, class Suf>
+FX_HD bool suffix_end_ok(const Suf& suf, const int ls, const Row& r, const int L, const int s, const int mm) {
+   if (s < 2 || mm <= 0) return false;
+   const int j = s - 2, e = mm >= L + 2 ? L : mm - 2;   // text bytes [j, e)
+   if (e - ls < j + 1) return false;
+   for (int k = 0; k < ls; ++k)
+      if (r[e - ls + k] != suf(k)) return false;
+   return true;
+}
+
 struct Result {
    uint32_t flag;   // verdict of `.in.` / `.match.`
    int32_t from, to;   // regex(): 1-based byte span, 0/0 when there is none
@@ -473,7 +499,8 @@ FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Resu
    }
    if (brute) {
       int s = 0;
-      if (h.flags & FXP_F_HAS_R) {
+      bool restart_loop = !(h.flags & FXP_F_HAS_R);
+      if (!restart_loop) {
          sim.rev_init();
          int j = L - 1;
          while (j >= 0) {
@@ -483,18 +510,36 @@ FX_HD void search_engine(const ProgView& pv, Sim& sim, const Row& r, int L, Resu
             j = start - 1;
          }
          if (sim.rev_step(pv.cls_nul_v)) s = 1;
-         if (force_brute && (h.flags & FXP_F_OVERLAP_SINK) && sim.at_overlap_sink()) {
-            // (test harness: what the tile kernels do with such a row -- they leave it to this procedure WITHOUT force_brute)
-            search_engine(pv, sim, r, L, out, false);
-            return;
+         if ((h.flags & FXP_F_OVERLAP_SINK) && sim.at_overlap_sink()) {
+            if (force_brute) {
+               // (test harness: what the tile kernels do with such a row -- they leave it to this procedure WITHOUT force_brute)
+               search_engine(pv, sim, r, L, out, false);
+               return;
+            }
+            // Round 6: the reference's OWN fallback to brute force (the prefix occurs nowhere byte-wise, api_internal_m.F90:79-81) on a row whose SYMBOLS hold
+            // two overlapping prefix occurrences -- possible only through non-canonical encodings (`αα[^a]*` over α, an overlong α, α): R was composed with the
+            // overlap detector and stopped recording hits once it entered the absorbing state, so its last hit is not the leftmost start.  The restart loop
+            // with A alone is exact.  (Found by fuzz_prefilter.py FX_FUZZ_UTF8=1 seed 2; the bug dates from round 3's overlap sink.)
+            restart_loop = true;
+            s = 0;
          }
+      }
+      if (!restart_loop) {
          if (s == 0) return;
+         bool prefix_nowhere = false;   // (the reference's own brute-force fallback: the suffix literal is not consulted either)
          if (force_brute && (h.flags & FXP_F_PREFIX_CHECK) && !prefix_start_ok(pre, lp, r, L, s)) {
-            // (test harness: what the tile kernels do with such a row -- they leave it to this procedure WITHOUT force_brute)
-            search_engine(pv, sim, r, L, out, false);
-            return;
+            prefix_nowhere = !prefix_occurs(pre, lp, r, L);
+            if (!prefix_nowhere) {
+               // (test harness: what the tile kernels do with such a row -- they leave it to this procedure WITHOUT force_brute)
+               search_engine(pv, sim, r, L, out, false);
+               return;
+            }
          }
          int mm = anchored_max_match(pv, sim, r, L, s);
+         if (force_brute && !prefix_nowhere && (h.flags & FXP_F_SUFFIX_CHECK) && !suffix_end_ok(suf, ls, r, L, s, mm)) {   // (test harness: as above)
+            search_engine(pv, sim, r, L, out, false);
+            return;
+         }
          span_from(s, mm, L, out.from, out.to);
       } else {
          // bounded restart loop, api_internal_m.F90:108-155

@@ -82,7 +82,8 @@ def gen_case(rng):
 # texts: the pattern's own literal characters repeated and overlapped, so that several prefix occurrences, overlapping ones and matches that do NOT start at an
 # occurrence all happen.
 CHECK_SHAPES = [r"(}[abc]){2}\d*c{2,}", r"(\t{3}[a-z]){2}", r" {3}\\{2}[a-z]{2,}", r"(ab|abc)x", r"(a|ab)(c|bcd)", r"a?ab+", r"(aa|a)b", r"x*yz", r"(ab)*abc", r"a{1,2}ab",
-                r"(-|--)a", r"(\t\t|\t)x+", r"aa(a|b)", r"(xy){1,2}z", r"ab?ab", r"(zz|z)\d", r"\d?12", r"(ab){2,}c?", r"a*aab", r"(b|)aba"]
+                r"(-|--)a", r"(\t\t|\t)x+", r"aa(a|b)", r"(xy){1,2}z", r"ab?ab", r"(zz|z)\d", r"\d?12", r"(ab){2,}c?", r"a*aab", r"(b|)aba",
+                r"A{1,2}bb", r"(ab{2}){1,2}-a{2}", r"a{1,2}b{2}", r"ab+c{0,1}bc", r"x(ab|b)b", r"(ab{2}){1,2}-α{2}", r"\x41{1,2}α{2}"]   # (the last rows: suffix literals the proof does not cover)
 _info = None
 
 
