@@ -92,3 +92,36 @@ def test_packed_results_and_batch_ends(fx):
                 f, a, b = fx.unpack_results(buf, n, L, spans=True)
                 torch.cuda.synchronize()
                 assert np.array_equal(f.cpu().numpy(), of) and np.array_equal(a.cpu().numpy(), oa) and np.array_equal(b.cpu().numpy(), ob), (pat, L, n, prog.last_path())
+
+
+def test_bordered_prefix_and_overlapping_occurrences_spelled_with_overlong_bytes(fx):
+    """Round 6 fix (found by tests/support/fuzz_prefilter.py FX_FUZZ_UTF8=1, a bug since round 3's overlap sink): a bordered prefix literal (`aa[bc]`, `αα[^a]*`) whose
+    occurrences overlap at the SYMBOL level while the literal occurs nowhere byte-wise -- possible only through non-canonical encodings (`a`, `C1 A1`, `a`, `b`).  The
+    reference's INDEX finds no occurrence and falls back to brute force (src/api_internal_m.F90:76-81); the product's row procedure used its reverse automaton for
+    that fallback -- the one composed with the overlap detector, which stops recording hits in its absorbing state -- and reported a later start.  It now takes the
+    restart loop with the forward automaton there.  Rows of several lengths (span kernel's follow-up, one-launch kernel, long rows), spans and flags only."""
+    rng = np.random.default_rng(61)
+    seeds = [b"a\xc1\xa1ab", b"\xc1\xa1aab", b"aa\xc1\xa1b", b"a\xc1\xa1\xc1\xa1c", b"\xce\xb1\xe8\x83\xa1\xce\xb1\xe0\x8e\xb1\xce\xb1", b"\xce\xb1\xe0\x8e\xb1\xce\xb1x",
+             b"\xe0\x8e\xb1\xce\xb1\xce\xb1", b"-\xc0\xad-a", b"\xc0\xad--ab", b"aab", b"aaab", b"\xce\xb1\xce\xb1\xce\xb1", b"x"]
+    alpha = np.frombuffer(b"abcx- ", dtype=np.uint8)
+    for L in (16, 64, 100, 256, 400):
+        n = 64 * 6 + 3
+        rows = alpha[rng.integers(0, len(alpha), size=(n, L))].copy()
+        for i in range(n):
+            sd = np.frombuffer(seeds[i % len(seeds)], dtype=np.uint8)
+            if len(sd) <= L:
+                off = int(rng.integers(0, L - len(sd) + 1))
+                rows[i, off:off + len(sd)] = sd
+        import torch
+        dev_rows = torch.from_numpy(rows).cuda()
+        for pat in (r"aa[bc]", r"αα[^a]*", r"--[a-z]+", r"aa.*b"):
+            of, oa, ob = oracle_lib.batch(2, pat.encode(), rows, NT)
+            prog = fx.Program(pat, fx.OP_SEARCH)
+            f, a, b = prog.match_device(dev_rows)
+            torch.cuda.synchronize()
+            f, a, b = f.cpu().numpy(), a.cpu().numpy(), b.cpu().numpy()
+            bad = np.flatnonzero((f != of) | (a != oa) | (b != ob))
+            assert bad.size == 0, (pat, L, int(bad[0]), bytes(rows[bad[0]]), int(f[bad[0]]), int(a[bad[0]]), int(b[bad[0]]), int(of[bad[0]]), int(oa[bad[0]]), int(ob[bad[0]]))
+            f2, _, _ = prog.match_device(dev_rows, spans=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(f2.cpu().numpy(), of), (pat, L, "flags only")

@@ -11,7 +11,7 @@ for sh in $SHAPES; do
   OUT=$REPO/gpurun_out/prof_${TAG}_$sh
   rm -rf $OUT   # (scratch of an earlier call with the same tag: its CSVs would sit next to this run's)
   mkdir -p $OUT
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 30 --warmup 10 > $OUT/bench_under_rocprof.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps ${FX_PROF_STEPS:-30} --warmup ${FX_PROF_WARMUP:-10} > $OUT/bench_under_rocprof.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/tools/bench_shapes.py --shape $sh --steps 3 --warmup 1 > $OUT/pmc_write.log 2>&1
   if [ "${3:-}" = "sq" ]; then   # issue / wait / LDS-conflict counters and instruction counts of the dominant kernel (two more passes)
