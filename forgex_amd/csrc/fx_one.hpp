@@ -710,8 +710,17 @@ __device__ __forceinline__ uint32_t fx_spec_forward(const uint4* tile, const uin
    uint4 w0 = cellc(0u), w1 = cellc(1u), w2 = cellc(2u);
    lookup8(fa, w0.x, w0.y, tabA);
    lookup8(fb, w0.z, w0.w, tabA);
-#pragma unroll 1
-   for (uint32_t c = 0; c <= (uint32_t)CH; c += 3u) {   // six groups = chunks c, c + 1, c + 2 (chunk CH = the end-of-row column: NUL, then KILL symbols)
+   // Whole trips of three text chunks (six groups), then the CH % 3 chunks left, then ONE group of the end-of-row column (chunk CH: the NUL, then
+   // KILL symbols -- no lane outlives it).  (Round 6: the loop used to run ceil((CH + 1) / 3) whole trips with the chunk index clamped to the
+   // end-of-row column -- config 4's 192-byte rows, whose matches mostly reach the row's end: 30 groups of lookups for 24 groups of text, a
+   // sixth of the kernel's LDS instructions, which are what bounds it: profiles/r06_cfg4_phases.md.)
+   constexpr uint32_t TRIPS = (uint32_t)CH / 3u, REST = (uint32_t)CH % 3u;
+   bool alive = true;
+   // in flight on entry of a trip: fa, fb = the two groups of chunk c (w0), w1 / w2 = chunks c + 1 / c + 2.  (END: the trip before the end-of-row
+   // column -- CH % 3 == 0, the last trip --: the column's second half is never walked, its lookups are not issued.  A trip of its own at
+   // compile time: a run-time guard around those eight lookups kept both versions of the buffer live -- 232 -> 266 registers, one wave per SIMD.)
+   auto trip = [&](auto end_, const uint32_t c) {
+      constexpr bool END = decltype(end_)::value;
       lookup8(fc, w1.x, w1.y, tabA);
       __builtin_amdgcn_sched_barrier(0);
       step8(fa, 2u * c);
@@ -722,12 +731,12 @@ __device__ __forceinline__ uint32_t fx_spec_forward(const uint4* tile, const uin
       step8(fb, 2u * c + 1u);
       __builtin_amdgcn_sched_barrier(0);
       lookup8(fb, w2.x, w2.y, tabA);
-      w1 = cellc(c + 4u);
+      if (!END) w1 = cellc(c + 4u);
       __builtin_amdgcn_sched_barrier(0);
       step8(fc, 2u * c + 2u);
       __builtin_amdgcn_sched_barrier(0);
       lookup8(fc, w2.z, w2.w, tabA);
-      w2 = cellc(c + 5u);
+      if (!END) w2 = cellc(c + 5u);
       __builtin_amdgcn_sched_barrier(0);
       step8(fa, 2u * c + 3u);
       __builtin_amdgcn_sched_barrier(0);
@@ -735,11 +744,40 @@ __device__ __forceinline__ uint32_t fx_spec_forward(const uint4* tile, const uin
       __builtin_amdgcn_sched_barrier(0);
       step8(fb, 2u * c + 4u);
       __builtin_amdgcn_sched_barrier(0);
-      lookup8(fb, w0.z, w0.w, tabA);
+      if (!END) lookup8(fb, w0.z, w0.w, tabA);
       __builtin_amdgcn_sched_barrier(0);
       step8(fc, 2u * c + 5u);
       __builtin_amdgcn_sched_barrier(0);
-      if (__builtin_amdgcn_ballot_w64(cur != 0 && (SPANS || gl2 == 0xFFFFFFFFu)) == 0) break;
+      alive = __builtin_amdgcn_ballot_w64(cur != 0 && (SPANS || gl2 == 0xFFFFFFFFu)) != 0;
+   };
+   constexpr uint32_t PLAIN = (REST == 0u && TRIPS >= 1u) ? TRIPS - 1u : TRIPS;   // trips of the rolled loop
+#pragma unroll 1
+   for (uint32_t c = 0; c < 3u * PLAIN; c += 3u) {
+      trip(std::false_type{}, c);
+      if (!alive) break;
+   }
+   if constexpr (PLAIN != TRIPS) {
+      if (alive) trip(std::true_type{}, 3u * PLAIN);
+   }
+   if (alive) {   // c = 3 TRIPS: fa (and, for a text chunk, fb) hold chunk c's groups, w1 / w2 = chunks c + 1 / c + 2 (clamped to the end-of-row column)
+      constexpr uint32_t c = 3u * TRIPS;
+      if constexpr (REST == 0) {
+         step8(fa, 2u * c);
+      } else if constexpr (REST == 1) {
+         lookup8(fc, w1.x, w1.y, tabA);
+         step8(fa, 2u * c);
+         step8(fb, 2u * c + 1u);
+         if (__builtin_amdgcn_ballot_w64(cur != 0 && (SPANS || gl2 == 0xFFFFFFFFu)) != 0) step8(fc, 2u * c + 2u);
+      } else {
+         lookup8(fc, w1.x, w1.y, tabA);
+         step8(fa, 2u * c);
+         lookup8(fa, w1.z, w1.w, tabA);
+         step8(fb, 2u * c + 1u);
+         lookup8(fb, w2.x, w2.y, tabA);
+         step8(fc, 2u * c + 2u);
+         step8(fa, 2u * c + 3u);
+         if (__builtin_amdgcn_ballot_w64(cur != 0 && (SPANS || gl2 == 0xFFFFFFFFu)) != 0) step8(fb, 2u * c + 4u);
+      }
    }
    if (!SPANS) return gl2 != 0xFFFFFFFFu ? 3u : 0u;
    uint32_t mm = 0;

@@ -9,5 +9,5 @@ cat > $TMP <<EOT
 template __global__ void fx_search_one<$ARGS>(const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint8_t*);
 const FxEnv& fx_env() { static FxEnv e{}; return e; }
 EOT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $EXTRA -I$(dirname $0)/../forgex_amd/csrc --cuda-device-only -Rpass-analysis=kernel-resource-usage -c $TMP -o /dev/null 2>&1 | grep -E "Function Name|VGPRs:|SGPRs Spill|Occupancy|ScratchSize|LDS Size" | sed 's/.*remark: *//'
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $EXTRA -I$(dirname $0)/../forgex_amd/csrc --cuda-device-only -Rpass-analysis=kernel-resource-usage -c $TMP -o /dev/null 2>&1 | grep -E "Function Name|VGPRs:|AGPRs:|VGPRs Spill|SGPRs Spill|Occupancy|ScratchSize|LDS Size" | sed 's/.*remark: *//'
 rm -f $TMP
