@@ -1,6 +1,6 @@
 // fx_search_multi: m patterns against the same rows in ONE pass over the rows (the reference's operators are
 // elemental over `pattern` too, src/forgex.F90:74,163).  A tile of 64 rows is staged in LDS once; the tables of all m patterns
-// (8-state v_perm scheme: 4 KB each) sit in LDS next to the tiles, and the wave that owns the tile scans it once per pattern
+// (8-state v_perm scheme or, round 6, the nibble scheme of automata with 9..16 states: 4 KB each) sit in LDS next to the tiles, and the wave that owns the tile scans it once per pattern
 // (fx_scan_tile), writing pattern p's results to flags[p*n + row] (from / to likewise).  HBM traffic: the rows once plus m result
 // sets, instead of m times the rows.  Patterns that have byte-level tables in the nibble format (FXP_F_BYTE_W16; bsch 2, or 3 with the
 // forward automaton in the v_perm format) bring them along (8 KB per pattern instead of 4): a tile with a byte >= 0x80 is scanned for
@@ -27,6 +27,7 @@ struct FxMultiArgs {
    uint32_t bsch[FX_MULTI_MAX];         // 0: no byte-level tables in this pass; 2: nibble tables; 3: nibble backwards, v_perm forwards (FXP_F_BYTE_A8)
    uint32_t any_bytes;                  // some pattern has bsch != 0: the table area holds 8 KB per pattern (else 4 KB)
    uint32_t inq[FX_MULTI_MAX];          // 1: exception rows of this pattern's byte-level scan are finished INSIDE this launch (its class-level tables decode UTF-8)
+   uint32_t sch[FX_MULTI_MAX];          // class-level table scheme of each: 0 = 8-state v_perm tables, 2 = nibble tables (9..16 states; round 6) -- 4 KB of LDS per pattern either way
    uint32_t m;
 };
 
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
    }
    for (uint32_t p = 0; p < a.m; ++p) {
       const FxpHeader* h = reinterpret_cast<const FxpHeader*>(a.blob[p]);
-      const uint2* gR = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastR);
-      const uint2* gA = reinterpret_cast<const uint2*>(a.blob[p] + h->off_fastA);
+      const uint2* gR = reinterpret_cast<const uint2*>(a.blob[p] + (a.sch[p] == 2u ? h->off_w16R : h->off_fastR));
+      const uint2* gA = reinterpret_cast<const uint2*>(a.blob[p] + (a.sch[p] == 2u ? h->off_w16A : h->off_fastA));
       const uint2* bR = reinterpret_cast<const uint2*>(a.blob[p] + h->off_bw16R);
       const uint2* bA = reinterpret_cast<const uint2*>(a.blob[p] + (a.bsch[p] == 3u ? h->off_b8A : h->off_bw16A));
       for (uint32_t i = threadIdx.x; i < 256u; i += 64u * WPB) {
@@ -206,8 +207,13 @@ __global__ __launch_bounds__(64 * WPB) void fx_search_multi(const uint8_t* __res
                                                                                                        a.fpb[p], row, row_ok, true, except, emit);
             }
          }
-         if (!bytes_here)
-            (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
+         if (!bytes_here) {
+            if (a.sch[p] == 2u)   // (automata of 9..16 states: the nibble tables, one 64-bit shift per byte -- the same 4 KB of LDS)
+               (void)fx_scan_tile<CH, SPANS, RAGGED, 2, false, false, false, true, true>(sc, reinterpret_cast<const fx_nib*>(tR), reinterpret_cast<const fx_nib*>(tA), nullptr,
+                                                                                         nullptr, a.fp[p], row, row_ok, true, except, emit);
+            else
+               (void)fx_scan_tile<CH, SPANS, RAGGED, 0, false, false, false, true, true>(sc, tR, tA, nullptr, nullptr, a.fp[p], row, row_ok, true, except, emit);
+         }
          // rows these tables cannot answer: finished inside the launch when the pattern's class-level tables can decode them (queued;
          // the queue is drained after this tile's last pattern when it would not take them), else marked and listed for the pattern's
          // row-level fix-up (one atomic per tile that has any)

@@ -24,7 +24,7 @@
 // loops, and a dozen getenv per enqueue is host time on their path.  fxamd_reload_env() (C ABI, tests only) reads them again.
 struct FxEnv {
    bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, no_span, no_pack_first, no_adapt, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
-      host_register;
+      host_register, multi_w16;
    int64_t slice_rows;                                      // rows per enqueue (a multiple of 64)
    int one_grid, one_round_mb, one_blocks, half_rounds, half_sch, span_lens;     // launch-grid experiments (0 = the built-in rule)
 };

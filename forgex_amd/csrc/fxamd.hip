@@ -88,6 +88,7 @@ static void env_load() {
    e.multi_inq = on("FXAMD_MULTI_INQ");
    e.multi_serial = on("FXAMD_MULTI_SERIAL");
    e.host_register = on("FXAMD_HOST_REGISTER");
+   e.multi_w16 = on("FXAMD_MULTI_W16");   // automata of 9..16 states (nibble tables) join the shared many-pattern pass (built and tested in round 6, OFF by default: measured no faster, see fxamd_match_multi_device)
    {
       const char* v = std::getenv("FXAMD_SLICE_ROWS");
       int64_t r = v ? std::atoll(v) & ~int64_t(63) : int64_t(1) << 30;
@@ -1727,9 +1728,15 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
       for (int32_t i = 0; i < m; ++i) {
          const FxpHeader& h = progs[i]->prog.hdr();
          if (first_of[(size_t)i] == i && progs[i]->prog.status == 0 && (h.mode == FXP_MODE_SEARCH_ENGINE || h.mode == FXP_MODE_SEARCH_LITERAL) && !(h.flags & FXP_F_NFA_SIM) &&
-             fast_scheme(h, d_rows, row_len) == 0 && !(h.flags & FXP_F_PREFIX_CHECK))   // (prefix-check programs: the one-launch kernel only, see fast_scheme)
+             (fast_scheme(h, d_rows, row_len) == 0 || (fast_scheme(h, d_rows, row_len) == 2 && fx_env().multi_w16)) &&
+             !(h.flags & FXP_F_PREFIX_CHECK))   // (prefix-check programs: the one-launch kernel only, see fast_scheme)
             fused.push_back(i);
       }
+   // Automata of 9..16 states (scheme 2, the nibble tables: the same 4 KB of LDS per pattern) can share the pass too (round 6, FXAMD_MULTI_W16=1) and
+   // do NOT by default: measured in one allocation (tools/exp_multi.py, gpurun call r06_m4) the shared pass is no faster with them -- 12.5 M x 128 B,
+   // six patterns of which three on the nibble tables: 2.16-2.20 ms shared against 2.24-2.25 ms (their own span-kernel pipelines, last_path 20);
+   // three nibble patterns alone 1.08-1.11 against 1.06 ms; 16 M x 64 B: 1.54 against 1.48 ms and 0.85 against 0.71 ms -- a lane that owns a
+   // span of whole short rows beats the shared pass's tile of 64 rows by more than the second read of the rows costs.
    // The shared pass pays where a tile is small enough for full occupancy next to m patterns' tables -- rows of up to 128 bytes: 6 patterns
    // over 100 M x 128 B 15.4 ms against 16.9 ms pattern by pattern (tools/exp_multi.py, gpurun call r03_c11).
    // Rows longer than 128 bytes: one pipeline per pattern.  The shared pass LOST there in every variant measured over rounds 2-3 (six
@@ -1744,7 +1751,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
    for (int32_t i : fused) {
       // (ragged rows: fx_search_multi still pads them with the inert symbol 255, which byte-level tables do not have -- the
       //  pad-free scheme of round 4 is the one-launch kernel's)
-      const int ob = row_len == 16 * tile_chunks(row_len) ? one_bytes_scheme(progs[i]->prog.hdr(), d_rows, row_len, 0) : 0;
+      const int ob = row_len == 16 * tile_chunks(row_len) ? one_bytes_scheme(progs[i]->prog.hdr(), d_rows, row_len, fast_scheme(progs[i]->prog.hdr(), d_rows, row_len)) : 0;
       obs[(size_t)i] = (ob == 2 || ob == 3) && progs[i]->prog.hdr().mode == FXP_MODE_SEARCH_ENGINE && !fx_env().multi_no_bytes ? ob : 0;
       any_bytes = any_bytes || obs[(size_t)i] != 0;
    }
@@ -1799,7 +1806,8 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
          }
          ++prepared;
          a.blob[a.m] = blobs[k - g0];
-         a.fp[a.m] = params_of(p->prog.hdr(), 0, false);
+         a.sch[a.m] = (uint32_t)fast_scheme(p->prog.hdr(), d_rows, row_len);   // (0 or 2: see the `fused` filter)
+         a.fp[a.m] = params_of(p->prog.hdr(), (int)a.sch[a.m], false);
          a.slot[a.m] = (uint32_t)slot;
          a.ctr[a.m] = shs[k - g0].ctr;
          a.worklist[a.m] = shs[k - g0].worklist;
@@ -1811,7 +1819,7 @@ int fxamd_match_multi_device(fxamd_program* const* progs, int32_t m, const uint8
             // (finishing the exception rows inside the shared pass -- one mixed-pattern queue per wave -- is built and tested but OFF: a
             //  drained row decodes through its pattern's class map in GLOBAL memory, there is no LDS left for six of them, and the
             //  pass got slower: 0.898 against 0.750 ms for 6 UTF-8 patterns on config 4's rows; FXAMD_MULTI_INQ=1 turns it on)
-            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && fx_env().multi_inq) {
+            if ((p->prog.hdr().flags & FXP_F_FAST_UTF8) && a.sch[a.m] == 0u && fx_env().multi_inq) {
                a.inq[a.m] = 1u;
                shs[k - g0].exc_in_shared = true;
             }

@@ -198,6 +198,7 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * kernel on a stream under hipGraph capture); rows longer than 256 bytes on the chain tables: 7 or 5 / 6, walked in 128-byte segments.
  * (Environment hooks for the tests: FXAMD_NO_BYTE_DFA, FXAMD_NO_W16, FXAMD_MULTIPASS, FXAMD_NO_HALF, FXAMD_NO_MULTI, FXAMD_NO_CACHE,
  * FXAMD_FORCE_GENERAL, FXAMD_NO_A8, FXAMD_NO_SPEC, FXAMD_NO_TINY, FXAMD_NO_ADAPT, FXAMD_MULTI_NO_BYTES, FXAMD_MULTI_INQ, FXAMD_MULTI_SERIAL,
+ * FXAMD_MULTI_W16 (fxamd_match_multi_device: 9..16-state programs join the shared first pass on their nibble tables; off by default: measured no faster),
  * FXAMD_NO_SPAN (paths 18 / 20 off: the one-launch kernel), FXAMD_SPAN_LENS (bit mask, default 111: bits 0..3 = rows that get 128 / 64 / 32 / 16
  * bytes of LDS take path 18; bit 4 = candidate-list driver programs too at rows of up to 64 bytes; bit 5 = ragged rows, any length 2..127 that
  * is not one of the four; bit 6 = path 20),

@@ -646,6 +646,56 @@ def test_many_patterns_over_one_batch(fx, shape, monkeypatch):
         assert np.array_equal(f2[i].cpu().numpy(), of), (shape, p, "flags only")
 
 
+@pytest.mark.parametrize("L", [128, 64, 100, 16])
+def test_many_patterns_nibble_tables_share_the_pass(fx, L, monkeypatch):
+    """Round 6: automata of 9..16 states (the nibble tables: `\\d{3}-\\d{4}`, an e-mail pattern, ...) CAN take part in the shared first pass of
+    fxamd_match_multi_device next to the 8-state ones (last_path 15; same 4 KB of LDS per pattern) -- FXAMD_MULTI_W16=1; off by default: measured
+    no faster than their own span-kernel pipelines (fxamd.hip).  Aligned and ragged rows, ASCII and mixed with valid / broken UTF-8 (tiles
+    deferred to each pattern's own follow-up); every result against the oracle, against one pattern at a time, and against the default
+    dispatch (the hook is live: more patterns report the shared pass with it)."""
+    import torch
+    from forgex_amd import synth
+    dev = torch.device("cuda")
+    pats = [rb"\d{3}-\d{4}", rb"[a-z]+\d+", rb"[a-z0-9._]+@[a-z0-9]+\.[a-z]+", rb"(ab|cd)+\d", rb"[a-c]{2}[0-9]{3}x", rb"zz+", rb"\d\d:\d\d:\d\d"]
+    n = 24000
+    flat = synth.batch("cfg3", 0, (n * L + 255) // 256, dev).reshape(-1)[: n * L]
+    rows = flat.reshape(n, L).contiguous().clone()
+    rows[5::17, :15] = torch.tensor(list(b"555-1234 a@b.cc"), dtype=torch.uint8, device=dev)
+    rows[3::29, L // 2] = 0xE3            # a lone lead byte: broken UTF-8 in some tiles
+    rows[7::31, 0:2] = torch.tensor([0xCE, 0xB1], dtype=torch.uint8, device=dev)   # valid UTF-8 in others
+    progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
+    singles = []
+    wide = []
+    for p in progs:
+        singles.append(tuple(t.clone() for t in p.match_device(rows)))
+        torch.cuda.synchronize()
+        wide.append(p.last_path() in (5, 6, 7, 8, 11, 14, 20))   # the nibble / chain pipelines of a single call
+    assert sum(wide) >= 2, [p.last_path() for p in progs]
+    f0, a0, b0 = fx.match_many(progs, rows)   # the default dispatch: the shared pass for the 8-state programs only
+    torch.cuda.synchronize()
+    paths0 = [p.last_path() for p in progs]
+    monkeypatch.setenv("FXAMD_MULTI_W16", "1")
+    f, a, b = fx.match_many(progs, rows)
+    torch.cuda.synchronize()
+    paths = [p.last_path() for p in progs]
+    assert sum(1 for w, lp in zip(wide, paths) if w and lp == 15) >= 2, paths
+    assert sum(1 for lp in paths0 if lp == 15) < sum(1 for lp in paths if lp == 15), (paths, paths0)
+    assert torch.equal(f, f0) and torch.equal(a, a0) and torch.equal(b, b0)
+    f2, _, _ = fx.match_many(progs, rows, spans=False)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("FXAMD_MULTI_W16", raising=False)
+    k = 6000
+    host = rows[:k].cpu().numpy()
+    for i, p in enumerate(pats):
+        sf, sa, sb = singles[i]
+        assert torch.equal(f[i], sf) and torch.equal(a[i], sa) and torch.equal(b[i], sb), (L, p, paths[i])
+        assert torch.equal(f2[i], sf), (L, p, "flags only")
+        of, oa, ob = oracle_lib.batch(2, p, host, NT)
+        assert np.array_equal(f[i][:k].cpu().numpy(), of) and np.array_equal(a[i][:k].cpu().numpy(), oa) and np.array_equal(b[i][:k].cpu().numpy(), ob), (L, p)
+        if i < 3:   # (the planted phone number, word + digits, e-mail address)
+            assert int(of.sum()) > 0, p
+
+
 def test_many_patterns_utf8_tiles_in_the_shared_pass(fx, monkeypatch):
     """fx_search_multi brings the patterns' byte-level tables along (nibble format; forward automaton in the v_perm format where the
     program has it): tiles with bytes >= 0x80 are scanned in the shared pass instead of being deferred to a pass per pattern.  Same

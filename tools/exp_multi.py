@@ -17,6 +17,9 @@ sets = {
     "6 mixed (test_many_patterns)": [rb"[a-z]+\d+", rb"\d{3}-\d{4}", rb"zz+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d"],
     "6 on the 8-state tables": [rb"[a-z]+\d+", rb"[0-9]$", b"needle", rb"(ab|cd)+\d", rb"x[yz]+\d", rb"[a-f]+ [g-z]"],
     "2 on the 8-state tables": [rb"[a-z]+\d+", rb"(ab|cd)+\d"],
+    # (round 6: automata of 9..16 states can share the pass too -- FXAMD_MULTI_W16=1; by default one pipeline each)
+    "6 with three on the nibble tables": [rb"[a-z]+\d+", rb"\d{3}-\d{4}", rb"[a-z0-9._]+@[a-z0-9]+\.[a-z]+", rb"\d\d:\d\d:\d\d", b"needle", rb"(ab|cd)+\d"],
+    "3 on the nibble tables": [rb"\d{3}-\d{4}", rb"[a-z0-9._]+@[a-z0-9]+\.[a-z]+", rb"\d\d:\d\d:\d\d"],
 }
 if cfg == "cfg4":   # UTF-8 rows: the shared pass scans them with the patterns' byte-level tables (FXAMD_MULTI_NO_BYTES=1: defers them instead)
     sets["6 UTF-8 patterns"] = [synth.PATTERNS["cfg4"].encode(), "[ぁ-ん]+".encode(), "[α-ω][ぁ-ん]".encode(), "ん[α-ω]+".encode(), rb"[a-z]+",
@@ -38,8 +41,8 @@ def rate(fn, reps=20):
 single = fx.Program(synth.PATTERNS[cfg].encode() if cfg == "cfg4" else rb"[a-z]+\d+", fx.OP_SEARCH)
 out1 = single.match_device(rows)
 t1 = rate(lambda: single.match_device(rows, out=out1))
-print("%s %d rows: single pattern %.3f ms (path %d)  [FXAMD_NO_MULTI=%s FXAMD_MULTI_NO_BYTES=%s]" % (
-    cfg, n, t1 * 1e3, single.last_path(), os.environ.get("FXAMD_NO_MULTI", ""), os.environ.get("FXAMD_MULTI_NO_BYTES", "")), flush=True)
+print("%s %d rows: single pattern %.3f ms (path %d)  [FXAMD_NO_MULTI=%s FXAMD_MULTI_NO_BYTES=%s FXAMD_MULTI_W16=%s]" % (
+    cfg, n, t1 * 1e3, single.last_path(), os.environ.get("FXAMD_NO_MULTI", ""), os.environ.get("FXAMD_MULTI_NO_BYTES", ""), os.environ.get("FXAMD_MULTI_W16", "")), flush=True)
 for name, pats in sets.items():
     progs = [fx.Program(p, fx.OP_SEARCH) for p in pats]
     tm = rate(lambda: fx.match_many(progs, rows), reps=10)
