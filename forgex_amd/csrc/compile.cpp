@@ -1302,6 +1302,23 @@ Program compile_from_nfa(const Nfa& nfa, const Literals& lit, int op, const Limi
    }
    h.off_fastA = bl.put(fa.data(), fa.size());
    h.off_fastR = bl.put(fr.data(), fr.size());
+   // FXP_F_R_LATCH (round 6): R with <= 4 states, doubled -- state s + 4 = "state s, and a hit state has been entered since the latch was last cleared".  From
+   // an unlatched state the step goes to fr's destination, latched when that destination is a hit state; from a latched state to fr's destination, latched.
+   // The kernels that use it (half-row first pass, span kernel) clear the latch (state & 3) at every 8-byte group's start: the group's last state then says
+   // whether any of its eight states was a hit -- the running maximum over them (v_max3_u32, one per two bytes) is gone.
+   h.off_fastRL = 0;   // (no latched format: the flag says so)
+   if (fast && !is_match && R.n <= 4 && !overlap_sink) {
+      std::vector<uint8_t> frl(256 * 8, 0);
+      const int hitmin = static_cast<int>(h.fast_hitR_min);
+      for (int sym = 0; sym < 256; ++sym)
+         for (int s = 0; s < 4; ++s) {
+            const int d = fr[static_cast<size_t>(sym) * 8 + s];   // (0 for s >= R.n and for symbols without a row: the dead / start state as in fr)
+            frl[static_cast<size_t>(sym) * 8 + s] = static_cast<uint8_t>(d >= hitmin && d < R.n ? d + 4 : d);
+            frl[static_cast<size_t>(sym) * 8 + 4 + s] = static_cast<uint8_t>(d + 4);
+         }
+      h.off_fastRL = bl.put(frl.data(), frl.size());
+      h.flags |= FXP_F_R_LATCH;
+   }
 
    // ---- 8. chain tables: any automaton whose class-indexed tables fit 16-bit row offsets (LDS chain kernel) ---------------
    {
@@ -1653,7 +1670,7 @@ int validate_blob(const uint8_t* b, size_t size) {
    const uint32_t known = FXP_F_INIT_ACCEPTING | FXP_F_PREFILTER | FXP_F_HAS_SUFFIX | FXP_F_FAST_OK | FXP_F_HAS_R | FXP_F_MATCH_LITERAL |
                           FXP_F_FAST_UTF8 | FXP_F_NFA_SIM | FXP_F_CHAIN_OK | FXP_F_CHAIN_UTF8 | FXP_F_RAW_BYTES | FXP_F_RAGGED_OK | FXP_F_BYTE_DFA |
                           FXP_F_W16_OK | FXP_F_W16_UTF8 | FXP_F_BYTE_W16 | FXP_F_PREFIX_NECESSARY | FXP_F_OVERLAP_SINK | FXP_F_BYTE_A8 | FXP_F_SPEC_FWD | FXP_F_NEEDS_NONASCII |
-                          FXP_F_PREFIX_CHECK | FXP_F_SUFFIX_CHECK;
+                          FXP_F_PREFIX_CHECK | FXP_F_SUFFIX_CHECK | FXP_F_R_LATCH;
    if (h.flags & ~known) return 5;
    // chain-format table: rows of (ncls + 3) uint16, entries = row offsets of the same table; the 256-entry map holds 2 * column
    auto chain_ok = [&](uint32_t off_cls, uint32_t off_T, uint32_t T_bytes, uint32_t ncls, uint32_t row_bytes, bool final_col) {
@@ -1732,6 +1749,15 @@ int validate_blob(const uint8_t* b, size_t size) {
    if ((h.flags & FXP_F_PREFIX_CHECK) && (!(h.flags & FXP_F_PREFILTER) || h.mode != FXP_MODE_SEARCH_ENGINE || h.len_prefix < 1u || h.len_prefix > 32u ||
                                           (h.flags & (FXP_F_BYTE_DFA | FXP_F_FAST_UTF8 | FXP_F_CHAIN_UTF8 | FXP_F_W16_UTF8)))) return 78;
    if ((h.flags & FXP_F_FAST_OK) && (!inside(h.off_fastA, 2048) || !inside(h.off_fastR, 2048))) return 50;
+   if (h.flags & FXP_F_R_LATCH) {   // the latched format of R: <= 4 base states, entries 0..7, a latched state never unlatches
+      if (!(h.flags & FXP_F_FAST_OK) || h.mode != FXP_MODE_SEARCH_ENGINE || (h.flags & FXP_F_OVERLAP_SINK) || nR > 4 || !inside(h.off_fastRL, 2048) || h.fast_hitR_min > 4u ||
+          h.fast_R_start > 3u)
+         return 80;
+      for (uint32_t i = 0; i < 2048; ++i) {
+         const uint8_t v = b[h.off_fastRL + i];
+         if (v > 7u || ((i & 7u) >= 4u && v < 4u)) return 81;
+      }
+   }
    if ((h.flags & FXP_F_FAST_UTF8) && (!(h.flags & FXP_F_FAST_OK) || nc > 126)) return 51;
    if (h.flags & FXP_F_CHAIN_OK) {
       if (nc > 126) return 52;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void fx_span_group(uint32_t& lo, uint32_t& hi, const 
 // Right-to-left pass over ONE row (chunks c0 .. c0 + NCH - 1 of the lane's own cells): the half-row kernel's lean loop (fx_tile.hpp,
 // FX_HALF4: running maximum instead of the group's eight states, one chunk of LDS prefetch).  gsel = the leftmost 8-byte group that
 // holds a hit (0xFFFFFFFF: none), esel = the state entering it, state = the state after the leading NUL.
-template <int RL, int SCH, bool RAG, class TabT>
+template <int RL, int SCH, bool RAG, bool LATCH = false, class TabT>
 __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t lane, const uint32_t c0, const TabT* __restrict__ tabR, const uint8_t* TRp,
                                              const FastParams& fp, const FxTail& T_, uint32_t& na, uint32_t& gsel, uint32_t& esel, uint32_t& state) {
    using F = typename FxF<SCH>::type;
@@ -140,16 +140,18 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
          if (T.nb > 8u) {
             lookup8(fa, wp.z, wp.w, tabR);
             const uint32_t entry = state;
-            const uint32_t mx = chain8_back_n(fa, state, TRp, T.nb - 8u);
+            const uint32_t mx = chain8_back_n<F, LATCH>(fa, state, TRp, T.nb - 8u);
             gsel = mx >= fp.hit_min ? 2u * T.kt + 1u : gsel;
             esel = mx >= fp.hit_min ? entry : esel;
+            if (LATCH) state &= FX_LATCH_MASK;
          }
          lookup8(fb, wp.x, wp.y, tabR);
          const uint32_t entry = state;
          const uint32_t nv0 = T.nb < 8u ? T.nb : 8u;
-         const uint32_t mx = nv0 == 8u ? chain8_back<F, true>(fb, state, TRp) : chain8_back_n(fb, state, TRp, nv0);
+         const uint32_t mx = nv0 == 8u ? chain8_back<F, true, LATCH>(fb, state, TRp) : chain8_back_n<F, LATCH>(fb, state, TRp, nv0);
          gsel = mx >= fp.hit_min ? 2u * T.kt : gsel;
          esel = mx >= fp.hit_min ? entry : esel;
+         if (LATCH) state &= FX_LATCH_MASK;
       }
       if (T.kt != 0u) {
          uint4 wk = tile[tile_cell(lane, c0 + T.kt - 1u)];
@@ -162,9 +164,10 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
                __builtin_amdgcn_sched_barrier(0);
                {
                   const uint32_t entry = state;
-                  const uint32_t mx = chain8_back<F, true>(fa, state, TRp);
+                  const uint32_t mx = chain8_back<F, true, LATCH>(fa, state, TRp);
                   gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
                   esel = mx >= fp.hit_min ? entry : esel;
+                  if (LATCH) state &= FX_LATCH_MASK;
                   asm volatile("" : "+v"(esel));
                }
                __builtin_amdgcn_sched_barrier(0);
@@ -175,9 +178,10 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
                __builtin_amdgcn_sched_barrier(0);
                {
                   const uint32_t entry = state;
-                  const uint32_t mx = chain8_back<F, true>(fb, state, TRp);
+                  const uint32_t mx = chain8_back<F, true, LATCH>(fb, state, TRp);
                   gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
                   esel = mx >= fp.hit_min ? entry : esel;
+                  if (LATCH) state &= FX_LATCH_MASK;
                   asm volatile("" : "+v"(esel));
                }
                __builtin_amdgcn_sched_barrier(0);
@@ -197,9 +201,10 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
       __builtin_amdgcn_sched_barrier(0);
       {
          const uint32_t entry = state;
-         const uint32_t mx = chain8_back<F, true>(fa, state, TRp);
+         const uint32_t mx = chain8_back<F, true, LATCH>(fa, state, TRp);
          gsel = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gsel;
          esel = mx >= fp.hit_min ? entry : esel;
+         if (LATCH) state &= FX_LATCH_MASK;   // (the latched format of R, program.h FXP_F_R_LATCH: no running maximum in the chain above)
          asm volatile("" : "+v"(esel));   // select now: otherwise every group's entry state stays live until after the loop
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -210,9 +215,10 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
       __builtin_amdgcn_sched_barrier(0);
       {
          const uint32_t entry = state;
-         const uint32_t mx = chain8_back<F, true>(fb, state, TRp);
+         const uint32_t mx = chain8_back<F, true, LATCH>(fb, state, TRp);
          gsel = mx >= fp.hit_min ? (uint32_t)(2 * k) : gsel;
          esel = mx >= fp.hit_min ? entry : esel;
+         if (LATCH) state &= FX_LATCH_MASK;
          asm volatile("" : "+v"(esel));
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -224,7 +230,7 @@ __device__ __forceinline__ void fx_span_back(const uint4* tile, const uint32_t l
 // FINISH of one row per lane; the result in ONE register: flag | from << 8 | to << 16 (from, to <= 128)
 // the row: the row = chunks c0 .. of lane R's cells (R, c0 per lane: a compacted slot, or the lane's own row), g = its
 // leftmost hit group, e = the state entering it, nul = the start is the leading NUL; on = this lane has a row.
-template <int RL, int SCH, int GB, bool RAG, class TabT>
+template <int RL, int SCH, int GB, bool RAG, bool LATCH = false, class TabT>
 __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint8_t* eor, const uint32_t R, const uint32_t c0, const uint32_t g, const uint32_t e,
                                                    const bool nul, const bool on, const TabT* __restrict__ tabR, const TabT* __restrict__ tabA,
                                                    const uint8_t* TRp, const uint8_t* TAp, const FastParams& fp, const uint32_t L) {
@@ -243,10 +249,10 @@ __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint
             const uint32_t nx = fxstep(f[i], st, TRp);
             const bool in_text = g * 8u + (uint32_t)i < L;
             st = in_text ? nx : st;
-            loc = (in_text && nx >= fp.hit_min) ? (uint32_t)i : loc;
+            loc = (in_text && (LATCH ? (nx & FX_LATCH_MASK) >= fp.hit_base : nx >= fp.hit_min)) ? (uint32_t)i : loc;
          } else {
             st = fxstep(f[i], st, TRp);
-            loc = st >= fp.hit_min ? (uint32_t)i : loc;
+            loc = (LATCH ? (st & FX_LATCH_MASK) >= fp.hit_base : st >= fp.hit_min) ? (uint32_t)i : loc;   // (a re-walk: the latch may be set by an earlier step)
          }
       }
       s = nul ? 1u : g * 8u + 2u + loc;
@@ -353,7 +359,7 @@ __device__ __forceinline__ uint32_t fx_span_finish(const uint8_t* tb, const uint
 
 // n_deferred: this call's group of four counter words (words of consecutive calls alternate; [0] "tiles were deferred", [2] / [3] the
 // sample FX_ADAPT_CALLS describes)
-template <int RL, int SCH, bool PACKED, bool RAG>
+template <int RL, int SCH, bool PACKED, bool RAG, bool LATCH = false>
 __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void fx_search_span(const uint8_t* __restrict__ rows, const int64_t n, const uint8_t* __restrict__ prog, const FastParams fp,
                                                           uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                           uint32_t* __restrict__ n_deferred, uint32_t* __restrict__ clear_next, uint8_t* __restrict__ marks,
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void 
    //  fx_search_fast<4, ..., LONG>, gpurun call r05_c14: whole lines instead of split ones, but the dependent LDS read per byte is what that
    //  scheme waits for -- and are not built.)
    static_assert(SCH == 0 || SCH == 2, "class-level v_perm or nibble tables");
+   static_assert(!LATCH || SCH == 0, "the latched format of R is an 8-state v_perm table");
    using S = FxSpan<RL>;
    using F = typename FxF<SCH>::type;
    constexpr int K = S::K, NCH = S::NCH;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void 
       }
    }
    // start-up: the table entries are READ first, then the first tile's loads go out, and only then are the entries written to LDS
-   const uint2 t_r = reinterpret_cast<const uint2*>(prog + (SCH == 2 ? h->off_w16R : h->off_fastR))[threadIdx.x];
+   const uint2 t_r = reinterpret_cast<const uint2*>(prog + (SCH == 2 ? h->off_w16R : (LATCH ? h->off_fastRL : h->off_fastR)))[threadIdx.x];
    const uint2 t_a = reinterpret_cast<const uint2*>(prog + (SCH == 2 ? h->off_w16A : h->off_fastA))[threadIdx.x];
    __builtin_amdgcn_sched_barrier(0);
    uint4 stage[8];
@@ -499,12 +506,12 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void 
       if (!defer_tile) {
          if constexpr (!COMPACT) {
             uint32_t gsel, esel, state;
-            fx_span_back<RL, SCH, RAG>(tile, lane, 0u, tabR, TRp, fp, tl, na, gsel, esel, state);
+            fx_span_back<RL, SCH, RAG, LATCH>(tile, lane, 0u, tabR, TRp, fp, tl, na, gsel, esel, state);
             const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
             sink = fp.inv_on != 0u && state == fp.inv;
             const bool want = hit || nul;
             if (__builtin_amdgcn_ballot_w64(want) != 0)
-               res_set(0, fx_span_finish<RL, SCH, 2, RAG>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, TRp, TAp, fp, Lr));
+               res_set(0, fx_span_finish<RL, SCH, 2, RAG, LATCH>(tb, eor, lane, 0u, hit ? gsel : 0u, esel, nul, want, tabR, tabA, TRp, TAp, fp, Lr));
          } else {
             // every row's backward pass; the rows that need the finish take a slot: lane | row << 6 | hit group << 9 | nul << 13 | entry state << 14.
             // Until its slot is finished a row's result register holds the slot number (bit 31 set).
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void 
                const bool on = base + lane < cnt;
                const uint32_t en = on ? sq[(base + lane) % QCAP] : 0u;
                const uint32_t e8 = en >> 14;
-               const uint32_t r = fx_span_finish<RL, SCH, FX_SPAN_GB, RAG>(tb, eor, en & 63u, ((en >> 6) & 7u) * (uint32_t)NCH, (en >> 9) & 15u, SCH == 0 ? e8 * 0x01010101u : e8,
+               const uint32_t r = fx_span_finish<RL, SCH, FX_SPAN_GB, RAG, LATCH>(tb, eor, en & 63u, ((en >> 6) & 7u) * (uint32_t)NCH, (en >> 9) & 15u, SCH == 0 ? e8 * 0x01010101u : e8,
                                                                            ((en >> 13) & 1u) != 0u, on, tabR, tabA, TRp, TAp, fp, Lr);
                if (on) sq[(base + lane) % QCAP] = r;
             };
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(256, RAG ? FX_SPAN_RAG_WAVES : FX_SPAN_WAVES) void 
                //  are K more live registers, the ones the K = 8 instantiations spilled at four waves per SIMD: computed here, from an opaque copy of the lane)
                uint32_t lane_here = lane;
                if constexpr (K >= 4) asm volatile("" : "+v"(lane_here));
-               fx_span_back<RL, SCH, RAG>(tile, lane_here, (uint32_t)(jr * NCH), tabR, TRp, fp, tl, na, gsel, esel, state);
+               fx_span_back<RL, SCH, RAG, LATCH>(tile, lane_here, (uint32_t)(jr * NCH), tabR, TRp, fp, tl, na, gsel, esel, state);
                const bool hit = gsel != 0xFFFFFFFFu, nul = state >= fp.hit_min;
                sink = sink || (fp.inv_on != 0u && state == fp.inv);
                const bool want = hit || nul;
@@ -724,10 +731,19 @@ hipError_t launch_span(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
    if (!from || !to) return hipErrorInvalidValue;   // (searches with spans only: fxamd.hip, span_kind)
    const bool rag = Lr != (uint32_t)RL;
 #define FX_SPAN_GO(P, R) hipLaunchKernelGGL((fx_search_span<RL, SCH, P, R>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks, Lr)
+#define FX_SPAN_GO_L(P, R) hipLaunchKernelGGL((fx_search_span<RL, SCH, P, R, true>), dim3((unsigned)blocks), dim3(256), 0, st, rows, n, d_blob, fp, flags, from, to, ctr, clear_next, marks, Lr)
    if constexpr (SCH != 0) {   // nibble tables: plain results (fxamd.hip, span_first); round 6: ragged rows too (101-124 VGPRs at four waves per SIMD, no scratch)
-      if (fp.out_mode != 0u) return hipErrorInvalidValue;
+      if (fp.out_mode != 0u || fp.latch != 0u) return hipErrorInvalidValue;
       if (rag) FX_SPAN_GO(false, true);
       else FX_SPAN_GO(false, false);
+   } else if (fp.latch != 0u) {   // the latched format of R (FXP_F_R_LATCH programs: no running maximum in the backward pass)
+      if (fp.out_mode != 0u) {
+         if (rag) FX_SPAN_GO_L(true, true);
+         else FX_SPAN_GO_L(true, false);
+      } else {
+         if (rag) FX_SPAN_GO_L(false, true);
+         else FX_SPAN_GO_L(false, false);
+      }
    } else if (fp.out_mode != 0u) {
       if (rag) FX_SPAN_GO(true, true);
       else FX_SPAN_GO(true, false);
@@ -736,6 +752,7 @@ hipError_t launch_span(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
       else FX_SPAN_GO(false, false);
    }
 #undef FX_SPAN_GO
+#undef FX_SPAN_GO_L
    return hipGetLastError();
 }
 #define FX_SPAN_SIG (const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, hipStream_t, uint8_t*, uint32_t)

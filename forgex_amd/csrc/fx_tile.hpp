@@ -24,7 +24,7 @@
 // loops, and a dozen getenv per enqueue is host time on their path.  fxamd_reload_env() (C ABI, tests only) reads them again.
 struct FxEnv {
    bool no_half, force_general, no_w16, no_byte_dfa, no_a8, no_spec, no_tiny, no_span, no_pack_first, no_adapt, multipass, no_cache, no_multi, multi_no_bytes, multi_inq, multi_serial,
-      host_register, multi_w16;
+      host_register, multi_w16, no_latch;
    int64_t slice_rows;                                      // rows per enqueue (a multiple of 64)
    int one_grid, one_round_mb, one_blocks, half_rounds, half_sch, span_lens;     // launch-grid experiments (0 = the built-in rule)
 };
@@ -501,7 +501,11 @@ struct FastParams {
    uint32_t out_mode;       // first passes that write PACKED results themselves (round 5: the half-row kernel of 256-byte rows, the span kernel):
                             // 0 = flags u8[n], from / to int32[n]; 1 / 2 / 4 = flag bit words + spans of that many bytes, and "this 64-row tile is left
                             // to the follow-up" goes to a byte per tile (`marks`) instead of the rows' flag bytes
+   uint32_t latch;          // 1: the LATCHED format of R (FXP_F_R_LATCH, program.h; round 6) -- the launcher picks the kernel's LATCH instantiation, the R
+                            // table is off_fastRL, hit_min = 4 (x 0x01010101: "latched"), and hit_base = the first hit state among the base states 0..3
+   uint32_t hit_base;
 };
+#define FX_LATCH_MASK 0x03030303u   // state & mask = the base state, latch cleared
 
 // 8 independent table lookups for 8 bytes.  Three table schemes share the kernels (template parameter SCH):
 //   0 v_perm       (<= 8 states): F = uint2 = the 8 next-state bytes of the symbol; step = ONE v_perm_b32.
@@ -545,8 +549,13 @@ struct FxF<2> {
 // identical copies), so whole registers compare like ids and no masking is needed.  Hit states have the LARGEST ids, so
 // the group's "any hit" is max(states) >= hit_min: one v_max3_u32 per two bytes instead of a compare+select per byte.
 // (LEAN: the running maximum instead of eight kept states -- four more v_max per group, five fewer live registers)
-template <class F, bool LEAN = false>
+template <class F, bool LEAN = false, bool LATCH = false>
 __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state, const uint8_t* T) {
+   if constexpr (LATCH) {   // (latched format of R: the group's last state says whether any of its states was a hit -- no maximum; the caller clears the latch)
+#pragma unroll
+      for (int i = 7; i >= 0; --i) state = fxstep(f[i], state, T);
+      return state;
+   }
    if constexpr (LEAN) {
       uint32_t m = 0;
 #pragma unroll
@@ -570,16 +579,16 @@ __device__ __forceinline__ uint32_t chain8_back(const F (&f)[8], uint32_t& state
 }
 
 // the same over only the first nv (1..7, wave-uniform) bytes of the group -- the end of a long row's last segment
-template <class F>
+template <class F, bool LATCH = false>
 __device__ __forceinline__ uint32_t chain8_back_n(const F (&f)[8], uint32_t& state, const uint8_t* T, uint32_t nv) {
    uint32_t mx = 0;
 #pragma unroll
    for (int i = 7; i >= 0; --i)
       if ((uint32_t)i < nv) {
          state = fxstep(f[i], state, T);
-         mx = max(mx, state);
+         if (!LATCH) mx = max(mx, state);
       }
-   return mx;
+   return LATCH ? state : mx;
 }
 
 // ---- on-device UTF-8 decode for the fast kernel (FXP_F_FAST_UTF8) -------------------------------------------------------
@@ -931,7 +940,7 @@ constexpr int fx_tile_cols() {
 // 256-byte segments.  For the chain tables only, whose one dependent LDS read per byte is latency-bound (17-state pattern over 1024-byte
 // rows: profiles/r04_half_chain_ab.txt); with the v_perm tables the backward pass is not what long rows wait for (0.562 -> 0.524 ms at
 // 1024 bytes, but 1.07 -> 1.17 ms at 400 and 0.493 -> 0.506 ms at 4096: not dispatched).
-template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false, bool NOHALF = false>
+template <int CH, bool SPANS, int MODE, int SCH, bool RAGGED, bool LONG = false, bool NOHALF = false, bool LATCH = false>
 __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 0) ? FX_HALF_WAVES : ((LONG && CH <= 8 && SPANS && FX_HALF4 != 0) ? 4 : 1)) void fx_search_fast(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog,
                                                         FastParams fp, uint8_t* __restrict__ flags, int32_t* __restrict__ from,
                                                         int32_t* __restrict__ to, uint32_t* __restrict__ n_deferred, uint32_t class_map_in_lds,
@@ -953,6 +962,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    constexpr bool HALF4 = FX_HALF4 != 0 && LONG && (CH == 8 || CH == 4) && SPANS && !DEFER;   // the four-waves-per-SIMD tuning of the half-row kernel (see FX_HALF4)
    static_assert(!LONG || ((CH == 16 || CH == 8 || CH == 4) && !RAGGED && (MODE == 0 || MODE == 2 || MODE == 3)), "long rows: CH 16, 8 or 4, first-pass / byte-level modes");
    constexpr bool CHAIN = SCH == 1, WIDE = SCH == 2;
+   static_assert(!LATCH || (HALF4 && SCH == 0 && MODE == 0 && CH == 8), "the latched format of R: the half-row first pass of 256-byte rows on the 8-state tables");
+   // a state of a RE-WALK (the latch was cleared at the group's start and may have been set by an earlier step): is its base state a hit state?  (group and
+   // leading-NUL tests compare with fp.hit_min as ever: in the latched format that is "latched", and they look at states whose predecessor was unlatched)
+   auto is_hit = [&](const uint32_t st) -> bool { return LATCH ? (st & FX_LATCH_MASK) >= fp.hit_base : st >= fp.hit_min; };
    constexpr bool LIST = MODE == 4, FIXUP = MODE == 1 || LIST, BYTES = MODE == 2 || MODE == 3, MARKED = MODE == 1 || MODE == 3;
    static_assert(!BYTES || (SCH != 0 && !RAGGED), "byte-level tables: chain or wide v_perm scheme, whole chunks");
    static_assert(!LIST || !RAGGED, "the worklist pass gathers whole-chunk rows");
@@ -997,7 +1010,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
    uint2 t_r = make_uint2(0, 0), t_a = make_uint2(0, 0);
    if (!CHAIN) {
       const FxpHeader* h0 = reinterpret_cast<const FxpHeader*>(prog);
-      t_r = reinterpret_cast<const uint2*>(prog + (WIDE ? (BYTES ? h0->off_bw16R : h0->off_w16R) : h0->off_fastR))[threadIdx.x];
+      t_r = reinterpret_cast<const uint2*>(prog + (WIDE ? (BYTES ? h0->off_bw16R : h0->off_w16R) : (LATCH ? h0->off_fastRL : h0->off_fastR)))[threadIdx.x];
       t_a = reinterpret_cast<const uint2*>(prog + (WIDE ? (BYTES ? h0->off_bw16A : h0->off_w16A) : h0->off_fastA))[threadIdx.x];
    }
    __builtin_amdgcn_sched_barrier(0);   // (the table reads stay ahead of the tiles' loads: their addresses wait for the header's offsets)
@@ -1389,9 +1402,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                __builtin_amdgcn_sched_barrier(0);
                if (nhi != 0u) {
                   const uint32_t entry = state;
-                  const uint32_t mx = nhi == 8u ? chain8_back<F, HALF4>(fa, state, TRp) : chain8_back_n(fa, state, TRp, nhi);
+                  const uint32_t mx = nhi == 8u ? chain8_back<F, HALF4, LATCH>(fa, state, TRp) : chain8_back_n<F, LATCH>(fa, state, TRp, nhi);
                   gloc = mx >= fp.hit_min ? (uint32_t)(2 * k + 1) : gloc;
                   esel = mx >= fp.hit_min ? entry : esel;
+                  if (LATCH) state &= FX_LATCH_MASK;
                   asm volatile("" : "+v"(esel));   // select now: otherwise all 2*CH entry states stay live until after the loop
                }
                __builtin_amdgcn_sched_barrier(0);
@@ -1404,9 +1418,10 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                __builtin_amdgcn_sched_barrier(0);
                if (nlo != 0u) {
                   const uint32_t entry = state;
-                  const uint32_t mx = nlo == 8u ? chain8_back<F, HALF4>(fb, state, TRp) : chain8_back_n(fb, state, TRp, nlo);
+                  const uint32_t mx = nlo == 8u ? chain8_back<F, HALF4, LATCH>(fb, state, TRp) : chain8_back_n<F, LATCH>(fb, state, TRp, nlo);
                   gloc = mx >= fp.hit_min ? (uint32_t)(2 * k) : gloc;
                   esel = mx >= fp.hit_min ? entry : esel;
+                  if (LATCH) state &= FX_LATCH_MASK;
                   asm volatile("" : "+v"(esel));
                }
                __builtin_amdgcn_sched_barrier(0);
@@ -1452,7 +1467,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
 #pragma unroll
                for (int i = 7; i >= 0; --i) {
                   st = fxstep(f[i], st, TRp);
-                  loc = st >= fp.hit_min ? (uint32_t)i : loc;
+                  loc = is_hit(st) ? (uint32_t)i : loc;
                }
                s_half = gsel != 0xFFFFFFFFu ? gsel * 8u + 2u + loc : 0u;
                if (SPANS && fp.lit_len == 0) {
@@ -1509,7 +1524,7 @@ __global__ __launch_bounds__(256, (LONG && CH == 8 && SPANS && FX_DEFER_LONG != 
                const uint32_t nx = fxstep(f[i], st, TRp);
                const bool on = !LONG || HALFROW || (uint32_t)i < nv;   // (per lane)
                st = on ? nx : st;
-               loc = on && nx >= fp.hit_min ? (uint32_t)i : loc;
+               loc = on && is_hit(nx) ? (uint32_t)i : loc;
             }
          }
          s = gsel != 0xFFFFFFFFu ? (here ? g * 8u + 2u + loc : s_half) : 0u;
@@ -2078,6 +2093,13 @@ hipError_t launch_fast(const uint8_t* rows, int64_t n, const uint8_t* d_blob, Fa
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
          }
+         if constexpr (CH == 8 && MODE == 0 && SCH == 0 && FX_HALF4 != 0 && FX_DEFER_LONG == 0) {
+            if (spans && fp.latch != 0u) {   // (the latched format of R: FXP_F_R_LATCH programs; same LDS, same grid)
+               hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHN, false, true, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
+               return hipGetLastError();
+            }
+         }
+         if (fp.latch != 0u) return hipErrorInvalidValue;   // (never dispatched: only the half-row first pass with spans reads the latched format)
          if (spans) hipLaunchKernelGGL((fx_search_fast<CH, true, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
          else hipLaunchKernelGGL((fx_search_fast<CH, false, MODE, CHN, false, true>), dim3((unsigned)blocks), dim3(256), lds, st, rows, n, d_blob, fp, flags, from, to, n_deferred, map_lds, Lr, clear_next, worklist);
          return hipGetLastError();

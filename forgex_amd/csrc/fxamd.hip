@@ -88,6 +88,7 @@ static void env_load() {
    e.multi_inq = on("FXAMD_MULTI_INQ");
    e.multi_serial = on("FXAMD_MULTI_SERIAL");
    e.host_register = on("FXAMD_HOST_REGISTER");
+   e.no_latch = on("FXAMD_NO_LATCH");   // the half-row first pass and the span kernel on the plain format of R (test / A-B hook; FXP_F_R_LATCH, program.h)
    e.multi_w16 = on("FXAMD_MULTI_W16");   // automata of 9..16 states (nibble tables) join the shared many-pattern pass (built and tested in round 6, OFF by default: measured no faster, see fxamd_match_multi_device)
    {
       const char* v = std::getenv("FXAMD_SLICE_ROWS");
@@ -653,6 +654,12 @@ static bool bytes_ok(const FxpHeader& h, const uint8_t* d_rows, int64_t row_len,
    return (size_t)4 * 64 * 16 * tile_cols_max(row_len) + 512 + h.byte_TR_bytes + h.byte_TA_bytes + 16 <= 150 * 1024;
 }
 
+// the latched format of R (FXP_F_R_LATCH): "latched" is state >= 4, a base state s is a hit state iff s >= fast_hitR_min
+static void latch_params(FastParams& fp, const FxpHeader& h) {
+   fp.latch = 1u;
+   fp.hit_min = 4u * 0x01010101u;
+   fp.hit_base = h.fast_hitR_min * 0x01010101u;
+}
 template <int MODE, int SCH>
 static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, const uint8_t* d_rows, int64_t n, int64_t row_len,
                                   uint8_t* d_flags, int32_t* d_from, int32_t* d_to, uint32_t* n_deferred, hipStream_t st, PassOpts po = PassOpts()) {
@@ -684,6 +691,9 @@ static hipError_t launch_fast_any(const FxpHeader& h, const uint8_t* d_blob, con
       fp.inv_on = 1u;
       fp.inv = WIDE ? h.R_inv : (CHAIN ? h.R_inv * h.chain_row_bytes : h.R_inv * 0x01010101u);
    }
+   // the half-row first pass of 256-byte rows with spans: the LATCHED format of R where the program has it (<= 4 states in R: FXP_F_R_LATCH, round 6)
+   if (MODE == 0 && SCH == 0 && po.half && row_len == 256 && d_from != nullptr && d_to != nullptr && (h.flags & FXP_F_R_LATCH) && !fx_env().no_latch)
+      latch_params(fp, h);
    // (rows longer than 256 bytes on the chain tables: 128-byte segments at four waves per SIMD -- fx_search_fast NOHALF; bit 3 of the hook)
    const bool long8 = CHAIN && (MODE == 0 || MODE == 2) && long_row(row_len) && (fx_env().half_sch & 8) != 0;
    switch ((po.half || long8) ? (row_len == 128 ? 4 : 8) : chunks_of(row_len)) {
@@ -993,6 +1003,7 @@ static int enqueue_batch_body(fxamd_program* p, const uint8_t* d_blob, DevScratc
          FastParams fps = params_of(h, 0, false);
          fps.defer_tiles = (fx_env().no_adapt || !utf8_tables) ? 1u : 3u;   // (bit 1: FX_ADAPT_CALLS -- batches that are mostly UTF-8 skip the first pass's loads)
          fps.out_mode = out_mode;
+         if ((h.flags & FXP_F_R_LATCH) && !fx_env().no_latch) latch_params(fps, h);   // (R of <= 4 states: its latched format, round 6)
          uint8_t* marks = nullptr;
          if (out_mode != 0u) {   // packed results: a byte per 64-row tile says "left to the follow-up" (in the worklist's memory: this pipeline lists no rows)
             const int rcw = grow_worklist(sc, (n >> 8) + 64);

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define FXP_MAGIC 0x31505846u /* "FXP1" */
-#define FXP_VERSION 16u
+#define FXP_VERSION 17u
 
 enum FxpMode {
    FXP_MODE_INVALID = 0,         // invalid pattern: every row is "no match" (reference forgex.F90:101-104)
@@ -48,6 +48,10 @@ enum FxpFlags {
    FXP_F_SUFFIX_CHECK = 1u << 22,   // ... and (with FXP_F_PREFIX_CHECK) a suffix literal that is not proven a necessary ending: the kernel also checks that the match it found
                                     // ends with the suffix literal, at least one byte behind the match's start -- what makes the driver's give-up / cut-off rules
                                     // (api_internal_m.F90:99-116) moot for this row (row_engine.hpp suffix_end_ok)
+   FXP_F_R_LATCH = 1u << 23,        // searches whose reverse automaton has <= 4 states (and no overlap state): R also exists in a LATCHED 8-state v_perm format
+                                    // (off_fastRL; round 6): states 0..3 as in off_fastR, states 4..7 = the same states once a hit state has been entered since
+                                    // the walker last cleared the latch (state & 3).  "Did any of this 8-byte group's states hit?" is then the group's LAST state
+                                    // >= 4 -- no running maximum over the group's states (4 of a group's 24 vector instructions in the half-row and span kernels)
    FXP_F_NEEDS_NONASCII = 1u << 20, // searches with byte-level tables: no non-empty match is made of ASCII symbols only -- a row without a byte >= 0x80 holds no match
    FXP_F_OVERLAP_SINK = 1u << 17,   // prefix literal with a border: R carries one absorbing state (R_inv) entered when two prefix occurrences overlap
    FXP_F_PREFIX_NECESSARY = 1u << 16,   // every non-empty match begins with the prefix literal (proven on A): a pure-ASCII row without it cannot match
@@ -118,6 +122,7 @@ struct FxpHeader {
    uint32_t off_b8A;      // uint8 [256][8]
    uint32_t b8_A_init, b8_acc_min;
    uint32_t R_inv;        // FXP_F_OVERLAP_SINK: that state of R (a row that ends its backward pass there is left to the general engine)
+   uint32_t off_fastRL;   // FXP_F_R_LATCH: uint8 [256][8], the latched format of off_fastR (fast_R_start is its start state too; base state s is a hit state iff s >= fast_hitR_min)
    uint32_t checksum;     // FNV-1a of the whole image with this field read as zero (fxc::blob_checksum); checked by fxamd_program_from_blob
 };
 

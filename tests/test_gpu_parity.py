@@ -1273,7 +1273,7 @@ def test_long_rows_last_bytes_of_a_tile(fx):
 
 @pytest.mark.parametrize("hook", ["", "FXAMD_MULTIPASS", "FXAMD_NO_A8", "FXAMD_NO_BYTE_DFA", "FXAMD_NO_W16", "FXAMD_NO_HALF", "FXAMD_FORCE_GENERAL",
                                   "FXAMD_NO_TINY", "FXAMD_NO_SPEC", "FXAMD_HALF_SCH=1", "FXAMD_HALF_SCH=7", "FXAMD_NO_ADAPT", "FXAMD_NO_SPAN", "FXAMD_SPAN_LENS=31",
-                                  "PACKED", "PACKED+FXAMD_NO_PACK_FIRST", "PACKED+FXAMD_NO_SPAN"])
+                                  "PACKED", "PACKED+FXAMD_NO_PACK_FIRST", "PACKED+FXAMD_NO_SPAN", "FXAMD_NO_LATCH", "PACKED+FXAMD_NO_LATCH"])
 def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
     """tests/golden/config_rows.tsv: the REAL reference's flag / from / to (recorded in the container by
     tests/golden/make_config_goldens.py through oracle/_ref/ref_driver) on 2000-6144 rows of each BASELINE config (first and last
@@ -1291,6 +1291,8 @@ def test_config_scale_rows_vs_real_reference_fixture(fx, hook, monkeypatch):
     #  default set, the adaptive first pass off, the span kernel off / also for programs with byte-level tables -- and the fixture's
     #  round-5 sections: rows of 2..32 bytes, chain / nibble tables over 256- and 128-byte rows, a chain program over 400- and 1024-byte
     #  rows, speculative-pass rows)
+    # (round 6: the half-row first pass and the span kernel walk the LATCHED format of R by default where the program has one -- configs 3 and 5 do --
+    #  FXAMD_NO_LATCH: the plain format)
     # (round 6, VERDICT r05: the PACKED entry -- fxamd_match_batch_device_packed, what a multi-GPU host gathers or has written peer-direct -- against the
     #  real reference's answers too: images straight from the first passes, through fx_pack, and from the one-launch kernel; unpacked on the device)
     packed = hook.startswith("PACKED")
