@@ -203,6 +203,7 @@ void fxamd_f_match_batch_host(fxamd_program* p, const uint8_t* h_rows, int64_t n
  * bytes of LDS take path 18; bit 4 = candidate-list driver programs too at rows of up to 64 bytes; bit 5 = ragged rows, any length 2..127 that
  * is not one of the four; bit 6 = path 20),
  * FXAMD_NO_PACK_FIRST (packed results through fx_pack instead of straight from the first passes),
+ * FXAMD_NO_LATCH (the half-row first pass and the span kernel walk the plain format of the reverse automaton, not its latched one: program.h FXP_F_R_LATCH),
  * FXAMD_HALF_SCH (bit s: table scheme s -- 0 v_perm, 1 chain, 2 nibble -- takes half rows; bit 3: 128-byte segments of long chain rows;
  * bit 4: 128-byte rows on the chain tables in 64-byte halves);
  * grid experiments: FXAMD_ONE_GRID, FXAMD_ONE_ROUND_MB, FXAMD_ONE_BLOCKS, FXAMD_HALF_ROUNDS.  They are read once
