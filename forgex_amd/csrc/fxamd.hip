@@ -1497,6 +1497,7 @@ int fxamd_launch_fast_only(fxamd_program* p, const uint8_t* d_rows, int64_t n, i
    if (!po.half && n > 0 && span_kind(h, scheme, row_len, d_from != nullptr)) {   // the span kernel's first pass
       FastParams fps = params_of(h, 0, false);
       fps.defer_tiles = 1u;
+      if ((h.flags & FXP_F_R_LATCH) && !fx_env().no_latch) latch_params(fps, h);   // (the instantiation the product's call launches)
       switch (span_cell(row_len)) {
          case 128: FX_HIP((launch_span<128, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr, (uint32_t)row_len))); break;
          case 64: FX_HIP((launch_span<64, 0>(d_rows, n, d_blob, fps, d_flags, d_from, d_to, ctr, (hipStream_t)hip_stream, nullptr, (uint32_t)row_len))); break;
