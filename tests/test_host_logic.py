@@ -262,6 +262,32 @@ def test_corrupt_blobs_are_rejected(built):
             assert load(fixed(bytes(b))) == -4
             n_bad += 1
     assert n_bad > 40
+    # the LATCHED format of the reverse automaton (FXP_F_R_LATCH, program.h; round 6): configs 3 and 4 carry it (R of 3 / 2 states), config 2 (7) does not;
+    # it is the plain table doubled -- a step from a state below 4 goes where the plain table goes (+ 4 when that is a hit state), a step from 4 + s where the
+    # plain table sends s, + 4 -- and an image whose latched state unlatches, or whose flag claims a table that is not there, is refused
+    for cfg, want in (("cfg3", True), ("cfg4", True), ("cfg2", False)):
+        good = fx.Program(synth.PATTERNS[cfg], fx.OP_SEARCH).blob()
+        flags = struct.unpack_from("<I", good, FIELDS["flags"])[0]
+        assert bool(flags & (1 << 23)) == want, (cfg, hex(flags))
+        if not want:
+            continue
+        orl, orp = struct.unpack_from("<I", good, FIELDS["off_fastRL"])[0], struct.unpack_from("<I", good, FIELDS["off_fastR"])[0]
+        hitmin, nR = struct.unpack_from("<I", good, FIELDS["fast_hitR_min"])[0], struct.unpack_from("<I", good, FIELDS["nR"])[0]
+        assert nR <= 4
+        for sym in range(256):
+            for st in range(4):
+                d = good[orp + 8 * sym + st]
+                assert good[orl + 8 * sym + st] == (d + 4 if hitmin <= d < nR else d), (cfg, sym, st)
+                assert good[orl + 8 * sym + 4 + st] == d + 4, (cfg, sym, st)
+        b = bytearray(good)
+        b[orl + 8 * ord("a") + 5] = 1                                  # a latched state that unlatches
+        assert load(fixed(bytes(b))) == -4
+        b = bytearray(good)
+        b[orl + 8 * ord("a") + 1] = 9                                  # not a state
+        assert load(fixed(bytes(b))) == -4
+        b = bytearray(good)
+        struct.pack_into("<I", b, FIELDS["off_fastRL"], len(good) - 100)   # the table does not fit
+        assert load(fixed(bytes(b))) == -4
     # NFA-simulation program: nfa_words = 0 must not reach the launch code (it divides by the per-row scratch size)
     good = fx.Program(r"[ab]*a[ab]{20}", fx.OP_SEARCH).blob()
     assert load(good) == 0
@@ -420,12 +446,17 @@ _ONE_SIG = "(const uint8_t*, int64_t, const uint8_t*, FastParams, FastParams, ui
 _SPAN_SIG = "(const uint8_t*, const int64_t, const uint8_t*, const FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, uint32_t*, uint8_t*, const uint32_t)"
 _FAST_SIG = "(const uint8_t*, int64_t, const uint8_t*, FastParams, uint8_t*, int32_t*, int32_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*)"
 _DEFAULT_PATH_KERNELS = [
-    ("fx_tile.hpp", "fx_search_fast", "8, true, 0, 0, false, true", _FAST_SIG),              # config 3: half-row first pass
+    ("fx_tile.hpp", "fx_search_fast", "8, true, 0, 0, false, true", _FAST_SIG),              # config 3: half-row first pass (plain format of R: FXAMD_NO_LATCH, R of 5..8 states)
+    ("fx_tile.hpp", "fx_search_fast", "8, true, 0, 0, false, true, false, true", _FAST_SIG), # ... on the LATCHED format of R (round 6: what config 3 runs)
     ("fx_one.hpp", "fx_search_one", "16, true, 0, 3, false, false, true", _ONE_SIG),         # ... its gated follow-up
     ("fx_one.hpp", "fx_search_one", "4, true, 0, 3, false, true", _ONE_SIG),                 # config 2
     ("fx_one.hpp", "fx_search_one", "12, true, 0, 3, false, false", _ONE_SIG),               # config 4
-    ("fx_span.hpp", "fx_search_span", "128, 0, false, false", _SPAN_SIG),                    # config 5's shard
+    ("fx_span.hpp", "fx_search_span", "128, 0, false, false", _SPAN_SIG),                    # config 5's shard (plain format of R)
+    ("fx_span.hpp", "fx_search_span", "128, 0, false, false, true", _SPAN_SIG),              # ... on the latched format (what config 5 runs)
     ("fx_span.hpp", "fx_search_span", "128, 0, true, false", _SPAN_SIG),                     # ... packed (what an 8-GPU run gathers)
+    ("fx_span.hpp", "fx_search_span", "128, 0, true, false, true", _SPAN_SIG),
+    ("fx_span.hpp", "fx_search_span", "16, 0, false, false, true", _SPAN_SIG),               # K = 8 rows per lane, latched
+    ("fx_span.hpp", "fx_search_span", "32, 0, false, true, true", _SPAN_SIG),                # ragged rows, latched
     ("fx_span.hpp", "fx_search_span", "16, 0, false, false", _SPAN_SIG),                     # K = 8 rows per lane (scratch in round 5)
     ("fx_span.hpp", "fx_search_span", "16, 0, true, false", _SPAN_SIG),
     ("fx_span.hpp", "fx_search_span", "16, 2, false, false", _SPAN_SIG),
@@ -478,6 +509,7 @@ def test_default_path_kernels_use_no_scratch_memory():
     assert not bad, bad
     occ = {(k[1], k[2]): r["occ"] for k, r in zip(_DEFAULT_PATH_KERNELS, res)}
     assert occ[("fx_search_fast", "8, true, 0, 0, false, true")] >= 4 and occ[("fx_search_span", "128, 0, false, false")] >= 4, occ
+    assert occ[("fx_search_fast", "8, true, 0, 0, false, true, false, true")] >= 4 and occ[("fx_search_span", "128, 0, false, false, true")] >= 4, occ
     assert occ[("fx_search_span", "16, 0, false, false")] >= 4 and occ[("fx_search_span", "32, 0, false, true")] >= 4, occ
     assert occ[("fx_search_one", "8, true, 0, 3, true, false")] >= 3, occ
     ru_dir = os.path.join(golden.ROOT, "forgex_amd", "csrc", "build_ru")
