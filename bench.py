@@ -457,6 +457,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--oracle-seconds", type=float, default=20.0,
+                    help="time budget of the oracle leg of the whole-batch parity check (oracle/liboracle.so over as many rows as fit; ~70 s cover all of config 3 on the GPU box's 256 cores)")
     ap.add_argument("--warmup", type=int, default=30,
                     help="untimed steps first; the clocks settle over the first ~20-30 back-to-back launches after an idle gap (DESIGN.md 4.1)")
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
@@ -803,7 +805,7 @@ def main():
             except Exception as e:
                 line["parity"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
             try:   # ... and against the oracle, which shares no matching code with the product (as many rows as ~20 s of this host allow)
-                line["parity"]["oracle"] = oracle_parity(pattern, rows, flags, frm, to, threads)
+                line["parity"]["oracle"] = oracle_parity(pattern, rows, flags, frm, to, threads, budget_s=args.oracle_seconds)
             except Exception as e:
                 line["parity"]["oracle"] = {"rows": 0, "mismatches": None, "checker": "failed: %r" % (e,)}
             # every OTHER rank's shard as it arrived on the root: the gathered + unpacked image against the host walker on that shard's
