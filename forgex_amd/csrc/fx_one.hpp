@@ -1003,7 +1003,7 @@ static __device__ unsigned long long fx_one_stamp_buf[FX_STAMP_MAX_WAVES * FX_ST
 #define FX_ONE_ROWS_FIRST 0   // (1: the first tile's loads before the table reads -- measured SLOWER, see the start-up comment in the kernel)
 #endif
 template <int CH, bool SPANS, int SCH, int BSCH, bool RAGGED, bool GEN, bool MARKED = false, bool MATCH = false>
-__global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : ((CH == 16 && BSCH == 3 && !RAGGED && !GEN && !MARKED && !MATCH) ? 2 : 1)))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
+__global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || CH == 8) ? 3 : ((CH == 16 && SCH == 0 && BSCH != 0 && !RAGGED && !GEN && !MARKED && !MATCH) ? 2 : 1)))) void fx_search_one(const uint8_t* __restrict__ rows, int64_t n, const uint8_t* __restrict__ prog, FastParams fp,
                                                        FastParams fpb, uint8_t* __restrict__ flags, int32_t* __restrict__ from, int32_t* __restrict__ to,
                                                        uint32_t class_map_in_lds, uint32_t Lr, uint32_t out_mode, const uint32_t* __restrict__ gate = nullptr,
                                                        const uint8_t* __restrict__ marks = nullptr) {
@@ -1434,9 +1434,9 @@ __global__ __launch_bounds__(256, (FX_ONE_MINW > 1 ? FX_ONE_MINW : ((CH == 6 || 
       // the byte-level scan (a 64-lane backward + forward pass for a handful of rows, which then finds the structure error and queues them AGAIN for a
       // second gather): the in-LDS decode + the chunk-parallel scan of fx_few.hpp answer every row, broken or not, in a fraction of the instructions
       // (round 6; FX_SPEC_FEW_GROUPS groups of 64 / CH rows)
-      // (not the whole-batch kernel of 256-byte rows with the speculative pass: with the chunk-parallel scan's 32 table registers it needed 262 registers -- ONE wave
+      // (not the whole-batch kernels of 256-byte rows: with the chunk-parallel scan's 32 table registers they needed 260-262 registers -- ONE wave
       //  per SIMD where the comment below promised two; without it 228.  Its marked-tile sibling, the half-row pipeline's follow-up, has both at 239.)
-      constexpr bool FEW_OK = SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0 && !RAGGED && !GEN && !(CH == 16 && BSCH == 3 && !MARKED);
+      constexpr bool FEW_OK = SCH == 0 && HAS_B && !MATCH && CH >= 12 && FX_FEW_ROWS != 0 && !RAGGED && !GEN && !(CH == 16 && !MARKED);
       const bool spec_few = FEW_OK && SPEC && spec_gather && take <= (uint32_t)FX_SPEC_FEW_GROUPS * fx_few_rows_max<CH>();
       if constexpr (HAS_B) {
          if ((is_tile && (ALLB || nonascii)) || (spec_gather && !spec_few)) {
